@@ -1,0 +1,45 @@
+# Builds the MI355X linearization library and (optionally) the test-only oracle.
+#
+#   make            -> moptimizer_0_amd/lib/libmoptimizer_hip.so   (gfx950 code object + C ABI)
+#   make oracle     -> oracle/_build/{liboracle.so,replay_reference_tests}   (CPU checker)
+#   make cpptests   -> tests/cpp/_build/*                           (C++ drop-in programs)
+#
+# hipcc cross-compiles for gfx950 without a GPU present.
+HIPCC      ?= /opt/rocm/bin/hipcc
+ARCH       ?= gfx950
+ROCM       ?= /opt/rocm
+HIPFLAGS   ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function
+INCLUDES    = -Iinclude -Imoptimizer_0_amd/csrc
+CSRC        = moptimizer_0_amd/csrc
+OBJDIR      = build/obj
+LIBDIR      = moptimizer_0_amd/lib
+LIB         = $(LIBDIR)/libmoptimizer_hip.so
+
+PUBLIC_HEADERS = include/moptimizer_hip.h include/moptimizer_amd/so3.hpp $(CSRC)/sweep.hpp
+
+all: $(LIB)
+
+$(OBJDIR) $(LIBDIR):
+	mkdir -p $@
+
+$(OBJDIR)/sweep_kernels.o: $(CSRC)/sweep_kernels.hip $(PUBLIC_HEADERS) | $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) $(INCLUDES) -c $< -o $@
+
+$(OBJDIR)/c_abi.o: $(CSRC)/c_abi.cpp $(PUBLIC_HEADERS) | $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) $(INCLUDES) -x hip -c $< -o $@
+
+$(LIB): $(OBJDIR)/sweep_kernels.o $(OBJDIR)/c_abi.o | $(LIBDIR)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -L$(ROCM)/lib -lrccl \
+	    -Wl,-rpath,$(ROCM)/lib -Wl,--no-undefined
+
+oracle:
+	$(MAKE) -C oracle all
+
+cpptests: $(LIB)
+	$(MAKE) -C tests/cpp all
+
+clean:
+	rm -rf build $(LIBDIR) tests/cpp/_build
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle cpptests clean

@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Benchmark of the linearization hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A *step* is one LM linearization sweep as the optimizer sees it: for the current parameter
+vector x, every rank runs the point-to-point analytic linearize kernels over its resident shard,
+the 43 partial sums (H 6x6 | b | cost) are combined with one RCCL all-reduce when N > 1, and the
+result is brought to the host (LM needs it there before it can choose the next x).  x changes
+every step.  Inputs are synthetic (seed 42) and already resident in HBM when timing starts.
+
+Workload: BASELINE.json quotes its metric at N = 10 M correspondences, which fits one GPU, so
+each GPU holds 10 M correspondences (480 MB fp64, larger than the 256 MiB Infinity Cache so the
+sweep really streams from HBM).  Per-GPU work is fixed as N grows ("weak" scaling).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) including
+  roofline     — achieved algorithmic GB/s of the dominant (sweep) kernel from HIP events
+                 recorded around each launch on the launch stream, vs the 8 TB/s HBM3E peak
+  cpu_baseline — the CPU restatement of the reference's single-threaded linearize
+                 (oracle/, kind "port") timed on this box's host cores on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BYTES_PER_CORRESPONDENCE = {8: 48, 4: 24}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--n", type=int, default=10_000_000, help="correspondences PER GPU")
+    ap.add_argument("--mode", choices=["analytic", "analytic_tst", "numeric"], default="analytic")
+    ap.add_argument("--variant", choices=["auto", "literal", "moments"], default="auto")
+    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0,
+                    help="target CPU time of the cpu_baseline sample")
+    return ap.parse_args()
+
+
+def make_shard_on_gpu(torch, n, rank, dtype):
+    """src ~ U[0,10]^3, tgt = R src + t + N(0, 0.01^2) with the fixture pose of
+    tst/point2point.cpp:93-101; generated on the device so nothing crosses PCIe."""
+    from tests import datasets as ds
+    g = torch.Generator(device="cuda")
+    g.manual_seed(42 + rank)
+    src = torch.rand((n, 3), generator=g, device="cuda", dtype=torch.float64) * 10.0
+    R = torch.tensor(ds.fixture_rotation(), device="cuda", dtype=torch.float64)
+    t = torch.tensor(ds.FIXTURE_T, device="cuda", dtype=torch.float64)
+    tgt = src @ R.T + t + 0.01 * torch.randn((n, 3), generator=g, device="cuda",
+                                              dtype=torch.float64)
+    return src.to(dtype).contiguous(), tgt.to(dtype).contiguous()
+
+
+def cpu_baseline(src_host, tgt_host, x, jac_mode, target_seconds):
+    """Single-threaded restatement of the reference's linearize (the reference loop is
+    single-threaded: linearization.h:97,142) on a bounded prefix of the same workload."""
+    from tests import oracle_binding as ob
+    oracle = ob.load()
+    cost_class = ob.NUMERIC_DYN if jac_mode == 2 else ob.ANALYTIC_DYN
+    layout = ob.LAYOUT_TST if jac_mode == 1 else ob.LAYOUT_ROW_MAJOR
+    probe = min(200_000, src_host.shape[0])
+    t0 = time.perf_counter()
+    oracle.p2p_linearize(src_host[:probe], tgt_host[:probe], x, cost_class=cost_class, layout=layout)
+    rate = probe / max(time.perf_counter() - t0, 1e-9)
+    sample = int(min(src_host.shape[0], max(probe, rate * target_seconds)))
+    t0 = time.perf_counter()
+    oracle.p2p_linearize(src_host[:sample], tgt_host[:sample], x, cost_class=cost_class,
+                         layout=layout)
+    dt = time.perf_counter() - t0
+    return {
+        "value": sample / dt,
+        "unit": "correspondences/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": "first %d correspondences of rank 0's shard, 1 sweep, %.1f s" % (sample, dt),
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    import moptimizer_0_amd as mo
+    from moptimizer_0_amd.sharded import gpu_point2point_sweep
+    from tests import datasets as ds
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    np_dtype = np.float64 if args.dtype == "f64" else np.float32
+    t_dtype = torch.float64 if args.dtype == "f64" else torch.float32
+    scalar_bytes = np.dtype(np_dtype).itemsize
+    jac_mode = {"analytic": mo.JAC_ANALYTIC, "analytic_tst": mo.JAC_ANALYTIC_TST_LAYOUT,
+                "numeric": mo.JAC_NUMERIC}[args.mode]
+
+    src, tgt = make_shard_on_gpu(torch, args.n, rank, t_dtype)
+    torch.cuda.synchronize()
+    cost = mo.Point2PointCost(src.data_ptr(), tgt.data_ptr(), device=local_rank, dtype=np_dtype,
+                              device_ptrs=True, count=args.n)
+    cost.set_kernel_variant({"auto": mo.KERNEL_AUTO, "literal": mo.KERNEL_LITERAL,
+                             "moments": mo.KERNEL_MOMENTS}[args.variant])
+    keep_host = (rank == 0 and world == 1 and not args.no_cpu_baseline)
+    if keep_host:
+        head = min(args.n, 4_000_000)
+        src_host = src[:head].double().cpu().numpy()
+        tgt_host = tgt[:head].double().cpu().numpy()
+    del src, tgt
+    torch.cuda.empty_cache()
+
+    sweep = gpu_point2point_sweep(cost)
+    x_base = ds.X_GENERIC.astype(np_dtype)
+
+    def step(k):
+        x = x_base + np_dtype(1e-4) * np_dtype(k % 16)
+        return sweep.linearize(x, jac_mode)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    barrier()
+    cost.set_profiling(True)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        H, b, s = step(k)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    sweep_ms, launches = cost.profile()
+    cost.set_profiling(False)
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        total = args.n * world
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total * args.steps / elapsed
+        kernel_ms = sweep_ms / max(launches, 1)
+        achieved = args.n * BYTES_PER_CORRESPONDENCE[scalar_bytes] / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("%s_%s_n%d" % (args.mode, args.dtype, args.n))
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "point-correspondences/sec per LM linearization sweep; % HBM peak",
+            "value": value,
+            "unit": "correspondences/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {
+                "workload": "point2point %s Jacobian, %d correspondences per GPU (%s), "
+                            "linearize + %s + result to host each step"
+                            % (args.mode, args.n, args.dtype,
+                               "RCCL all-reduce of 43 fp64" if world > 1 else "no collective"),
+                "correspondences_per_gpu": args.n,
+                "total_correspondences": total,
+                "parallelism": "shard%d" % world,
+                "kernel_variant": args.variant,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "kernel_ms": kernel_ms,
+                "kernel_launches": launches,
+            },
+            "pct_hbm_peak": 100.0 * achieved / HBM_PEAK_GBS,
+            "check": {"sum_sq": float(s), "H00": float(H[0, 0])},
+        }
+        if keep_host:
+            line["cpu_baseline"] = cpu_baseline(src_host, tgt_host, ds.X_GENERIC, jac_mode,
+                                                args.cpu_seconds)
+        elif world == 1:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+
+    cost.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,250 @@
+// The caller of the linearization path: Levenberg-Marquardt over a list of cost functions.
+//
+// Not accelerated and not part of the GPU work; it is restated (without Eigen) only so that
+// this repository can drive the HIP-backed costs end to end and replay the reference's
+// known-answer tests.  In the reference tree the original files are used unchanged
+// (see INTEGRATION.md).
+//
+// Behaviour follows /root/reference:
+//   Optimizer<Scalar>                  include/moptimizer/optimizer.h:12-89
+//   LevenbergMarquadtDynamic<Scalar>   include/moptimizer/levenberg_marquadt_dyn.h:8-50,
+//                                      src/levenberg_marquadt_dyn.cpp:7-127
+//   isDeltaSmall                       include/moptimizer/delta.h:10-16
+//   duna::Logger (subset)              include/moptimizer/logger.h:12-65
+#pragma once
+
+#include <cmath>
+#include <iostream>
+#include <limits>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "moptimizer_amd/dense.hpp"
+#include "moptimizer_amd/host_api.hpp"
+
+namespace duna {
+// Level-filtered line logger; only what the optimizer uses.
+class Logger {
+ public:
+  enum VERBOSITY_LEVEL { L_ERROR, L_WARN, L_INFO, L_DEBUG };
+
+  explicit Logger(std::ostream &sink, VERBOSITY_LEVEL level = L_ERROR,
+                  const std::string &name = "logger")
+      : sink_(&sink), level_(level), name_(name) {}
+
+  template <typename... Args>
+  void log(VERBOSITY_LEVEL level, Args &&...args) const {
+    if (level > level_) return;
+    static const char *const tags[] = {"ERROR", "WARN", "INFO", "DEBUG"};
+    std::ostringstream line;
+    line << '[' << tags[level] << "] duna::" << name_ << "::";
+    (line << ... << args);
+    line << '\n';
+    (*sink_) << line.str();
+  }
+  void setLogLevel(VERBOSITY_LEVEL level) { level_ = level; }
+
+ private:
+  std::ostream *sink_;
+  VERBOSITY_LEVEL level_;
+  std::string name_;
+};
+}  // namespace duna
+
+namespace moptimizer {
+
+template <class Scalar>
+inline bool isDeltaSmall(const dense::Vector<Scalar> &delta) {
+  return delta.maxAbsCoeff() < std::sqrt(std::numeric_limits<Scalar>::epsilon());
+}
+
+template <class Scalar = double>
+class Optimizer {
+ public:
+  using Ptr = std::shared_ptr<Optimizer>;
+  using ConstPtr = std::shared_ptr<const Optimizer>;
+  using CostFunctionType = CostFunctionBase<Scalar>;
+
+  Optimizer()
+      : maximum_iterations_(15),
+        executed_iterations_(0),
+        logger_(std::make_shared<duna::Logger>(std::cout, duna::Logger::L_ERROR, "Optimizer")) {}
+  Optimizer(const Optimizer &) = delete;
+  Optimizer &operator=(const Optimizer &) = delete;
+  virtual ~Optimizer() = default;
+
+  bool isCostSmall(Scalar cost_sum) const {
+    return std::fabs(cost_sum) < Scalar(8) * std::numeric_limits<Scalar>::epsilon();
+  }
+
+  void setMaximumIterations(int max_iterations) {
+    if (max_iterations < 0)
+      throw std::invalid_argument("Optimization::max_iterations cannot be less than 0.");
+    maximum_iterations_ = static_cast<unsigned int>(max_iterations);
+  }
+  unsigned int getMaximumIterations() const { return maximum_iterations_; }
+  unsigned int getExecutedIterations() const { return executed_iterations_; }
+
+  bool checkCosts() const {
+    if (costs_.empty()) {
+      std::cerr << "No cost function added!\n";
+      throw std::runtime_error("No cost function added!");
+    }
+    return true;
+  }
+
+  // Non-owning; the cost must outlive the optimizer's use of it.
+  void addCost(CostFunctionType *cost) { costs_.push_back(cost); }
+  void clearCosts(bool delete_costs = false) {
+    if (delete_costs)
+      for (auto *c : costs_) delete c;
+    costs_.clear();
+  }
+
+  virtual OptimizationStatus step(Scalar *x0) = 0;
+  virtual OptimizationStatus minimize(Scalar *x0) = 0;
+
+ protected:
+  virtual bool hasConverged() = 0;
+  virtual void prepare(Scalar *x0) = 0;
+
+  std::vector<CostFunctionType *> costs_;
+  unsigned int maximum_iterations_;
+  unsigned int executed_iterations_;
+  std::shared_ptr<duna::Logger> logger_;
+};
+
+template <class Scalar>
+class LevenbergMarquadtDynamic : public Optimizer<Scalar> {
+ public:
+  using HessianType = dense::Matrix<Scalar>;
+  using ParametersType = dense::Vector<Scalar>;
+
+  explicit LevenbergMarquadtDynamic(int num_parameters)
+      : num_parameters_(num_parameters), lm_max_iterations_(3), x0_(nullptr) {}
+  ~LevenbergMarquadtDynamic() override = default;
+
+  OptimizationStatus step(Scalar *) override { return OptimizationStatus::NUMERIC_ERROR; }
+
+  OptimizationStatus minimize(Scalar *x0) override {
+    this->checkCosts();
+    this->prepare(x0);
+    const int n = num_parameters_;
+
+    for (executed_iterations_ = 0; executed_iterations_ < maximum_iterations_;
+         ++executed_iterations_) {
+      logger_->log(duna::Logger::L_DEBUG, "Iteration: ", executed_iterations_, '/',
+                   maximum_iterations_);
+
+      // --- one linearization sweep per cost: this is the hot path ---------------------
+      Scalar y0 = 0;
+      hessian_.setZero();
+      b_.setZero();
+      for (std::size_t ci = 0; ci < costs_.size(); ++ci) {
+        cost_hessian_.setZero();
+        cost_b_.setZero();
+        costs_[ci]->update(x0);
+        const Scalar cost_y = costs_[ci]->linearize(x0, cost_hessian_.data(), cost_b_.data());
+        logger_->log(duna::Logger::L_DEBUG, "Cost(", ci, ") = ", cost_y);
+        y0 += cost_y;
+        hessian_ += cost_hessian_;
+        b_ += cost_b_;
+      }
+
+      if (this->isCostSmall(y0)) return OptimizationStatus::CONVERGED;
+
+      Scalar max_diag = 0;
+      for (int i = 0; i < n; ++i) max_diag = std::max(max_diag, std::fabs(hessian_(i, i)));
+      if (lm_lambda_ < Scalar(0)) lm_lambda_ = lm_init_lambda_factor_ * max_diag;
+
+      Scalar nu = 2;
+      logger_->log(duna::Logger::L_DEBUG,
+                   "Internal Iteration --- : it | max | prev_cost | new_cost | rho | lambda| nu");
+
+      for (unsigned int k = 0; k < lm_max_iterations_; ++k) {
+        // (H + lambda diag(H)) delta = -b
+        HessianType damped = hessian_;
+        for (int i = 0; i < n; ++i) damped(i, i) += lm_lambda_ * hessian_(i, i);
+        ParametersType rhs(n, 1);
+        for (int i = 0; i < n; ++i) rhs[i] = -b_[i];
+        delta_ = dense::PivotedLDLT<Scalar>(damped).solve(rhs);
+
+        // Euclidean update (the reference leaves the manifold update as a TODO, :82-83)
+        for (int i = 0; i < n; ++i) xi_[i] = x0[i] + delta_[i];
+
+        Scalar yi = 0;
+        for (auto *cost : costs_) yi += cost->computeCost(xi_.data());
+
+        if (std::isnan(yi)) {
+          logger_->log(duna::Logger::L_ERROR, "Numeric Error!");
+          return OptimizationStatus::NUMERIC_ERROR;
+        }
+
+        Scalar predicted = 0;
+        for (int i = 0; i < n; ++i) predicted += delta_[i] * (lm_lambda_ * delta_[i] - b_[i]);
+        const Scalar rho = (y0 - yi) / predicted;
+        logger_->log(duna::Logger::L_DEBUG, "Internal Iteration --- : ", k + 1, '/',
+                     lm_max_iterations_, ' ', y0, ' ', yi, ' ', rho, ' ', lm_lambda_, ' ', nu);
+
+        if (rho < 0) {
+          if (isDeltaSmall(delta_)) {
+            logger_->log(duna::Logger::L_DEBUG, "## Small delta reached: ", delta_.maxAbsCoeff());
+            return this->isCostSmall(yi) ? OptimizationStatus::CONVERGED
+                                         : OptimizationStatus::SMALL_DELTA;
+          }
+          lm_lambda_ = nu * lm_lambda_;
+          nu = 2 * nu;
+          continue;
+        }
+
+        for (int i = 0; i < n; ++i) x0[i] = xi_[i];
+        const double shrink = std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * double(rho) - 1.0, 3));
+        lm_lambda_ = static_cast<Scalar>(lm_lambda_ * shrink);
+        break;
+      }
+    }
+    return OptimizationStatus::MAXIMUM_ITERATIONS_REACHED;
+  }
+
+  void setLogger(std::shared_ptr<duna::Logger> logger) { logger_ = std::move(logger); }
+  unsigned int getLevenbergMarquadtIterations() const { return lm_max_iterations_; }
+  void setLevenbergMarquadtIterations(int max_iterations) { lm_max_iterations_ = max_iterations; }
+
+ protected:
+  bool hasConverged() override { return false; }
+  void prepare(Scalar *x0) override {
+    lm_init_lambda_factor_ = Scalar(1e-9);
+    lm_lambda_ = Scalar(-1);
+    x0_ = x0;
+    const int n = num_parameters_;
+    xi_.resize(n, 1);
+    b_.resize(n, 1);
+    delta_.resize(n, 1);
+    hessian_.resize(n, n);
+    cost_hessian_.resize(n, n);
+    cost_b_.resize(n, 1);
+  }
+
+  using Optimizer<Scalar>::costs_;
+  using Optimizer<Scalar>::maximum_iterations_;
+  using Optimizer<Scalar>::executed_iterations_;
+  using Optimizer<Scalar>::logger_;
+
+  int num_parameters_;
+  Scalar lm_init_lambda_factor_ = Scalar(1e-9);
+  Scalar lm_lambda_ = Scalar(-1);
+  unsigned int lm_max_iterations_;
+
+  Scalar *x0_;
+  HessianType hessian_;
+  ParametersType b_;
+  ParametersType xi_;
+  HessianType cost_hessian_;
+  ParametersType cost_b_;
+  ParametersType delta_;
+};
+
+}  // namespace moptimizer

@@ -1,0 +1,94 @@
+// x = (tx, ty, tz, wx, wy, wz)  ->  rigid transform [ Exp(w) t ; 0 1 ].
+//
+// Host-side, evaluated once per parameter vector (1x per analytic sweep, 1+n per
+// forward-difference sweep) and handed to the kernels by value, so the device never calls
+// sin/cos and every rank sees bit-identical R, t.
+//
+// Follows the behaviour of so3::convert6DOFParameterToMatrix and so3::Exp(Ref, Ref) in
+// /root/reference/src/so3.cpp:7-19 and :43-57: theta = |w|; for theta > 10*eps the rotation is
+// Rodrigues' I + sin(theta) K + (1 - cos(theta)) K^2 with K = skew(w / theta)
+// (skew layout: include/moptimizer/so3.h:4); otherwise the identity.  K^2 is expanded in closed
+// form here (K^2 = a a^T - I for a unit axis a).
+#pragma once
+
+#include <cmath>
+#include <limits>
+
+namespace moptimizer {
+namespace so3 {
+
+// Row-major 3x4 [R | t]; what the kernels consume.
+template <typename Scalar>
+struct Rigid3 {
+  Scalar m[12];
+  Scalar r(int i, int j) const { return m[i * 4 + j]; }
+  Scalar t(int i) const { return m[i * 4 + 3]; }
+};
+
+template <typename Scalar>
+inline void expSO3(const Scalar *w, Scalar R[9] /* row-major */) {
+  const Scalar theta = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  if (theta > Scalar(10) * std::numeric_limits<Scalar>::epsilon()) {
+    const Scalar ax = w[0] / theta, ay = w[1] / theta, az = w[2] / theta;
+    const Scalar s = std::sin(theta);
+    const Scalar c1 = Scalar(1) - std::cos(theta);
+    // K = [[0,-az,ay],[az,0,-ax],[-ay,ax,0]],  K^2 = a a^T - |a|^2 I (|a|^2 kept explicit so
+    // that rounding in the normalisation is carried the same way a matrix product would).
+    const Scalar xx = ax * ax, yy = ay * ay, zz = az * az;
+    R[0] = Scalar(1) + c1 * (-(yy + zz));
+    R[1] = s * (-az) + c1 * (ax * ay);
+    R[2] = s * (ay) + c1 * (ax * az);
+    R[3] = s * (az) + c1 * (ax * ay);
+    R[4] = Scalar(1) + c1 * (-(xx + zz));
+    R[5] = s * (-ax) + c1 * (ay * az);
+    R[6] = s * (-ay) + c1 * (ax * az);
+    R[7] = s * (ax) + c1 * (ay * az);
+    R[8] = Scalar(1) + c1 * (-(xx + yy));
+  } else {
+    R[0] = 1; R[1] = 0; R[2] = 0;
+    R[3] = 0; R[4] = 1; R[5] = 0;
+    R[6] = 0; R[7] = 0; R[8] = 1;
+  }
+}
+
+template <typename Scalar>
+inline Rigid3<Scalar> rigidFrom6DOF(const Scalar *x) {
+  Scalar R[9];
+  expSO3<Scalar>(x + 3, R);
+  Rigid3<Scalar> T;
+  for (int i = 0; i < 3; ++i) {
+    T.m[i * 4 + 0] = R[i * 3 + 0];
+    T.m[i * 4 + 1] = R[i * 3 + 1];
+    T.m[i * 4 + 2] = R[i * 3 + 2];
+    T.m[i * 4 + 3] = x[i];
+  }
+  return T;
+}
+
+// 4x4 column-major homogeneous matrix, the layout user models written against the reference
+// expect from so3::convert6DOFParameterToMatrix.
+template <typename Scalar>
+inline void convert6DOFParameterToMatrix(const Scalar *x, Scalar T[16]) {
+  const Rigid3<Scalar> rt = rigidFrom6DOF<Scalar>(x);
+  for (int c = 0; c < 4; ++c) {
+    for (int r = 0; r < 3; ++r) T[c * 4 + r] = rt.m[r * 4 + c];
+    T[c * 4 + 3] = (c == 3) ? Scalar(1) : Scalar(0);
+  }
+}
+
+// Inverse map for reporting / tests: rotation matrix (row-major) -> rotation vector.
+template <typename Scalar>
+inline void logSO3(const Scalar R[9], Scalar w[3]) {
+  const Scalar tr = R[0] + R[4] + R[8];
+  Scalar c = (tr - Scalar(1)) / Scalar(2);
+  c = c > Scalar(1) ? Scalar(1) : (c < Scalar(-1) ? Scalar(-1) : c);
+  const Scalar theta = std::acos(c);
+  const Scalar vx = R[7] - R[5], vy = R[2] - R[6], vz = R[3] - R[1];
+  const Scalar k = (theta < Scalar(1e-6)) ? Scalar(0.5) : theta / (Scalar(2) * std::sin(theta));
+  w[0] = k * vx;
+  w[1] = k * vy;
+  w[2] = k * vz;
+}
+
+}  // namespace so3
+}  // namespace moptimizer

@@ -1,0 +1,173 @@
+/*
+ * moptimizer_hip.h — C ABI of the MI355X linearization library (libmoptimizer_hip.so).
+ *
+ * This is the drop-in boundary of the path: one `mopt_cost` object stands for one
+ * moptimizer cost function (a model bound to its data arrays + a loss + a covariance) whose
+ * per-residual sweeps run as HIP kernels on one gfx950 device.  Each entry point replaces one
+ * piece of the reference's C++ interface (paths relative to /root/reference):
+ *
+ *   mopt_point2point_create      the `Point2Point` model object bound to its two clouds plus
+ *                                the cost-class constructor      tst/point2point.cpp:24-29,82-83;
+ *                                include/moptimizer/cost_function_analytical_dyn.h:17-18
+ *   mopt_reprojection_create     `CameraModel` + its cost           tst/camera_calibration.cpp:12-31,91-92
+ *   mopt_cost_set_covariance     CostFunctionBase::setCovariance    include/moptimizer/cost_function.h:38-40
+ *   mopt_cost_set_loss           CostFunctionBase::setLossFunction  include/moptimizer/cost_function.h:37
+ *   mopt_cost_linearize          CostFunctionBase::linearize        include/moptimizer/cost_function.h:50
+ *                                (= CostComputation::computeHessian / computeHessianNumerical,
+ *                                include/moptimizer/linearization.h:65-158)
+ *   mopt_cost_compute            CostFunctionBase::computeCost      include/moptimizer/cost_function.h:49
+ *                                (= CostComputation::parallelComputeCost, linearization.h:49-63)
+ *   mopt_cost_destroy            ~CostFunctionBase                  include/moptimizer/cost_function.h:35
+ *
+ * The *_async forms and mopt_group_* are additions for sharded (multi-GPU) use: they leave the
+ * n*n + n + 1 partial sums on the device so that a collective (RCCL all-reduce) can combine the
+ * shards before anything crosses PCIe.
+ *
+ * Conventions (identical to the reference's buffers):
+ *   - scalar_bytes is 4 (float) or 8 (double); `x`, `cov`, `hessian`, `b`, `sum_sq` of a call are
+ *     in that scalar.  x has n = 6 entries (tx, ty, tz, wx, wy, wz).
+ *   - hessian: n*n, column-major, fully overwritten.  b: n.  sum_sq: the UNWEIGHTED sum of
+ *     squared residuals (linearization.h:152,157), also what mopt_cost_compute returns.
+ *   - cov: m*m column-major (m = 3 point2point, m = 2 reprojection); NULL = identity.
+ *   - device result layout of the async forms: double[n*n + n + 1] = H (column-major) | b | sum_sq,
+ *     always fp64 whatever the cost's scalar.
+ *   - every function returns MOPT_OK (0) or an error code; mopt_last_error() gives the text for
+ *     the calling thread.  No call falls back to a CPU implementation: without a usable HIP
+ *     device the create functions fail with MOPT_ERR_NO_DEVICE / MOPT_ERR_HIP.
+ */
+#ifndef MOPTIMIZER_HIP_H_
+#define MOPTIMIZER_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define MOPT_API __attribute__((visibility("default")))
+#else
+#define MOPT_API
+#endif
+
+typedef struct mopt_cost mopt_cost;
+typedef struct mopt_group mopt_group;
+
+enum mopt_status {
+  MOPT_OK = 0,
+  MOPT_ERR_INVALID_ARGUMENT = 1,
+  MOPT_ERR_HIP = 2,
+  MOPT_ERR_NO_DEVICE = 3,
+  MOPT_ERR_RCCL = 4,
+  MOPT_ERR_UNSUPPORTED = 5
+};
+
+/* How the per-residual Jacobian is obtained. */
+enum mopt_jacobian_mode {
+  /* model-supplied Jacobian, row-major m x n as the API contract states (model.h:35-42):
+   * point2point J = [ I3 | -skew(p) ]. */
+  MOPT_JAC_ANALYTIC = 0,
+  /* bit-faithful to tst/point2point.cpp:71-75, whose f_df fills the buffer column-major while
+   * linearization.h:17-18 reads it row-major. */
+  MOPT_JAC_ANALYTIC_TST_LAYOUT = 1,
+  /* forward differences with the reference's step rule (linearization.h:78-105). */
+  MOPT_JAC_NUMERIC = 2
+};
+
+enum mopt_loss_kind {
+  MOPT_LOSS_NONE = 0,          /* loss::NoLoss          w = 1               */
+  MOPT_LOSS_GEMAN_MCCLURE = 1  /* loss::GemmanMCClure   w = t^2 / (s + t)^2 */
+};
+
+enum mopt_create_flags {
+  MOPT_INPUT_HOST = 0,   /* data pointers are host memory (copied once to HBM)             */
+  MOPT_INPUT_DEVICE = 1  /* data pointers are already device memory on `device` (re-laid out
+                            on the GPU, no PCIe traffic)                                     */
+};
+
+/* How a sweep evaluates the reference's per-residual arithmetic. */
+enum mopt_kernel_variant {
+  MOPT_KERNEL_AUTO = 0,    /* fastest variant that meets the parity bar for the mode         */
+  MOPT_KERNEL_LITERAL = 1, /* every residual and Jacobian entry formed per point, then
+                              w * J^T * S * J accumulated entry by entry, as the reference does */
+  MOPT_KERNEL_MOMENTS = 2  /* Jacobians that are affine in the source point (all point2point
+                              modes) reduced through weighted point/residual moments           */
+};
+
+MOPT_API int mopt_device_count(int *count);
+MOPT_API const char *mopt_last_error(void);
+MOPT_API const char *mopt_version(void);
+
+/* ---- cost objects ------------------------------------------------------------------------ */
+
+/* Point-to-point ICP cost over `count` index-aligned correspondences.  src_xyz / tgt_xyz: packed
+ * xyz triples (24 B per point in fp64 — the memory of a std::vector<Eigen::Vector3d>). */
+MOPT_API int mopt_point2point_create(mopt_cost **out, int device, int scalar_bytes,
+                                     const void *src_xyz, const void *tgt_xyz, int64_t count,
+                                     unsigned flags);
+
+/* Reprojection (camera-calibration) cost, fp64, numeric Jacobian only.  points_xyzw: packed
+ * 4-vectors (32 B); pixels_uv: packed int32 pairs (8 B).  camera_3x4 / frame_4x4: row-major
+ * constants (tst/camera_calibration.cpp:22-30); NULL selects the reference's values. */
+MOPT_API int mopt_reprojection_create(mopt_cost **out, int device, const double *points_xyzw,
+                                      const int32_t *pixels_uv, int64_t count,
+                                      const double *camera_3x4, const double *frame_4x4,
+                                      unsigned flags);
+
+MOPT_API int mopt_cost_destroy(mopt_cost *cost);
+
+MOPT_API int mopt_cost_set_covariance(mopt_cost *cost, const void *cov_colmajor);
+MOPT_API int mopt_cost_set_loss(mopt_cost *cost, int loss_kind, double parameter);
+MOPT_API int mopt_cost_set_kernel_variant(mopt_cost *cost, int variant);
+
+/* count, n (parameters), m (outputs per residual), scalar_bytes, device; any pointer may be NULL */
+MOPT_API int mopt_cost_info(const mopt_cost *cost, int64_t *count, int *n, int *m,
+                            int *scalar_bytes, int *device);
+
+/* ---- blocking sweeps (what LevenbergMarquadtDynamic::minimize calls) ----------------------- */
+
+MOPT_API int mopt_cost_linearize(mopt_cost *cost, int jacobian_mode, const void *x, void *hessian,
+                                 void *b, void *sum_sq);
+MOPT_API int mopt_cost_compute(mopt_cost *cost, const void *x, void *sum_sq);
+
+/* ---- asynchronous sweeps (shard partials stay in HBM) -------------------------------------- */
+
+/* Enqueue on `hip_stream` (a hipStream_t; NULL = the cost's own stream) and return at once.
+ * d_result: device double[n*n + n + 1].  d_sum_sq: device double[1]. */
+MOPT_API int mopt_cost_linearize_async(mopt_cost *cost, int jacobian_mode, const void *x,
+                                       double *d_result, void *hip_stream);
+MOPT_API int mopt_cost_compute_async(mopt_cost *cost, const void *x, double *d_sum_sq,
+                                     void *hip_stream);
+/* The cost's own stream (hipStream_t) and a wait for it. */
+MOPT_API int mopt_cost_stream(mopt_cost *cost, void **hip_stream);
+MOPT_API int mopt_cost_synchronize(mopt_cost *cost);
+
+/* ---- measurement -------------------------------------------------------------------------- */
+
+/* With profiling on, every sweep kernel launch is bracketed by HIP events on its stream.
+ * mopt_cost_profile synchronises and reports the accumulated time of the dominant (sweep)
+ * kernels and how many were launched since profiling was last switched on. */
+MOPT_API int mopt_cost_set_profiling(mopt_cost *cost, int enabled);
+MOPT_API int mopt_cost_profile(mopt_cost *cost, double *sweep_ms_total, int64_t *sweep_launches);
+
+/* ---- single-process multi-GPU group (RCCL) ------------------------------------------------- */
+
+/* Shard `count` correspondences contiguously over `num_devices` GPUs of this node, one
+ * mopt_cost per device, and combine the n*n + n + 1 partial sums of every sweep with one
+ * ncclAllReduce(sum, fp64) over xGMI.  The blocking calls below have the semantics of
+ * mopt_cost_linearize / mopt_cost_compute on the whole data set. */
+MOPT_API int mopt_group_point2point_create(mopt_group **out, const int *devices, int num_devices,
+                                           int scalar_bytes, const void *src_xyz,
+                                           const void *tgt_xyz, int64_t count);
+MOPT_API int mopt_group_destroy(mopt_group *group);
+MOPT_API int mopt_group_set_covariance(mopt_group *group, const void *cov_colmajor);
+MOPT_API int mopt_group_set_loss(mopt_group *group, int loss_kind, double parameter);
+MOPT_API int mopt_group_linearize(mopt_group *group, int jacobian_mode, const void *x,
+                                  void *hessian, void *b, void *sum_sq);
+MOPT_API int mopt_group_compute(mopt_group *group, const void *x, void *sum_sq);
+MOPT_API int mopt_group_size(const mopt_group *group, int *num_devices);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOPTIMIZER_HIP_H_ */

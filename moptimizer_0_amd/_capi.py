@@ -1,0 +1,286 @@
+"""ctypes binding of libmoptimizer_hip.so (C ABI: include/moptimizer_hip.h).
+
+Plumbing for tests/ and bench.py only — the host side of the product is C++
+(include/moptimizer_amd/*.hpp).  There is no Python or CPU implementation behind these
+calls: if the shared library is missing, or no HIP device can run the work, they raise.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmoptimizer_hip.so")
+
+MOPT_OK = 0
+JAC_ANALYTIC, JAC_ANALYTIC_TST_LAYOUT, JAC_NUMERIC = 0, 1, 2
+LOSS_NONE, LOSS_GEMAN_MCCLURE = 0, 1
+INPUT_HOST, INPUT_DEVICE = 0, 1
+KERNEL_AUTO, KERNEL_LITERAL, KERNEL_MOMENTS = 0, 1, 2
+RESULT_DOUBLES = 43
+
+_lib = None
+
+
+class MoptError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library once.  torch (when present) is imported first so that the process ends
+    up with a single HIP runtime: torch wheels bundle libamdhip64.so.7 and the loader shares it
+    by soname only if it is already mapped."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MoptError(
+            "%s not found: build it with `make` (or __graft_entry__.build()); there is no "
+            "fallback implementation" % LIB_PATH)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    c_void_pp = ctypes.POINTER(ctypes.c_void_p)
+    sigs = {
+        "mopt_device_count": [ctypes.POINTER(ctypes.c_int)],
+        "mopt_point2point_create": [c_void_pp, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                    ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint],
+        "mopt_reprojection_create": [c_void_pp, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_uint],
+        "mopt_cost_destroy": [ctypes.c_void_p],
+        "mopt_cost_set_covariance": [ctypes.c_void_p, ctypes.c_void_p],
+        "mopt_cost_set_loss": [ctypes.c_void_p, ctypes.c_int, ctypes.c_double],
+        "mopt_cost_set_kernel_variant": [ctypes.c_void_p, ctypes.c_int],
+        "mopt_cost_info": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64),
+                           ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                           ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)],
+        "mopt_cost_linearize": [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                ctypes.c_void_p, ctypes.c_void_p],
+        "mopt_cost_compute": [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p],
+        "mopt_cost_linearize_async": [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                      ctypes.c_void_p, ctypes.c_void_p],
+        "mopt_cost_compute_async": [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                    ctypes.c_void_p],
+        "mopt_cost_stream": [ctypes.c_void_p, c_void_pp],
+        "mopt_cost_synchronize": [ctypes.c_void_p],
+        "mopt_cost_set_profiling": [ctypes.c_void_p, ctypes.c_int],
+        "mopt_cost_profile": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
+                              ctypes.POINTER(ctypes.c_int64)],
+        "mopt_group_point2point_create": [c_void_pp, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_int64],
+        "mopt_group_destroy": [ctypes.c_void_p],
+        "mopt_group_set_covariance": [ctypes.c_void_p, ctypes.c_void_p],
+        "mopt_group_set_loss": [ctypes.c_void_p, ctypes.c_int, ctypes.c_double],
+        "mopt_group_linearize": [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                 ctypes.c_void_p, ctypes.c_void_p],
+        "mopt_group_compute": [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p],
+        "mopt_group_size": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)],
+    }
+    for name, argtypes in sigs.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    lib.mopt_last_error.restype = ctypes.c_char_p
+    lib.mopt_last_error.argtypes = []
+    lib.mopt_version.restype = ctypes.c_char_p
+    lib.mopt_version.argtypes = []
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != MOPT_OK:
+        raise MoptError("moptimizer_hip error %d: %s" % (rc, load().mopt_last_error().decode()))
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    check(load().mopt_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def _dtype_of(scalar_bytes):
+    return np.float64 if scalar_bytes == 8 else np.float32
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class _CostBase:
+    """Mirror of the CostFunctionBase surface over one mopt_cost handle."""
+
+    def __init__(self):
+        self._h = ctypes.c_void_p()
+        self.scalar_bytes = 8
+        self.n_out = 3
+
+    # -- CostFunctionBase::setCovariance / setLossFunction ---------------------------------
+    def set_covariance(self, cov):
+        if cov is None:
+            check(load().mopt_cost_set_covariance(self._h, None))
+            return
+        cov = np.asfortranarray(np.asarray(cov, dtype=_dtype_of(self.scalar_bytes)))
+        assert cov.shape == (self.n_out, self.n_out)
+        check(load().mopt_cost_set_covariance(self._h, _ptr(cov)))
+
+    def set_loss(self, kind, parameter=0.0):
+        check(load().mopt_cost_set_loss(self._h, int(kind), float(parameter)))
+
+    def set_kernel_variant(self, variant):
+        check(load().mopt_cost_set_kernel_variant(self._h, int(variant)))
+
+    # -- CostFunctionBase::linearize / computeCost ------------------------------------------
+    def linearize(self, x, jac_mode):
+        dt = _dtype_of(self.scalar_bytes)
+        x = np.ascontiguousarray(x, dtype=dt)
+        H = np.zeros((6, 6), dtype=dt, order="F")
+        b = np.zeros(6, dtype=dt)
+        s = np.zeros(1, dtype=dt)
+        check(load().mopt_cost_linearize(self._h, int(jac_mode), _ptr(x), _ptr(H), _ptr(b), _ptr(s)))
+        return H, b, s[0]
+
+    def compute_cost(self, x):
+        dt = _dtype_of(self.scalar_bytes)
+        x = np.ascontiguousarray(x, dtype=dt)
+        s = np.zeros(1, dtype=dt)
+        check(load().mopt_cost_compute(self._h, _ptr(x), _ptr(s)))
+        return s[0]
+
+    # -- asynchronous forms: results stay in HBM --------------------------------------------
+    def linearize_async(self, x, jac_mode, d_result_ptr, stream_ptr=None):
+        x = np.ascontiguousarray(x, dtype=_dtype_of(self.scalar_bytes))
+        check(load().mopt_cost_linearize_async(self._h, int(jac_mode), _ptr(x),
+                                               ctypes.c_void_p(d_result_ptr),
+                                               ctypes.c_void_p(stream_ptr or 0)))
+
+    def compute_cost_async(self, x, d_sum_ptr, stream_ptr=None):
+        x = np.ascontiguousarray(x, dtype=_dtype_of(self.scalar_bytes))
+        check(load().mopt_cost_compute_async(self._h, _ptr(x), ctypes.c_void_p(d_sum_ptr),
+                                             ctypes.c_void_p(stream_ptr or 0)))
+
+    def synchronize(self):
+        check(load().mopt_cost_synchronize(self._h))
+
+    def set_profiling(self, enabled):
+        check(load().mopt_cost_set_profiling(self._h, 1 if enabled else 0))
+
+    def profile(self):
+        ms = ctypes.c_double(0)
+        n = ctypes.c_int64(0)
+        check(load().mopt_cost_profile(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+    def info(self):
+        count = ctypes.c_int64()
+        n, m, sb, dev = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        check(load().mopt_cost_info(self._h, ctypes.byref(count), ctypes.byref(n), ctypes.byref(m),
+                                    ctypes.byref(sb), ctypes.byref(dev)))
+        return dict(count=count.value, n=n.value, m=m.value, scalar_bytes=sb.value,
+                    device=dev.value)
+
+    def close(self):
+        if self._h:
+            load().mopt_cost_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Point2PointCost(_CostBase):
+    """Point-to-point ICP cost on one GPU.  src / tgt: [N, 3] arrays (host), or raw device
+    pointers with `count` when device_ptrs=True."""
+
+    def __init__(self, src, tgt, device=0, dtype=np.float64, device_ptrs=False, count=None):
+        super().__init__()
+        self.scalar_bytes = np.dtype(dtype).itemsize
+        self.n_out = 3
+        if device_ptrs:
+            n = int(count)
+            check(load().mopt_point2point_create(ctypes.byref(self._h), device, self.scalar_bytes,
+                                                 ctypes.c_void_p(int(src)),
+                                                 ctypes.c_void_p(int(tgt)), n, INPUT_DEVICE))
+        else:
+            src = np.ascontiguousarray(src, dtype=dtype).reshape(-1, 3)
+            tgt = np.ascontiguousarray(tgt, dtype=dtype).reshape(-1, 3)
+            assert src.shape == tgt.shape
+            n = src.shape[0]
+            check(load().mopt_point2point_create(ctypes.byref(self._h), device, self.scalar_bytes,
+                                                 _ptr(src), _ptr(tgt), n, INPUT_HOST))
+        self.count = n
+
+
+class ReprojectionCost(_CostBase):
+    """Camera-calibration reprojection cost (fp64, numeric Jacobian) on one GPU."""
+
+    def __init__(self, points_xyzw, pixels_uv, device=0, camera=None, frame=None):
+        super().__init__()
+        self.scalar_bytes = 8
+        self.n_out = 2
+        pts = np.ascontiguousarray(points_xyzw, dtype=np.float64).reshape(-1, 4)
+        pix = np.ascontiguousarray(pixels_uv, dtype=np.int32).reshape(-1, 2)
+        assert pts.shape[0] == pix.shape[0]
+        cam = None if camera is None else np.ascontiguousarray(camera, dtype=np.float64)
+        frm = None if frame is None else np.ascontiguousarray(frame, dtype=np.float64)
+        check(load().mopt_reprojection_create(
+            ctypes.byref(self._h), device, _ptr(pts), _ptr(pix), pts.shape[0],
+            None if cam is None else _ptr(cam), None if frm is None else _ptr(frm), INPUT_HOST))
+        self.count = pts.shape[0]
+
+
+class Point2PointGroup:
+    """Single-process multi-GPU point-to-point cost (RCCL all-reduce inside the library)."""
+
+    def __init__(self, src, tgt, devices, dtype=np.float64):
+        self._h = ctypes.c_void_p()
+        self.scalar_bytes = np.dtype(dtype).itemsize
+        src = np.ascontiguousarray(src, dtype=dtype).reshape(-1, 3)
+        tgt = np.ascontiguousarray(tgt, dtype=dtype).reshape(-1, 3)
+        devs = (ctypes.c_int * len(devices))(*devices)
+        check(load().mopt_group_point2point_create(ctypes.byref(self._h), devs, len(devices),
+                                                   self.scalar_bytes, _ptr(src), _ptr(tgt),
+                                                   src.shape[0]))
+
+    def set_covariance(self, cov):
+        cov = None if cov is None else np.asfortranarray(
+            np.asarray(cov, dtype=_dtype_of(self.scalar_bytes)))
+        check(load().mopt_group_set_covariance(self._h, None if cov is None else _ptr(cov)))
+
+    def set_loss(self, kind, parameter=0.0):
+        check(load().mopt_group_set_loss(self._h, int(kind), float(parameter)))
+
+    def linearize(self, x, jac_mode):
+        dt = _dtype_of(self.scalar_bytes)
+        x = np.ascontiguousarray(x, dtype=dt)
+        H = np.zeros((6, 6), dtype=dt, order="F")
+        b = np.zeros(6, dtype=dt)
+        s = np.zeros(1, dtype=dt)
+        check(load().mopt_group_linearize(self._h, int(jac_mode), _ptr(x), _ptr(H), _ptr(b),
+                                          _ptr(s)))
+        return H, b, s[0]
+
+    def compute_cost(self, x):
+        dt = _dtype_of(self.scalar_bytes)
+        x = np.ascontiguousarray(x, dtype=dt)
+        s = np.zeros(1, dtype=dt)
+        check(load().mopt_group_compute(self._h, _ptr(x), _ptr(s)))
+        return s[0]
+
+    def close(self):
+        if self._h:
+            load().mopt_group_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

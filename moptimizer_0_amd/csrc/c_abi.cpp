@@ -1,0 +1,816 @@
+// C ABI of libmoptimizer_hip.so (declared in include/moptimizer_hip.h): cost-object lifetime,
+// the once-per-x host work (SE(3) transforms, forward-difference steps), kernel selection and
+// the RCCL-combined device group.  There is no CPU implementation behind any entry point: when
+// HIP cannot run the work the call returns an error code.
+#include "moptimizer_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "moptimizer_amd/so3.hpp"
+#include "sweep.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+  g_last_error = msg;
+  return code;
+}
+
+#define MOPT_HIP_TRY(expr)                                                                  \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(MOPT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+  } while (0)
+
+#define MOPT_NCCL_TRY(expr)                                                                 \
+  do {                                                                                      \
+    ncclResult_t r_ = (expr);                                                               \
+    if (r_ != ncclSuccess)                                                                  \
+      return fail(MOPT_ERR_RCCL, std::string(#expr) + ": " + ncclGetErrorString(r_));      \
+  } while (0)
+
+enum ModelKind { kModelPoint2Point = 1, kModelReprojection = 2 };
+
+int envInt(const char *name, int fallback) {
+  const char *v = std::getenv(name);
+  if (!v || !*v) return fallback;
+  const int parsed = std::atoi(v);
+  return parsed > 0 ? parsed : fallback;
+}
+
+}  // namespace
+
+struct mopt_cost {
+  int device = 0;
+  int scalar_bytes = 8;
+  int model = kModelPoint2Point;
+  int n_out = 3;
+  long long count = 0;
+  int num_tiles = 0;
+  int num_cus = 0;
+  int max_grid = 0;
+
+  void *d_tiles = nullptr;
+  double *d_partials = nullptr;
+  double *d_result = nullptr;  // kResultDoubles
+  double *h_result = nullptr;  // pinned
+  hipStream_t stream = nullptr;
+
+  double cov[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // row-major m x m, as double
+  int cov_mode = mopt::kCovIdentity;
+  int loss_kind = MOPT_LOSS_NONE;
+  double loss_param = 0.0;
+  int variant = MOPT_KERNEL_AUTO;
+
+  double camera[12];
+  double frame[16];
+
+  bool profiling = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
+  double sweep_ms_total = 0.0;
+  long long sweep_launches = 0;
+};
+
+namespace {
+
+using mopt::kNumParams;
+using mopt::kResultDoubles;
+
+int gridFor(const mopt_cost *c, int blocks_per_cu) {
+  long long g = (long long)c->num_cus * blocks_per_cu;
+  if (g > c->num_tiles) g = c->num_tiles;
+  if (g > c->max_grid) g = c->max_grid;
+  if (g < 1) g = 1;
+  return int(g);
+}
+
+int resolvePendingEvents(mopt_cost *c) {
+  for (auto &pr : c->pending_events) {
+    MOPT_HIP_TRY(hipEventSynchronize(pr.second));
+    float ms = 0.f;
+    MOPT_HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+    c->sweep_ms_total += double(ms);
+    c->sweep_launches += 1;
+    hipEventDestroy(pr.first);
+    hipEventDestroy(pr.second);
+  }
+  c->pending_events.clear();
+  return MOPT_OK;
+}
+
+// Brackets the dominant kernel of a sweep with events when profiling is on.
+struct SweepTimer {
+  mopt_cost *c;
+  hipStream_t s;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  bool on;
+  SweepTimer(mopt_cost *cost, hipStream_t stream) : c(cost), s(stream), on(cost->profiling) {
+    if (on) {
+      if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) on = false;
+      if (on) hipEventRecord(e0, s);
+    }
+  }
+  void stop() {
+    if (!on) return;
+    hipEventRecord(e1, s);
+    c->pending_events.emplace_back(e0, e1);
+    on = false;
+  }
+};
+
+template <typename S>
+void defaultReprojConstants(double K[12], double C[16]) {
+  // tst/camera_calibration.cpp:22-30
+  const double k[12] = {586.122314453125, 0, 638.8477694496105, 0, 0, 722.3973388671875,
+                        323.031267074588, 0, 0, 0, 1, 0};
+  std::memcpy(K, k, sizeof k);
+  const double a = M_PI_2;
+  const double rx[3][3] = {{1, 0, 0}, {0, std::cos(a), -std::sin(a)}, {0, std::sin(a), std::cos(a)}};
+  const double rz[3][3] = {{std::cos(a), -std::sin(a), 0}, {std::sin(a), std::cos(a), 0}, {0, 0, 1}};
+  for (int i = 0; i < 16; ++i) C[i] = 0.0;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c)
+      C[r * 4 + c] = rx[r][0] * rz[0][c] + rx[r][1] * rz[1][c] + rx[r][2] * rz[2][c];
+  C[15] = 1.0;
+}
+
+// Forward-difference points of the reference (linearization.h:78-92): h_j = sqrt(eps) |x_j|,
+// or sqrt(eps) when that is zero; x_plus_j = x + h_j e_j.
+template <typename S>
+void forwardSteps(const S *x, S h[kNumParams], S x_plus[kNumParams][kNumParams]) {
+  const S min_step = std::sqrt(std::numeric_limits<S>::epsilon());
+  for (int j = 0; j < kNumParams; ++j) {
+    h[j] = min_step * std::fabs(x[j]);
+    if (h[j] == S(0)) h[j] = min_step;
+    for (int k = 0; k < kNumParams; ++k) x_plus[j][k] = x[k];
+    x_plus[j][j] += h[j];
+  }
+}
+
+template <typename S>
+void fillP2PArgs(const mopt_cost *c, const S *x, bool with_steps, mopt::P2PSweepArgs<S> &a) {
+  a.tiles = static_cast<const S *>(c->d_tiles);
+  a.count = c->count;
+  a.num_tiles = c->num_tiles;
+  a.loss_kind = c->loss_kind;
+  a.loss_param = S(c->loss_param);
+  a.partials = c->d_partials;
+  const auto T0 = moptimizer::so3::rigidFrom6DOF<S>(x);
+  std::memcpy(a.T[0], T0.m, sizeof T0.m);
+  for (int j = 0; j < kNumParams; ++j) {
+    std::memcpy(a.T[1 + j], T0.m, sizeof T0.m);
+    a.inv_h[j] = S(0);
+  }
+  if (with_steps) {
+    S h[kNumParams], xp[kNumParams][kNumParams];
+    forwardSteps<S>(x, h, xp);
+    for (int j = 0; j < kNumParams; ++j) {
+      const auto Tj = moptimizer::so3::rigidFrom6DOF<S>(xp[j]);
+      std::memcpy(a.T[1 + j], Tj.m, sizeof Tj.m);
+      a.inv_h[j] = S(1) / h[j];
+    }
+  }
+  for (int k = 0; k < 9; ++k) a.cov[k] = S(c->cov[k]);
+}
+
+// The 3x6 row-major Jacobian pattern of a point, host copy of the device formulas; used to
+// derive the affine basis J(p) = J0 + px Jx + py Jy + pz Jz.
+void analyticPattern(int jac_mode, const double p[3], double J[18]) {
+  for (int k = 0; k < 18; ++k) J[k] = 0.0;
+  if (jac_mode == MOPT_JAC_ANALYTIC) {
+    J[0 * 6 + 0] = 1; J[1 * 6 + 1] = 1; J[2 * 6 + 2] = 1;
+    J[0 * 6 + 4] = p[2];  J[0 * 6 + 5] = -p[1];
+    J[1 * 6 + 3] = -p[2]; J[1 * 6 + 5] = p[0];
+    J[2 * 6 + 3] = p[1];  J[2 * 6 + 4] = -p[0];
+  } else {
+    J[0 * 6 + 0] = 1; J[0 * 6 + 4] = 1;
+    J[1 * 6 + 2] = 1; J[1 * 6 + 4] = -p[2]; J[1 * 6 + 5] = p[1];
+    J[2 * 6 + 0] = p[2]; J[2 * 6 + 2] = -p[0]; J[2 * 6 + 3] = -p[1]; J[2 * 6 + 4] = p[0];
+  }
+}
+
+template <typename S>
+void fillBasis(const mopt_cost *c, int jac_mode, const mopt::P2PSweepArgs<S> &a,
+               mopt::AffineBasis &B) {
+  if (jac_mode == MOPT_JAC_NUMERIC) {
+    // column j of J is ((R_j - R) p + (t_j - t)) / h_j
+    for (int r = 0; r < 3; ++r)
+      for (int j = 0; j < kNumParams; ++j) {
+        B.J[0][r * 6 + j] = double((a.T[1 + j][r * 4 + 3] - a.T[0][r * 4 + 3]) * a.inv_h[j]);
+        for (int k = 0; k < 3; ++k)
+          B.J[1 + k][r * 6 + j] = double((a.T[1 + j][r * 4 + k] - a.T[0][r * 4 + k]) * a.inv_h[j]);
+      }
+  } else {
+    const double origin[3] = {0, 0, 0};
+    analyticPattern(jac_mode, origin, B.J[0]);
+    for (int k = 0; k < 3; ++k) {
+      double e[3] = {0, 0, 0};
+      e[k] = 1.0;
+      analyticPattern(jac_mode, e, B.J[1 + k]);
+      for (int q = 0; q < 18; ++q) B.J[1 + k][q] -= B.J[0][q];
+    }
+  }
+  for (int k = 0; k < 9; ++k) B.cov[k] = c->cov[k];
+}
+
+template <typename S>
+int p2pLinearizeAsync(mopt_cost *c, int jac_mode, const S *x, double *d_result, hipStream_t s) {
+  mopt::P2PSweepArgs<S> args;
+  fillP2PArgs<S>(c, x, jac_mode == MOPT_JAC_NUMERIC, args);
+  bool moments;
+  switch (c->variant) {
+    case MOPT_KERNEL_LITERAL: moments = false; break;
+    case MOPT_KERNEL_MOMENTS: moments = true; break;
+    default: moments = (jac_mode != MOPT_JAC_NUMERIC); break;
+  }
+  if (moments) {
+    mopt::AffineBasis basis;
+    fillBasis<S>(c, jac_mode, args, basis);
+    const int grid = gridFor(c, envInt("MOPT_BLOCKS_PER_CU", 4));
+    SweepTimer timer(c, s);
+    MOPT_HIP_TRY(mopt::launchP2PMoments<S>(args, grid, s));
+    timer.stop();
+    MOPT_HIP_TRY(mopt::launchFinalizeMoments(c->d_partials, grid, basis, d_result, s));
+  } else {
+    const int grid = gridFor(c, envInt("MOPT_BLOCKS_PER_CU", 4));
+    const int nacc = c->cov_mode == mopt::kCovGeneral ? mopt::kAccFull : mopt::kAccSym;
+    SweepTimer timer(c, s);
+    MOPT_HIP_TRY(mopt::launchP2PLinearizeLiteral<S>(args, jac_mode, c->cov_mode, grid, s));
+    timer.stop();
+    MOPT_HIP_TRY(mopt::launchFinalizeDense(c->d_partials, grid, nacc, kNumParams, d_result, s));
+  }
+  return MOPT_OK;
+}
+
+template <typename S>
+int p2pCostAsync(mopt_cost *c, const S *x, double *d_sum, hipStream_t s) {
+  mopt::P2PSweepArgs<S> args;
+  fillP2PArgs<S>(c, x, false, args);
+  const int grid = gridFor(c, envInt("MOPT_BLOCKS_PER_CU", 8));
+  SweepTimer timer(c, s);
+  MOPT_HIP_TRY(mopt::launchP2PCost<S>(args, grid, s));
+  timer.stop();
+  MOPT_HIP_TRY(mopt::launchFinalizeCost(c->d_partials, grid, d_sum, s));
+  return MOPT_OK;
+}
+
+// (K * T) * C, row-major 3x4, the matrix products of tst/camera_calibration.cpp:37.
+void projectionFor(const mopt_cost *c, const double *x, double M[12]) {
+  const auto T = moptimizer::so3::rigidFrom6DOF<double>(x);
+  double T4[16];
+  for (int r = 0; r < 3; ++r)
+    for (int k = 0; k < 4; ++k) T4[r * 4 + k] = T.m[r * 4 + k];
+  T4[12] = T4[13] = T4[14] = 0.0;
+  T4[15] = 1.0;
+  double KT[12];
+  for (int r = 0; r < 3; ++r)
+    for (int k = 0; k < 4; ++k) {
+      double v = 0.0;
+      for (int q = 0; q < 4; ++q) v += c->camera[r * 4 + q] * T4[q * 4 + k];
+      KT[r * 4 + k] = v;
+    }
+  for (int r = 0; r < 3; ++r)
+    for (int k = 0; k < 4; ++k) {
+      double v = 0.0;
+      for (int q = 0; q < 4; ++q) v += KT[r * 4 + q] * c->frame[q * 4 + k];
+      M[r * 4 + k] = v;
+    }
+}
+
+void fillReprojArgs(const mopt_cost *c, const double *x, bool with_steps,
+                    mopt::ReprojSweepArgs &a) {
+  a.tiles = static_cast<const unsigned char *>(c->d_tiles);
+  a.count = c->count;
+  a.num_tiles = c->num_tiles;
+  a.loss_kind = c->loss_kind;
+  a.loss_param = c->loss_param;
+  a.partials = c->d_partials;
+  projectionFor(c, x, a.M[0]);
+  for (int j = 0; j < kNumParams; ++j) {
+    std::memcpy(a.M[1 + j], a.M[0], sizeof a.M[0]);
+    a.inv_h[j] = 0.0;
+  }
+  if (with_steps) {
+    double h[kNumParams], xp[kNumParams][kNumParams];
+    forwardSteps<double>(x, h, xp);
+    for (int j = 0; j < kNumParams; ++j) {
+      projectionFor(c, xp[j], a.M[1 + j]);
+      a.inv_h[j] = 1.0 / h[j];
+    }
+  }
+  // row-major 2x2 out of the 3x3 slot
+  a.cov[0] = c->cov[0]; a.cov[1] = c->cov[1];
+  a.cov[2] = c->cov[3]; a.cov[3] = c->cov[4];
+}
+
+int reprojLinearizeAsync(mopt_cost *c, int jac_mode, const double *x, double *d_result,
+                         hipStream_t s) {
+  if (jac_mode != MOPT_JAC_NUMERIC)
+    return fail(MOPT_ERR_UNSUPPORTED,
+                "the reprojection model has no analytic Jacobian (BaseModel, numeric only)");
+  mopt::ReprojSweepArgs args;
+  fillReprojArgs(c, x, true, args);
+  const int grid = gridFor(c, envInt("MOPT_BLOCKS_PER_CU", 4));
+  const int nacc = c->cov_mode == mopt::kCovGeneral ? mopt::kAccFull : mopt::kAccSym;
+  SweepTimer timer(c, s);
+  MOPT_HIP_TRY(mopt::launchReprojLinearize(args, c->cov_mode, grid, s));
+  timer.stop();
+  MOPT_HIP_TRY(mopt::launchFinalizeDense(c->d_partials, grid, nacc, kNumParams, d_result, s));
+  return MOPT_OK;
+}
+
+int reprojCostAsync(mopt_cost *c, const double *x, double *d_sum, hipStream_t s) {
+  mopt::ReprojSweepArgs args;
+  fillReprojArgs(c, x, false, args);
+  const int grid = gridFor(c, envInt("MOPT_BLOCKS_PER_CU", 8));
+  SweepTimer timer(c, s);
+  MOPT_HIP_TRY(mopt::launchReprojCost(args, grid, s));
+  timer.stop();
+  MOPT_HIP_TRY(mopt::launchFinalizeCost(c->d_partials, grid, d_sum, s));
+  return MOPT_OK;
+}
+
+int linearizeAsyncImpl(mopt_cost *c, int jac_mode, const void *x, double *d_result,
+                       hipStream_t s) {
+  if (jac_mode < MOPT_JAC_ANALYTIC || jac_mode > MOPT_JAC_NUMERIC)
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "unknown jacobian_mode");
+  if (c->model == kModelReprojection)
+    return reprojLinearizeAsync(c, jac_mode, static_cast<const double *>(x), d_result, s);
+  if (c->scalar_bytes == 8)
+    return p2pLinearizeAsync<double>(c, jac_mode, static_cast<const double *>(x), d_result, s);
+  return p2pLinearizeAsync<float>(c, jac_mode, static_cast<const float *>(x), d_result, s);
+}
+
+int costAsyncImpl(mopt_cost *c, const void *x, double *d_sum, hipStream_t s) {
+  if (c->model == kModelReprojection)
+    return reprojCostAsync(c, static_cast<const double *>(x), d_sum, s);
+  if (c->scalar_bytes == 8) return p2pCostAsync<double>(c, static_cast<const double *>(x), d_sum, s);
+  return p2pCostAsync<float>(c, static_cast<const float *>(x), d_sum, s);
+}
+
+void storeResult(const mopt_cost *c, const double *res, void *hessian, void *b, void *sum_sq) {
+  if (c->scalar_bytes == 8) {
+    if (hessian) std::memcpy(hessian, res, 36 * sizeof(double));
+    if (b) std::memcpy(b, res + 36, 6 * sizeof(double));
+    if (sum_sq) *static_cast<double *>(sum_sq) = res[42];
+  } else {
+    if (hessian)
+      for (int k = 0; k < 36; ++k) static_cast<float *>(hessian)[k] = float(res[k]);
+    if (b)
+      for (int k = 0; k < 6; ++k) static_cast<float *>(b)[k] = float(res[36 + k]);
+    if (sum_sq) *static_cast<float *>(sum_sq) = float(res[42]);
+  }
+}
+
+int commonCreate(mopt_cost *c, int device) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(MOPT_ERR_NO_DEVICE, "no HIP device is visible to this process");
+  if (device < 0 || device >= ndev)
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "device index out of range");
+  c->device = device;
+  MOPT_HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  MOPT_HIP_TRY(hipGetDeviceProperties(&prop, device));
+  c->num_cus = prop.multiProcessorCount;
+  c->max_grid = c->num_cus * 16;
+  MOPT_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  MOPT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_partials),
+                         size_t(c->max_grid) * mopt::kAccFull * sizeof(double)));
+  MOPT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_result), kResultDoubles * sizeof(double)));
+  MOPT_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_result),
+                             kResultDoubles * sizeof(double), hipHostMallocDefault));
+  return MOPT_OK;
+}
+
+void destroyCost(mopt_cost *c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  for (auto &pr : c->pending_events) {
+    hipEventDestroy(pr.first);
+    hipEventDestroy(pr.second);
+  }
+  if (c->d_tiles) hipFree(c->d_tiles);
+  if (c->d_partials) hipFree(c->d_partials);
+  if (c->d_result) hipFree(c->d_result);
+  if (c->h_result) hipHostFree(c->h_result);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+// Copies (or adopts) two input arrays into device staging memory and returns device pointers.
+struct Staging {
+  void *a = nullptr, *b = nullptr;
+  bool owned = false;
+  ~Staging() {
+    if (owned) {
+      if (a) hipFree(a);
+      if (b) hipFree(b);
+    }
+  }
+};
+
+int stageInputs(const void *ha, size_t bytes_a, const void *hb, size_t bytes_b, unsigned flags,
+                hipStream_t s, Staging &st) {
+  if (flags & MOPT_INPUT_DEVICE) {
+    st.a = const_cast<void *>(ha);
+    st.b = const_cast<void *>(hb);
+    st.owned = false;
+    return MOPT_OK;
+  }
+  st.owned = true;
+  if (bytes_a) {
+    MOPT_HIP_TRY(hipMalloc(&st.a, bytes_a));
+    MOPT_HIP_TRY(hipMemcpyAsync(st.a, ha, bytes_a, hipMemcpyHostToDevice, s));
+  }
+  if (bytes_b) {
+    MOPT_HIP_TRY(hipMalloc(&st.b, bytes_b));
+    MOPT_HIP_TRY(hipMemcpyAsync(st.b, hb, bytes_b, hipMemcpyHostToDevice, s));
+  }
+  return MOPT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mopt_last_error(void) { return g_last_error.c_str(); }
+const char *mopt_version(void) { return "moptimizer_hip 0.1 (gfx950)"; }
+
+int mopt_device_count(int *count) {
+  if (!count) return fail(MOPT_ERR_INVALID_ARGUMENT, "count is NULL");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+  *count = n;
+  return MOPT_OK;
+}
+
+int mopt_point2point_create(mopt_cost **out, int device, int scalar_bytes, const void *src_xyz,
+                            const void *tgt_xyz, int64_t count, unsigned flags) {
+  if (!out) return fail(MOPT_ERR_INVALID_ARGUMENT, "out is NULL");
+  *out = nullptr;
+  if (scalar_bytes != 4 && scalar_bytes != 8)
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "scalar_bytes must be 4 or 8");
+  if (count < 0 || (count > 0 && (!src_xyz || !tgt_xyz)))
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "bad point arrays / count");
+  std::unique_ptr<mopt_cost, void (*)(mopt_cost *)> c(new (std::nothrow) mopt_cost, destroyCost);
+  if (!c) return fail(MOPT_ERR_HIP, "out of host memory");
+  c->scalar_bytes = scalar_bytes;
+  c->model = kModelPoint2Point;
+  c->n_out = 3;
+  c->count = count;
+  const int tile_points =
+      scalar_bytes == 8 ? mopt::TileShape<double>::kPoints : mopt::TileShape<float>::kPoints;
+  const long long tiles = (count + tile_points - 1) / tile_points;
+  if (tiles > std::numeric_limits<int>::max())
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "count too large");
+  c->num_tiles = int(tiles);
+  int rc = commonCreate(c.get(), device);
+  if (rc != MOPT_OK) return rc;
+
+  const size_t tile_bytes = size_t(tile_points) * 6 * scalar_bytes;
+  if (c->num_tiles > 0) {
+    MOPT_HIP_TRY(hipMalloc(&c->d_tiles, tile_bytes * c->num_tiles));
+    Staging st;
+    const size_t bytes = size_t(count) * 3 * scalar_bytes;
+    rc = stageInputs(src_xyz, bytes, tgt_xyz, bytes, flags, c->stream, st);
+    if (rc != MOPT_OK) return rc;
+    if (scalar_bytes == 8)
+      MOPT_HIP_TRY(mopt::launchRelayoutP2P<double>(
+          static_cast<const double *>(st.a), static_cast<const double *>(st.b), count,
+          static_cast<double *>(c->d_tiles), c->num_tiles, c->stream));
+    else
+      MOPT_HIP_TRY(mopt::launchRelayoutP2P<float>(
+          static_cast<const float *>(st.a), static_cast<const float *>(st.b), count,
+          static_cast<float *>(c->d_tiles), c->num_tiles, c->stream));
+    MOPT_HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  *out = c.release();
+  return MOPT_OK;
+}
+
+int mopt_reprojection_create(mopt_cost **out, int device, const double *points_xyzw,
+                             const int32_t *pixels_uv, int64_t count, const double *camera_3x4,
+                             const double *frame_4x4, unsigned flags) {
+  if (!out) return fail(MOPT_ERR_INVALID_ARGUMENT, "out is NULL");
+  *out = nullptr;
+  if (count <= 0 || !points_xyzw || !pixels_uv)
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "Empty point / pixel list");
+  std::unique_ptr<mopt_cost, void (*)(mopt_cost *)> c(new (std::nothrow) mopt_cost, destroyCost);
+  if (!c) return fail(MOPT_ERR_HIP, "out of host memory");
+  c->scalar_bytes = 8;
+  c->model = kModelReprojection;
+  c->n_out = 2;
+  c->count = count;
+  defaultReprojConstants<double>(c->camera, c->frame);
+  if (camera_3x4) std::memcpy(c->camera, camera_3x4, sizeof c->camera);
+  if (frame_4x4) std::memcpy(c->frame, frame_4x4, sizeof c->frame);
+  const long long tiles = (count + mopt::kReprojTilePoints - 1) / mopt::kReprojTilePoints;
+  if (tiles > std::numeric_limits<int>::max())
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "count too large");
+  c->num_tiles = int(tiles);
+  int rc = commonCreate(c.get(), device);
+  if (rc != MOPT_OK) return rc;
+  MOPT_HIP_TRY(hipMalloc(&c->d_tiles, size_t(mopt::kReprojTileBytes) * c->num_tiles));
+  Staging st;
+  rc = stageInputs(points_xyzw, size_t(count) * 32, pixels_uv, size_t(count) * 8, flags, c->stream,
+                   st);
+  if (rc != MOPT_OK) return rc;
+  MOPT_HIP_TRY(mopt::launchRelayoutReproj(static_cast<const double *>(st.a),
+                                          static_cast<const int32_t *>(st.b), count,
+                                          static_cast<unsigned char *>(c->d_tiles), c->num_tiles,
+                                          c->stream));
+  MOPT_HIP_TRY(hipStreamSynchronize(c->stream));
+  *out = c.release();
+  return MOPT_OK;
+}
+
+int mopt_cost_destroy(mopt_cost *cost) {
+  destroyCost(cost);
+  return MOPT_OK;
+}
+
+int mopt_cost_set_covariance(mopt_cost *c, const void *cov_colmajor) {
+  if (!c) return fail(MOPT_ERR_INVALID_ARGUMENT, "cost is NULL");
+  const int m = c->n_out;
+  for (int k = 0; k < 9; ++k) c->cov[k] = 0.0;
+  for (int a = 0; a < 3; ++a) c->cov[a * 3 + a] = 1.0;
+  if (cov_colmajor) {
+    for (int a = 0; a < m; ++a)
+      for (int b = 0; b < m; ++b) {
+        const double v = c->scalar_bytes == 8
+                             ? static_cast<const double *>(cov_colmajor)[b * m + a]
+                             : double(static_cast<const float *>(cov_colmajor)[b * m + a]);
+        c->cov[a * 3 + b] = v;
+      }
+    if (m == 2) c->cov[8] = 1.0;
+  }
+  bool identity = true, symmetric = true;
+  for (int a = 0; a < m; ++a)
+    for (int b = 0; b < m; ++b) {
+      if (c->cov[a * 3 + b] != (a == b ? 1.0 : 0.0)) identity = false;
+      if (c->cov[a * 3 + b] != c->cov[b * 3 + a]) symmetric = false;
+    }
+  c->cov_mode = identity ? mopt::kCovIdentity
+                         : (symmetric ? mopt::kCovSymmetric : mopt::kCovGeneral);
+  return MOPT_OK;
+}
+
+int mopt_cost_set_loss(mopt_cost *c, int loss_kind, double parameter) {
+  if (!c) return fail(MOPT_ERR_INVALID_ARGUMENT, "cost is NULL");
+  if (loss_kind != MOPT_LOSS_NONE && loss_kind != MOPT_LOSS_GEMAN_MCCLURE)
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "unknown loss_kind");
+  c->loss_kind = loss_kind;
+  c->loss_param = parameter;
+  return MOPT_OK;
+}
+
+int mopt_cost_set_kernel_variant(mopt_cost *c, int variant) {
+  if (!c) return fail(MOPT_ERR_INVALID_ARGUMENT, "cost is NULL");
+  if (variant < MOPT_KERNEL_AUTO || variant > MOPT_KERNEL_MOMENTS)
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "unknown kernel variant");
+  if (variant == MOPT_KERNEL_MOMENTS && c->model != kModelPoint2Point)
+    return fail(MOPT_ERR_UNSUPPORTED, "the reprojection Jacobian is not affine in the point");
+  c->variant = variant;
+  return MOPT_OK;
+}
+
+int mopt_cost_info(const mopt_cost *c, int64_t *count, int *n, int *m, int *scalar_bytes,
+                   int *device) {
+  if (!c) return fail(MOPT_ERR_INVALID_ARGUMENT, "cost is NULL");
+  if (count) *count = c->count;
+  if (n) *n = kNumParams;
+  if (m) *m = c->n_out;
+  if (scalar_bytes) *scalar_bytes = c->scalar_bytes;
+  if (device) *device = c->device;
+  return MOPT_OK;
+}
+
+int mopt_cost_linearize_async(mopt_cost *c, int jacobian_mode, const void *x, double *d_result,
+                              void *hip_stream) {
+  if (!c || !x || !d_result) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
+  MOPT_HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+  return linearizeAsyncImpl(c, jacobian_mode, x, d_result, s);
+}
+
+int mopt_cost_compute_async(mopt_cost *c, const void *x, double *d_sum_sq, void *hip_stream) {
+  if (!c || !x || !d_sum_sq) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
+  MOPT_HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+  return costAsyncImpl(c, x, d_sum_sq, s);
+}
+
+int mopt_cost_linearize(mopt_cost *c, int jacobian_mode, const void *x, void *hessian, void *b,
+                        void *sum_sq) {
+  if (!c || !x) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
+  MOPT_HIP_TRY(hipSetDevice(c->device));
+  const int rc = linearizeAsyncImpl(c, jacobian_mode, x, c->d_result, c->stream);
+  if (rc != MOPT_OK) return rc;
+  MOPT_HIP_TRY(hipMemcpyAsync(c->h_result, c->d_result, kResultDoubles * sizeof(double),
+                              hipMemcpyDeviceToHost, c->stream));
+  MOPT_HIP_TRY(hipStreamSynchronize(c->stream));
+  storeResult(c, c->h_result, hessian, b, sum_sq);
+  return MOPT_OK;
+}
+
+int mopt_cost_compute(mopt_cost *c, const void *x, void *sum_sq) {
+  if (!c || !x || !sum_sq) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
+  MOPT_HIP_TRY(hipSetDevice(c->device));
+  const int rc = costAsyncImpl(c, x, c->d_result + 42, c->stream);
+  if (rc != MOPT_OK) return rc;
+  MOPT_HIP_TRY(hipMemcpyAsync(c->h_result + 42, c->d_result + 42, sizeof(double),
+                              hipMemcpyDeviceToHost, c->stream));
+  MOPT_HIP_TRY(hipStreamSynchronize(c->stream));
+  storeResult(c, c->h_result, nullptr, nullptr, sum_sq);
+  return MOPT_OK;
+}
+
+int mopt_cost_stream(mopt_cost *c, void **hip_stream) {
+  if (!c || !hip_stream) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
+  *hip_stream = c->stream;
+  return MOPT_OK;
+}
+
+int mopt_cost_synchronize(mopt_cost *c) {
+  if (!c) return fail(MOPT_ERR_INVALID_ARGUMENT, "cost is NULL");
+  MOPT_HIP_TRY(hipSetDevice(c->device));
+  MOPT_HIP_TRY(hipStreamSynchronize(c->stream));
+  return MOPT_OK;
+}
+
+int mopt_cost_set_profiling(mopt_cost *c, int enabled) {
+  if (!c) return fail(MOPT_ERR_INVALID_ARGUMENT, "cost is NULL");
+  MOPT_HIP_TRY(hipSetDevice(c->device));
+  const int rc = resolvePendingEvents(c);
+  if (rc != MOPT_OK) return rc;
+  c->profiling = enabled != 0;
+  c->sweep_ms_total = 0.0;
+  c->sweep_launches = 0;
+  return MOPT_OK;
+}
+
+int mopt_cost_profile(mopt_cost *c, double *sweep_ms_total, int64_t *sweep_launches) {
+  if (!c) return fail(MOPT_ERR_INVALID_ARGUMENT, "cost is NULL");
+  MOPT_HIP_TRY(hipSetDevice(c->device));
+  const int rc = resolvePendingEvents(c);
+  if (rc != MOPT_OK) return rc;
+  if (sweep_ms_total) *sweep_ms_total = c->sweep_ms_total;
+  if (sweep_launches) *sweep_launches = c->sweep_launches;
+  return MOPT_OK;
+}
+
+}  // extern "C"
+
+// ---- single-process multi-GPU group --------------------------------------------------------
+struct mopt_group {
+  std::vector<mopt_cost *> shards;
+  std::vector<ncclComm_t> comms;
+  int scalar_bytes = 8;
+};
+
+namespace {
+void destroyGroup(mopt_group *g) {
+  if (!g) return;
+  for (auto comm : g->comms)
+    if (comm) ncclCommDestroy(comm);
+  for (auto *c : g->shards) destroyCost(c);
+  delete g;
+}
+}  // namespace
+
+extern "C" {
+
+int mopt_group_point2point_create(mopt_group **out, const int *devices, int num_devices,
+                                  int scalar_bytes, const void *src_xyz, const void *tgt_xyz,
+                                  int64_t count) {
+  if (!out) return fail(MOPT_ERR_INVALID_ARGUMENT, "out is NULL");
+  *out = nullptr;
+  if (!devices || num_devices < 1) return fail(MOPT_ERR_INVALID_ARGUMENT, "no devices given");
+  if (scalar_bytes != 4 && scalar_bytes != 8)
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "scalar_bytes must be 4 or 8");
+  std::unique_ptr<mopt_group, void (*)(mopt_group *)> g(new (std::nothrow) mopt_group,
+                                                        destroyGroup);
+  if (!g) return fail(MOPT_ERR_HIP, "out of host memory");
+  g->scalar_bytes = scalar_bytes;
+  const char *src = static_cast<const char *>(src_xyz);
+  const char *tgt = static_cast<const char *>(tgt_xyz);
+  for (int k = 0; k < num_devices; ++k) {
+    // contiguous index ranges [k N / G, (k + 1) N / G)
+    const int64_t lo = count * k / num_devices, hi = count * (k + 1) / num_devices;
+    mopt_cost *shard = nullptr;
+    const int rc = mopt_point2point_create(&shard, devices[k], scalar_bytes,
+                                           src + size_t(lo) * 3 * scalar_bytes,
+                                           tgt + size_t(lo) * 3 * scalar_bytes, hi - lo,
+                                           MOPT_INPUT_HOST);
+    if (rc != MOPT_OK) return rc;
+    g->shards.push_back(shard);
+  }
+  if (num_devices > 1) {
+    g->comms.assign(num_devices, nullptr);
+    MOPT_NCCL_TRY(ncclCommInitAll(g->comms.data(), num_devices, devices));
+  }
+  *out = g.release();
+  return MOPT_OK;
+}
+
+int mopt_group_destroy(mopt_group *group) {
+  destroyGroup(group);
+  return MOPT_OK;
+}
+
+int mopt_group_size(const mopt_group *g, int *num_devices) {
+  if (!g || !num_devices) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
+  *num_devices = int(g->shards.size());
+  return MOPT_OK;
+}
+
+int mopt_group_set_covariance(mopt_group *g, const void *cov_colmajor) {
+  if (!g) return fail(MOPT_ERR_INVALID_ARGUMENT, "group is NULL");
+  for (auto *c : g->shards) {
+    const int rc = mopt_cost_set_covariance(c, cov_colmajor);
+    if (rc != MOPT_OK) return rc;
+  }
+  return MOPT_OK;
+}
+
+int mopt_group_set_loss(mopt_group *g, int loss_kind, double parameter) {
+  if (!g) return fail(MOPT_ERR_INVALID_ARGUMENT, "group is NULL");
+  for (auto *c : g->shards) {
+    const int rc = mopt_cost_set_loss(c, loss_kind, parameter);
+    if (rc != MOPT_OK) return rc;
+  }
+  return MOPT_OK;
+}
+
+static int groupReduceAndFetch(mopt_group *g, int offset, int n_doubles) {
+  const int G = int(g->shards.size());
+  if (G > 1) {
+    // one all-reduce per sweep over xGMI; every rank ends with the full sums
+    MOPT_NCCL_TRY(ncclGroupStart());
+    for (int k = 0; k < G; ++k) {
+      mopt_cost *c = g->shards[k];
+      ncclResult_t r = ncclAllReduce(c->d_result + offset, c->d_result + offset, n_doubles,
+                                     ncclDouble, ncclSum, g->comms[k], c->stream);
+      if (r != ncclSuccess) {
+        ncclGroupEnd();
+        return fail(MOPT_ERR_RCCL, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+      }
+    }
+    MOPT_NCCL_TRY(ncclGroupEnd());
+  }
+  mopt_cost *c0 = g->shards[0];
+  MOPT_HIP_TRY(hipSetDevice(c0->device));
+  MOPT_HIP_TRY(hipMemcpyAsync(c0->h_result + offset, c0->d_result + offset,
+                              n_doubles * sizeof(double), hipMemcpyDeviceToHost, c0->stream));
+  for (int k = G - 1; k >= 0; --k) {
+    MOPT_HIP_TRY(hipSetDevice(g->shards[k]->device));
+    MOPT_HIP_TRY(hipStreamSynchronize(g->shards[k]->stream));
+  }
+  return MOPT_OK;
+}
+
+int mopt_group_linearize(mopt_group *g, int jacobian_mode, const void *x, void *hessian, void *b,
+                         void *sum_sq) {
+  if (!g || !x) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
+  for (auto *c : g->shards) {
+    MOPT_HIP_TRY(hipSetDevice(c->device));
+    const int rc = linearizeAsyncImpl(c, jacobian_mode, x, c->d_result, c->stream);
+    if (rc != MOPT_OK) return rc;
+  }
+  const int rc = groupReduceAndFetch(g, 0, kResultDoubles);
+  if (rc != MOPT_OK) return rc;
+  storeResult(g->shards[0], g->shards[0]->h_result, hessian, b, sum_sq);
+  return MOPT_OK;
+}
+
+int mopt_group_compute(mopt_group *g, const void *x, void *sum_sq) {
+  if (!g || !x || !sum_sq) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
+  for (auto *c : g->shards) {
+    MOPT_HIP_TRY(hipSetDevice(c->device));
+    const int rc = costAsyncImpl(c, x, c->d_result + 42, c->stream);
+    if (rc != MOPT_OK) return rc;
+  }
+  const int rc = groupReduceAndFetch(g, 42, 1);
+  if (rc != MOPT_OK) return rc;
+  storeResult(g->shards[0], g->shards[0]->h_result, nullptr, nullptr, sum_sq);
+  return MOPT_OK;
+}
+
+}  // extern "C"

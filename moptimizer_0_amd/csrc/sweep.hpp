@@ -1,0 +1,106 @@
+// Internal interface between the C ABI (c_abi.cpp) and the gfx950 kernels (sweep_kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace mopt {
+
+constexpr int kBlockThreads = 256;  // 4 wavefronts of 64
+constexpr int kNumParams = 6;       // (t, w) of SE(3)
+
+// ---- HBM layout ----------------------------------------------------------------------------
+// Correspondences live in HBM as *tiled structure-of-arrays*: a tile holds kBlockThreads * V
+// consecutive correspondences (V = 16 B / sizeof(Scalar): 2 in fp64, 4 in fp32) as six planes
+// sx | sy | sz | tx | ty | tz of tile-length each.  One wavefront load instruction then reads
+// 64 lanes x 16 B = 1 KiB of contiguous memory, a workgroup's six loads cover one contiguous
+// 24 KiB tile, and consecutive workgroups walk consecutive tiles — the whole sweep is a single
+// linear stream over count * 48 B (fp64).  The last tile is zero-padded and masked by index.
+template <typename S>
+struct TileShape {
+  static constexpr int kVec = 16 / int(sizeof(S));
+  static constexpr int kPoints = kBlockThreads * kVec;
+  static constexpr int kP2PPlanes = 6;
+  static constexpr int kP2PScalars = kPoints * kP2PPlanes;
+};
+// Reprojection elements: planes px | py | pz | pw (fp64) followed by interleaved int32 (u, v)
+// pairs; 512 elements per tile, 20 KiB, 40 B per element.
+constexpr int kReprojTilePoints = kBlockThreads * 2;
+constexpr int kReprojTileBytes = kReprojTilePoints * (4 * 8 + 2 * 4);
+
+enum JacMode : int { kJacAnalytic = 0, kJacAnalyticTst = 1, kJacNumeric = 2 };
+enum CovMode : int { kCovIdentity = 0, kCovSymmetric = 1, kCovGeneral = 2 };
+enum LossKind : int { kLossNone = 0, kLossGemanMcClure = 1 };
+
+// Accumulator counts per workgroup partial.
+constexpr int kAccSym = 21 + 6 + 1;   // upper triangle of H | b | sum_sq
+constexpr int kAccFull = 36 + 6 + 1;  // full H (non-symmetric covariance) | b | sum_sq
+constexpr int kAccMoments = 23;       // w | w p (3) | w p p^T (6) | w r (3) | w p r^T (9) | r^T r
+constexpr int kAccCost = 1;
+constexpr int kResultDoubles = kNumParams * kNumParams + kNumParams + 1;  // 43
+
+// Per-sweep constants, passed by value as the kernel argument.
+template <typename S>
+struct P2PSweepArgs {
+  const S *tiles;
+  long long count;
+  int num_tiles;
+  int loss_kind;
+  S loss_param;
+  S T[1 + kNumParams][12];  // row-major [R | t] at x and at x + h_j e_j
+  S inv_h[kNumParams];      // 1 / h_j (forward-difference steps)
+  S cov[9];                 // row-major m x m (cov[a * 3 + c] = S(a, c))
+  double *partials;         // [grid][num accumulators]
+};
+
+struct ReprojSweepArgs {
+  const unsigned char *tiles;
+  long long count;
+  int num_tiles;
+  int loss_kind;
+  double loss_param;
+  double M[1 + kNumParams][12];  // row-major 3x4 projection (K T C) at x and x + h_j e_j
+  double inv_h[kNumParams];
+  double cov[4];  // row-major 2 x 2
+  double *partials;
+};
+
+// Affine-Jacobian basis for the moment finalisation: J(p) = J0 + px Jx + py Jy + pz Jz,
+// each row-major 3 x 6, plus the covariance (row-major 3 x 3).
+struct AffineBasis {
+  double J[4][18];
+  double cov[9];
+};
+
+// ---- launches (all asynchronous on `stream`) ------------------------------------------------
+template <typename S>
+hipError_t launchRelayoutP2P(const S *src_xyz, const S *tgt_xyz, long long count, S *tiles,
+                             int num_tiles, hipStream_t stream);
+hipError_t launchRelayoutReproj(const double *points_xyzw, const int32_t *pixels_uv,
+                                long long count, unsigned char *tiles, int num_tiles,
+                                hipStream_t stream);
+
+// literal per-point evaluation; partials: [grid][kAccSym or kAccFull]
+template <typename S>
+hipError_t launchP2PLinearizeLiteral(const P2PSweepArgs<S> &args, int jac_mode, int cov_mode,
+                                     int grid, hipStream_t stream);
+// moment accumulation (analytic modes; numeric via the affine forward-difference basis)
+template <typename S>
+hipError_t launchP2PMoments(const P2PSweepArgs<S> &args, int grid, hipStream_t stream);
+template <typename S>
+hipError_t launchP2PCost(const P2PSweepArgs<S> &args, int grid, hipStream_t stream);
+
+hipError_t launchReprojLinearize(const ReprojSweepArgs &args, int cov_mode, int grid,
+                                 hipStream_t stream);
+hipError_t launchReprojCost(const ReprojSweepArgs &args, int grid, hipStream_t stream);
+
+// partials[grid][nacc] -> result[n*n + n + 1] (H column-major | b | sum_sq)
+hipError_t launchFinalizeDense(const double *partials, int grid, int nacc, int n, double *result,
+                               hipStream_t stream);
+hipError_t launchFinalizeMoments(const double *partials, int grid, const AffineBasis &basis,
+                                 double *result, hipStream_t stream);
+hipError_t launchFinalizeCost(const double *partials, int grid, double *result,
+                              hipStream_t stream);
+
+}  // namespace mopt

@@ -1,0 +1,657 @@
+// gfx950 (CDNA4, MI355X) kernels of the per-residual linearization sweep.
+//
+// What is computed follows /root/reference/include/moptimizer/linearization.h:
+//   for every index i:  r_i, J_i  ->  w_i = loss(|r_i|^2)
+//                       H += w_i J_i^T S J_i ;  b += w_i J_i^T S r_i ;  sum += r_i^T r_i
+// (:101-117 forward-difference form, :143-154 analytic form, :36-47 cost only), with the
+// point-to-point model of tst/point2point.cpp:32-78 and the reprojection model of
+// tst/camera_calibration.cpp:35-41 built in as device code in place of the per-point virtual
+// calls.  How it is computed is laid out for the hardware:
+//
+//   * HBM-bound streaming reduction (48 B in, O(1) out per correspondence): no MFMA, no LDS
+//     staging of inputs — every lane issues 16-byte loads straight to VGPRs, six per tile, all
+//     six landing in one contiguous 24 KiB tile (layout in sweep.hpp), with the next tile's loads
+//     issued before the current tile's arithmetic so each wave keeps 2 x 96 B per lane in flight.
+//   * 64-wide wavefronts: per-thread register accumulators -> wave reduction with shuffles ->
+//     4 waves combined through LDS -> one partial row per workgroup in HBM.
+//   * A fixed grid (workgroups per CU x CUs) strides over tiles, so the summation tree — and
+//     therefore the result — is deterministic for a given device and count.
+//   * A second tiny kernel adds the workgroup partials in a fixed order and writes
+//     H (column-major) | b | sum_sq; no atomics anywhere.
+#include "sweep.hpp"
+
+namespace mopt {
+namespace {
+
+template <typename S>
+struct alignas(16) Pack {
+  S v[16 / sizeof(S)];
+};
+
+template <typename S>
+__device__ __forceinline__ Pack<S> loadPack(const S *p) {
+  return *reinterpret_cast<const Pack<S> *>(p);
+}
+
+template <typename S>
+__device__ __forceinline__ S lossWeight(int kind, S param, S s) {
+  if (kind == kLossGemanMcClure) {
+    const S d = s + param;
+    return (param * param) / (d * d);
+  }
+  return S(1);
+}
+
+// r = (R p + t) - q with the association of a 4x4 * [p;1] product followed by the subtraction
+// (tst/point2point.cpp:42-45).
+template <typename S>
+__device__ __forceinline__ void p2pResidual(const S (&T)[12], const S (&p)[3], const S (&q)[3],
+                                            S (&r)[3]) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const S warped = ((T[a * 4 + 0] * p[0] + T[a * 4 + 1] * p[1]) + T[a * 4 + 2] * p[2]) +
+                     T[a * 4 + 3];
+    r[a] = warped - q[a];
+  }
+}
+
+__device__ __forceinline__ double waveSum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// Per-thread accumulators -> one row of `NACC` doubles per workgroup.
+template <int NACC>
+__device__ __forceinline__ void blockReduceStore(double (&acc)[NACC], double *out_row) {
+  constexpr int kWaves = kBlockThreads / 64;
+  __shared__ double lds[kWaves][NACC];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) {
+    const double v = waveSum(acc[k]);
+    if (lane == 0) lds[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NACC) {
+    double v = lds[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) v += lds[w][threadIdx.x];
+    out_row[threadIdx.x] = v;
+  }
+}
+
+// acc += w J^T S J (upper triangle, or all 36 entries when S is not symmetric), w J^T S r, r^T r.
+// J is m x 6 (row index = output), cov row-major m x m.
+template <typename S, int M, int COV, int NACC>
+__device__ __forceinline__ void accumulateDense(const S (&J)[M][6], const S (&r)[M], S w, S rr,
+                                                const S *cov, double (&acc)[NACC]) {
+  S SJ[M][6];
+  S Sr[M];
+  if (COV == kCovIdentity) {
+#pragma unroll
+    for (int a = 0; a < M; ++a) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) SJ[a][j] = J[a][j];
+      Sr[a] = r[a];
+    }
+  } else {
+#pragma unroll
+    for (int a = 0; a < M; ++a) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        S v = 0;
+#pragma unroll
+        for (int c = 0; c < M; ++c) v += cov[a * M + c] * J[c][j];
+        SJ[a][j] = v;
+      }
+      S v = 0;
+#pragma unroll
+      for (int c = 0; c < M; ++c) v += cov[a * M + c] * r[c];
+      Sr[a] = v;
+    }
+  }
+  S wJ[M][6];
+#pragma unroll
+  for (int a = 0; a < M; ++a)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) wJ[a][i] = w * J[a][i];
+
+  constexpr bool kFull = (NACC == kAccFull);
+  constexpr int kNH = kFull ? 36 : 21;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      if (!kFull && i > j) continue;
+      S v = 0;
+#pragma unroll
+      for (int a = 0; a < M; ++a) v += wJ[a][i] * SJ[a][j];
+      const int k = kFull ? (j * 6 + i) : (j * (j + 1) / 2 + i);
+      acc[k] += double(v);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    S v = 0;
+#pragma unroll
+    for (int a = 0; a < M; ++a) v += wJ[a][i] * Sr[a];
+    acc[kNH + i] += double(v);
+  }
+  acc[kNH + 6] += double(rr);
+}
+
+// ---- point-to-point, literal evaluation ------------------------------------------------------
+template <typename S, int JAC, int COV>
+__device__ __forceinline__ void p2pPointLiteral(
+    const P2PSweepArgs<S> &A, const S (&p)[3], const S (&q)[3], bool valid,
+    double (&acc)[(COV == kCovGeneral) ? kAccFull : kAccSym]) {
+  S r[3];
+  p2pResidual<S>(A.T[0], p, q, r);
+  S J[3][6];
+  if (JAC == kJacAnalytic) {
+    // [ I3 | -skew(p) ], row-major (model.h:35-42)
+    const S z = S(0), o = S(1);
+    const S Ja[3][6] = {{o, z, z, z, p[2], -p[1]}, {z, o, z, -p[2], z, p[0]}, {z, z, o, p[1], -p[0], z}};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) J[a][j] = Ja[a][j];
+  } else if (JAC == kJacAnalyticTst) {
+    // the same 18 numbers written column-major and read row-major (tst/point2point.cpp:71-75
+    // against linearization.h:17-18)
+    const S z = S(0), o = S(1);
+    const S Jt[3][6] = {{o, z, z, z, o, z}, {z, z, o, z, -p[2], p[1]}, {p[2], z, -p[0], -p[1], p[0], z}};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) J[a][j] = Jt[a][j];
+  } else {
+    // forward differences, nominal step (linearization.h:103-106); 1/h_j is formed on the host
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      S rp[3];
+      p2pResidual<S>(A.T[1 + j], p, q, rp);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) J[a][j] = (rp[a] - r[a]) * A.inv_h[j];
+    }
+  }
+  const S rr = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+  const S w = lossWeight<S>(A.loss_kind, A.loss_param, rr);
+  accumulateDense<S, 3, COV>(J, r, valid ? w : S(0), valid ? rr : S(0), A.cov, acc);
+}
+
+template <typename S, int JAC, int COV>
+__global__ __launch_bounds__(kBlockThreads) void p2pLinearizeLiteralKernel(
+    const P2PSweepArgs<S> A) {
+  constexpr int NACC = (COV == kCovGeneral) ? kAccFull : kAccSym;
+  constexpr int V = TileShape<S>::kVec;
+  constexpr int TP = TileShape<S>::kPoints;
+  double acc[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+
+  int tile = blockIdx.x;
+  Pack<S> cur[6];
+  if (tile < A.num_tiles) {
+    const S *base = A.tiles + size_t(tile) * TileShape<S>::kP2PScalars + threadIdx.x * V;
+#pragma unroll
+    for (int pl = 0; pl < 6; ++pl) cur[pl] = loadPack<S>(base + pl * TP);
+  }
+  while (tile < A.num_tiles) {
+    const int next = tile + gridDim.x;
+    Pack<S> nxt[6];
+    if (next < A.num_tiles) {
+      const S *base = A.tiles + size_t(next) * TileShape<S>::kP2PScalars + threadIdx.x * V;
+#pragma unroll
+      for (int pl = 0; pl < 6; ++pl) nxt[pl] = loadPack<S>(base + pl * TP);
+    }
+    const long long first = (long long)tile * TP + threadIdx.x * V;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const S p[3] = {cur[0].v[e], cur[1].v[e], cur[2].v[e]};
+      const S q[3] = {cur[3].v[e], cur[4].v[e], cur[5].v[e]};
+      p2pPointLiteral<S, JAC, COV>(A, p, q, first + e < A.count, acc);
+    }
+    if (next < A.num_tiles) {
+#pragma unroll
+      for (int pl = 0; pl < 6; ++pl) cur[pl] = nxt[pl];
+    }
+    tile = next;
+  }
+  blockReduceStore<NACC>(acc, A.partials + size_t(blockIdx.x) * NACC);
+}
+
+// ---- point-to-point, weighted moments --------------------------------------------------------
+// Every Jacobian this model produces is affine in the source point p (analytic: [I | -skew(p)];
+// forward differences: ((R_j - R) p + (t_j - t)) / h_j), so
+//   sum_i w_i J_i^T S J_i  and  sum_i w_i J_i^T S r_i
+// are linear in the 22 moments  sum w, sum w p, sum w p p^T, sum w r, sum w p r^T.  The sweep
+// accumulates those (plus sum r^T r); finalizeMomentsKernel contracts them with the basis.
+template <typename S>
+__global__ __launch_bounds__(kBlockThreads) void p2pMomentsKernel(const P2PSweepArgs<S> A) {
+  constexpr int V = TileShape<S>::kVec;
+  constexpr int TP = TileShape<S>::kPoints;
+  double acc[kAccMoments];
+#pragma unroll
+  for (int k = 0; k < kAccMoments; ++k) acc[k] = 0.0;
+
+  int tile = blockIdx.x;
+  Pack<S> cur[6];
+  if (tile < A.num_tiles) {
+    const S *base = A.tiles + size_t(tile) * TileShape<S>::kP2PScalars + threadIdx.x * V;
+#pragma unroll
+    for (int pl = 0; pl < 6; ++pl) cur[pl] = loadPack<S>(base + pl * TP);
+  }
+  while (tile < A.num_tiles) {
+    const int next = tile + gridDim.x;
+    Pack<S> nxt[6];
+    if (next < A.num_tiles) {
+      const S *base = A.tiles + size_t(next) * TileShape<S>::kP2PScalars + threadIdx.x * V;
+#pragma unroll
+      for (int pl = 0; pl < 6; ++pl) nxt[pl] = loadPack<S>(base + pl * TP);
+    }
+    const long long first = (long long)tile * TP + threadIdx.x * V;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const S p[3] = {cur[0].v[e], cur[1].v[e], cur[2].v[e]};
+      const S q[3] = {cur[3].v[e], cur[4].v[e], cur[5].v[e]};
+      S r[3];
+      p2pResidual<S>(A.T[0], p, q, r);
+      const bool valid = first + e < A.count;
+      S rr = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+      S w = lossWeight<S>(A.loss_kind, A.loss_param, rr);
+      w = valid ? w : S(0);
+      rr = valid ? rr : S(0);
+      const S wp[3] = {w * p[0], w * p[1], w * p[2]};
+      const S wr[3] = {w * r[0], w * r[1], w * r[2]};
+      acc[0] += double(w);
+      acc[1] += double(wp[0]);
+      acc[2] += double(wp[1]);
+      acc[3] += double(wp[2]);
+      acc[4] += double(wp[0] * p[0]);
+      acc[5] += double(wp[0] * p[1]);
+      acc[6] += double(wp[0] * p[2]);
+      acc[7] += double(wp[1] * p[1]);
+      acc[8] += double(wp[1] * p[2]);
+      acc[9] += double(wp[2] * p[2]);
+      acc[10] += double(wr[0]);
+      acc[11] += double(wr[1]);
+      acc[12] += double(wr[2]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[13 + 3 * k + c] += double(p[k] * wr[c]);
+      acc[22] += double(rr);
+    }
+    if (next < A.num_tiles) {
+#pragma unroll
+      for (int pl = 0; pl < 6; ++pl) cur[pl] = nxt[pl];
+    }
+    tile = next;
+  }
+  blockReduceStore<kAccMoments>(acc, A.partials + size_t(blockIdx.x) * kAccMoments);
+}
+
+// ---- point-to-point, cost only (linearization.h:36-63) ----------------------------------------
+template <typename S>
+__global__ __launch_bounds__(kBlockThreads) void p2pCostKernel(const P2PSweepArgs<S> A) {
+  constexpr int V = TileShape<S>::kVec;
+  constexpr int TP = TileShape<S>::kPoints;
+  double acc[1] = {0.0};
+  for (int tile = blockIdx.x; tile < A.num_tiles; tile += gridDim.x) {
+    const S *base = A.tiles + size_t(tile) * TileShape<S>::kP2PScalars + threadIdx.x * V;
+    Pack<S> cur[6];
+#pragma unroll
+    for (int pl = 0; pl < 6; ++pl) cur[pl] = loadPack<S>(base + pl * TP);
+    const long long first = (long long)tile * TP + threadIdx.x * V;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const S p[3] = {cur[0].v[e], cur[1].v[e], cur[2].v[e]};
+      const S q[3] = {cur[3].v[e], cur[4].v[e], cur[5].v[e]};
+      S r[3];
+      p2pResidual<S>(A.T[0], p, q, r);
+      const S rr = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+      acc[0] += (first + e < A.count) ? double(rr) : 0.0;
+    }
+  }
+  blockReduceStore<1>(acc, A.partials + blockIdx.x);
+}
+
+// ---- reprojection (camera calibration), fp64, forward differences ------------------------------
+struct alignas(16) Int4Pack {
+  int v[4];
+};
+
+__device__ __forceinline__ void reprojResidual(const double (&Mx)[12], const double (&P)[4],
+                                               double u, double v, double (&r)[2]) {
+  double o[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+    o[a] = ((Mx[a * 4 + 0] * P[0] + Mx[a * 4 + 1] * P[1]) + Mx[a * 4 + 2] * P[2]) +
+           Mx[a * 4 + 3] * P[3];
+  r[0] = u - (o[0] / o[2]);  // tst/camera_calibration.cpp:38
+  r[1] = v - (o[1] / o[2]);  // :39
+}
+
+template <int COV, bool COST_ONLY>
+__global__ __launch_bounds__(kBlockThreads) void reprojKernel(const ReprojSweepArgs A) {
+  constexpr int NACC = COST_ONLY ? 1 : ((COV == kCovGeneral) ? kAccFull : kAccSym);
+  double acc[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+
+  for (int tile = blockIdx.x; tile < A.num_tiles; tile += gridDim.x) {
+    const unsigned char *tb = A.tiles + size_t(tile) * kReprojTileBytes;
+    const double *planes = reinterpret_cast<const double *>(tb) + threadIdx.x * 2;
+    Pack<double> pk[4];
+#pragma unroll
+    for (int pl = 0; pl < 4; ++pl) pk[pl] = loadPack<double>(planes + pl * kReprojTilePoints);
+    const Int4Pack px = *reinterpret_cast<const Int4Pack *>(
+        tb + size_t(4) * kReprojTilePoints * 8 + threadIdx.x * 16);
+    const long long first = (long long)tile * kReprojTilePoints + threadIdx.x * 2;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const double P[4] = {pk[0].v[e], pk[1].v[e], pk[2].v[e], pk[3].v[e]};
+      const double u = double(px.v[2 * e + 0]);
+      const double v = double(px.v[2 * e + 1]);
+      const bool valid = first + e < A.count;
+      double r[2];
+      reprojResidual(A.M[0], P, u, v, r);
+      const double rr = r[0] * r[0] + r[1] * r[1];
+      if constexpr (COST_ONLY) {
+        acc[0] += valid ? rr : 0.0;
+      } else {
+        double J[2][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          double rp[2];
+          reprojResidual(A.M[1 + j], P, u, v, rp);
+          J[0][j] = (rp[0] - r[0]) * A.inv_h[j];
+          J[1][j] = (rp[1] - r[1]) * A.inv_h[j];
+        }
+        const double w = lossWeight<double>(A.loss_kind, A.loss_param, rr);
+        // padded elements are all-zero points: o[2] = 0 gives inf/NaN, so mask by selection
+        if (valid) accumulateDense<double, 2, COV>(J, r, w, rr, A.cov, acc);
+      }
+    }
+  }
+  blockReduceStore<NACC>(acc, A.partials + size_t(blockIdx.x) * NACC);
+}
+
+// ---- layout conversion (once per data set) -----------------------------------------------------
+template <typename S>
+__global__ void relayoutP2PKernel(const S *__restrict__ src, const S *__restrict__ tgt,
+                                  long long count, S *__restrict__ tiles, long long padded) {
+  constexpr int TP = TileShape<S>::kPoints;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= padded) return;
+  const long long tile = i / TP;
+  const int within = int(i % TP);
+  S *dst = tiles + tile * TileShape<S>::kP2PScalars + within;
+  const bool valid = i < count;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    dst[k * TP] = valid ? src[3 * i + k] : S(0);
+    dst[(3 + k) * TP] = valid ? tgt[3 * i + k] : S(0);
+  }
+}
+
+__global__ void relayoutReprojKernel(const double *__restrict__ pts, const int *__restrict__ pix,
+                                     long long count, unsigned char *__restrict__ tiles,
+                                     long long padded) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= padded) return;
+  const long long tile = i / kReprojTilePoints;
+  const int within = int(i % kReprojTilePoints);
+  unsigned char *tb = tiles + tile * kReprojTileBytes;
+  double *planes = reinterpret_cast<double *>(tb);
+  int *pixels = reinterpret_cast<int *>(tb + size_t(4) * kReprojTilePoints * 8);
+  const bool valid = i < count;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) planes[k * kReprojTilePoints + within] = valid ? pts[4 * i + k] : 0.0;
+  pixels[2 * within + 0] = valid ? pix[2 * i + 0] : 0;
+  pixels[2 * within + 1] = valid ? pix[2 * i + 1] : 0;
+}
+
+// ---- finalisation: workgroup partials -> H | b | sum_sq -----------------------------------------
+constexpr int kFinalThreads = 1024;
+constexpr int kFinalGroups = kFinalThreads / 64;
+
+// Column sums of partials[grid][nacc] (nacc <= 64) in a fixed order; totals land in `total`.
+__device__ __forceinline__ void columnTotals(const double *partials, int grid, int nacc,
+                                             double (&lds)[kFinalGroups][64], double (&total)[64]) {
+  const int c = threadIdx.x & 63;
+  const int g = threadIdx.x >> 6;
+  double s = 0.0;
+  if (c < nacc)
+    for (int row = g; row < grid; row += kFinalGroups) s += partials[size_t(row) * nacc + c];
+  lds[g][c] = s;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < kFinalGroups; ++k) t += lds[k][threadIdx.x];
+    total[threadIdx.x] = t;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kFinalThreads) void finalizeDenseKernel(const double *partials,
+                                                                      int grid, int nacc,
+                                                                      double *result) {
+  __shared__ double lds[kFinalGroups][64];
+  __shared__ double total[64];
+  columnTotals(partials, grid, nacc, lds, total);
+  const int k = threadIdx.x;
+  if (k >= kResultDoubles) return;
+  const bool full = (nacc == kAccFull);
+  const int nh = full ? 36 : 21;
+  if (k < 36) {
+    const int i = k % 6, j = k / 6;  // column-major H(i, j)
+    if (full) {
+      result[k] = total[j * 6 + i];
+    } else {
+      const int lo = i < j ? i : j, hi = i < j ? j : i;
+      result[k] = total[hi * (hi + 1) / 2 + lo];
+    }
+  } else {
+    result[k] = total[nh + (k - 36)];  // b (6) then sum_sq
+  }
+}
+
+__global__ __launch_bounds__(kFinalThreads) void finalizeMomentsKernel(const double *partials,
+                                                                        int grid,
+                                                                        const AffineBasis B,
+                                                                        double *result) {
+  __shared__ double lds[kFinalGroups][64];
+  __shared__ double total[64];
+  columnTotals(partials, grid, kAccMoments, lds, total);
+  const int k = threadIdx.x;
+  if (k >= kResultDoubles) return;
+  // W(a, b) = sum w p_a p_b with p_0 = 1;  V(a, c) = sum w p_a r_c
+  auto W = [&](int a, int b) -> double {
+    if (a > b) {
+      const int t = a;
+      a = b;
+      b = t;
+    }
+    if (a == 0) return b == 0 ? total[0] : total[b];
+    // (1,1)=4 (1,2)=5 (1,3)=6 (2,2)=7 (2,3)=8 (3,3)=9
+    return a == 1 ? total[3 + b] : (a == 2 ? total[5 + b] : total[9]);
+  };
+  auto V = [&](int a, int c) -> double { return a == 0 ? total[10 + c] : total[13 + 3 * (a - 1) + c]; };
+  if (k < 36) {
+    const int i = k % 6, j = k / 6;
+    double h = 0.0;
+    for (int a = 0; a < 4; ++a)
+      for (int b = 0; b < 4; ++b) {
+        double form = 0.0;  // (J_a^T S J_b)(i, j)
+        for (int r = 0; r < 3; ++r)
+          for (int c = 0; c < 3; ++c) form += B.J[a][r * 6 + i] * B.cov[r * 3 + c] * B.J[b][c * 6 + j];
+        h += W(a, b) * form;
+      }
+    result[k] = h;
+  } else if (k < 42) {
+    const int i = k - 36;
+    double g = 0.0;
+    for (int a = 0; a < 4; ++a)
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) g += B.J[a][r * 6 + i] * B.cov[r * 3 + c] * V(a, c);
+    result[k] = g;
+  } else {
+    result[k] = total[22];
+  }
+}
+
+__global__ __launch_bounds__(kFinalThreads) void finalizeCostKernel(const double *partials,
+                                                                     int grid, double *result) {
+  __shared__ double lds[kFinalGroups];
+  double s = 0.0;
+  for (int row = threadIdx.x; row < grid; row += kFinalThreads) s += partials[row];
+  s = waveSum(s);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < kFinalGroups; ++k) t += lds[k];
+    result[0] = t;
+  }
+}
+
+}  // namespace
+
+// ---- host-side launch wrappers -----------------------------------------------------------------
+template <typename S>
+hipError_t launchRelayoutP2P(const S *src_xyz, const S *tgt_xyz, long long count, S *tiles,
+                             int num_tiles, hipStream_t stream) {
+  const long long padded = (long long)num_tiles * TileShape<S>::kPoints;
+  if (padded == 0) return hipSuccess;
+  const unsigned blocks = unsigned((padded + 255) / 256);
+  hipLaunchKernelGGL((relayoutP2PKernel<S>), dim3(blocks), dim3(256), 0, stream, src_xyz, tgt_xyz,
+                     count, tiles, padded);
+  return hipGetLastError();
+}
+template hipError_t launchRelayoutP2P<float>(const float *, const float *, long long, float *, int,
+                                             hipStream_t);
+template hipError_t launchRelayoutP2P<double>(const double *, const double *, long long, double *,
+                                              int, hipStream_t);
+
+hipError_t launchRelayoutReproj(const double *points_xyzw, const int32_t *pixels_uv,
+                                long long count, unsigned char *tiles, int num_tiles,
+                                hipStream_t stream) {
+  const long long padded = (long long)num_tiles * kReprojTilePoints;
+  if (padded == 0) return hipSuccess;
+  const unsigned blocks = unsigned((padded + 255) / 256);
+  hipLaunchKernelGGL(relayoutReprojKernel, dim3(blocks), dim3(256), 0, stream, points_xyzw,
+                     pixels_uv, count, tiles, padded);
+  return hipGetLastError();
+}
+
+namespace {
+template <typename S, int JAC>
+hipError_t launchLiteralCov(const P2PSweepArgs<S> &args, int cov_mode, int grid,
+                            hipStream_t stream) {
+  switch (cov_mode) {
+    case kCovIdentity:
+      hipLaunchKernelGGL((p2pLinearizeLiteralKernel<S, JAC, kCovIdentity>), dim3(grid),
+                         dim3(kBlockThreads), 0, stream, args);
+      break;
+    case kCovSymmetric:
+      hipLaunchKernelGGL((p2pLinearizeLiteralKernel<S, JAC, kCovSymmetric>), dim3(grid),
+                         dim3(kBlockThreads), 0, stream, args);
+      break;
+    default:
+      hipLaunchKernelGGL((p2pLinearizeLiteralKernel<S, JAC, kCovGeneral>), dim3(grid),
+                         dim3(kBlockThreads), 0, stream, args);
+      break;
+  }
+  return hipGetLastError();
+}
+}  // namespace
+
+template <typename S>
+hipError_t launchP2PLinearizeLiteral(const P2PSweepArgs<S> &args, int jac_mode, int cov_mode,
+                                     int grid, hipStream_t stream) {
+  switch (jac_mode) {
+    case kJacAnalytic:
+      return launchLiteralCov<S, kJacAnalytic>(args, cov_mode, grid, stream);
+    case kJacAnalyticTst:
+      return launchLiteralCov<S, kJacAnalyticTst>(args, cov_mode, grid, stream);
+    case kJacNumeric:
+      return launchLiteralCov<S, kJacNumeric>(args, cov_mode, grid, stream);
+    default:
+      return hipErrorInvalidValue;
+  }
+}
+template hipError_t launchP2PLinearizeLiteral<float>(const P2PSweepArgs<float> &, int, int, int,
+                                                     hipStream_t);
+template hipError_t launchP2PLinearizeLiteral<double>(const P2PSweepArgs<double> &, int, int, int,
+                                                      hipStream_t);
+
+template <typename S>
+hipError_t launchP2PMoments(const P2PSweepArgs<S> &args, int grid, hipStream_t stream) {
+  hipLaunchKernelGGL((p2pMomentsKernel<S>), dim3(grid), dim3(kBlockThreads), 0, stream, args);
+  return hipGetLastError();
+}
+template hipError_t launchP2PMoments<float>(const P2PSweepArgs<float> &, int, hipStream_t);
+template hipError_t launchP2PMoments<double>(const P2PSweepArgs<double> &, int, hipStream_t);
+
+template <typename S>
+hipError_t launchP2PCost(const P2PSweepArgs<S> &args, int grid, hipStream_t stream) {
+  hipLaunchKernelGGL((p2pCostKernel<S>), dim3(grid), dim3(kBlockThreads), 0, stream, args);
+  return hipGetLastError();
+}
+template hipError_t launchP2PCost<float>(const P2PSweepArgs<float> &, int, hipStream_t);
+template hipError_t launchP2PCost<double>(const P2PSweepArgs<double> &, int, hipStream_t);
+
+hipError_t launchReprojLinearize(const ReprojSweepArgs &args, int cov_mode, int grid,
+                                 hipStream_t stream) {
+  switch (cov_mode) {
+    case kCovIdentity:
+      hipLaunchKernelGGL((reprojKernel<kCovIdentity, false>), dim3(grid), dim3(kBlockThreads), 0,
+                         stream, args);
+      break;
+    case kCovSymmetric:
+      hipLaunchKernelGGL((reprojKernel<kCovSymmetric, false>), dim3(grid), dim3(kBlockThreads), 0,
+                         stream, args);
+      break;
+    default:
+      hipLaunchKernelGGL((reprojKernel<kCovGeneral, false>), dim3(grid), dim3(kBlockThreads), 0,
+                         stream, args);
+      break;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launchReprojCost(const ReprojSweepArgs &args, int grid, hipStream_t stream) {
+  hipLaunchKernelGGL((reprojKernel<kCovIdentity, true>), dim3(grid), dim3(kBlockThreads), 0,
+                     stream, args);
+  return hipGetLastError();
+}
+
+hipError_t launchFinalizeDense(const double *partials, int grid, int nacc, int n, double *result,
+                               hipStream_t stream) {
+  if (n != kNumParams || (nacc != kAccSym && nacc != kAccFull)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(finalizeDenseKernel, dim3(1), dim3(kFinalThreads), 0, stream, partials, grid,
+                     nacc, result);
+  return hipGetLastError();
+}
+
+hipError_t launchFinalizeMoments(const double *partials, int grid, const AffineBasis &basis,
+                                 double *result, hipStream_t stream) {
+  hipLaunchKernelGGL(finalizeMomentsKernel, dim3(1), dim3(kFinalThreads), 0, stream, partials,
+                     grid, basis, result);
+  return hipGetLastError();
+}
+
+hipError_t launchFinalizeCost(const double *partials, int grid, double *result,
+                              hipStream_t stream) {
+  hipLaunchKernelGGL(finalizeCostKernel, dim3(1), dim3(kFinalThreads), 0, stream, partials, grid,
+                     result);
+  return hipGetLastError();
+}
+
+}  // namespace mopt

@@ -1,0 +1,67 @@
+"""Sharding of one cost over ranks (one process per GPU).
+
+Every correspondence adds an independent term to H, b and the cost
+(/root/reference/include/moptimizer/linearization.h:113-115,150-152), so a rank sweeps its own
+contiguous index range and the n*n + n + 1 = 43 partial sums are combined with ONE all-reduce
+per sweep — RCCL over xGMI when the tensor lives on a GPU (torch backend "nccl"), gloo in the
+CPU tests.  This is the only collective on the path; the per-cost accumulation of the LM loop
+(/root/reference/src/levenberg_marquadt_dyn.cpp:57-59) stays on the host as in the reference.
+"""
+import torch
+import torch.distributed as dist
+
+RESULT_DOUBLES = 43
+
+
+def shard_range(count, rank, world_size):
+    """Contiguous index range [lo, hi) of `rank`: [rank*N/G, (rank+1)*N/G)."""
+    return (count * rank) // world_size, (count * (rank + 1)) // world_size
+
+
+class ShardedSweep:
+    """Combines per-rank sweep partials.
+
+    local_linearize(x, jac_mode, out): enqueue this rank's linearize into `out`
+        (float64[43] tensor = H column-major | b | sum_sq) on the current stream.
+    local_cost(x, out): same for the cost-only sweep (out[42] receives the sum).
+    """
+
+    def __init__(self, local_linearize, local_cost=None, device="cpu", group=None):
+        self.local_linearize = local_linearize
+        self.local_cost = local_cost
+        self.group = group
+        self.device = torch.device(device)
+        self.result = torch.zeros(RESULT_DOUBLES, dtype=torch.float64, device=self.device)
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def linearize_device(self, x, jac_mode):
+        """Asynchronous: returns the device tensor holding the all-reduced sums."""
+        self.local_linearize(x, jac_mode, self.result)
+        if self.world > 1:
+            dist.all_reduce(self.result, op=dist.ReduceOp.SUM, group=self.group)
+        return self.result
+
+    def linearize(self, x, jac_mode):
+        r = self.linearize_device(x, jac_mode).cpu().numpy()
+        return r[:36].reshape(6, 6, order="F").copy(), r[36:42].copy(), float(r[42])
+
+    def compute_cost(self, x):
+        self.local_cost(x, self.result)
+        if self.world > 1:
+            dist.all_reduce(self.result[42:43], op=dist.ReduceOp.SUM, group=self.group)
+        return float(self.result[42].item())
+
+
+def gpu_point2point_sweep(cost, jac_mode_default=None):
+    """ShardedSweep over a Point2PointCost (this rank's shard) using torch's current stream."""
+
+    def lin(x, jac_mode, out):
+        cost.linearize_async(x, jac_mode, out.data_ptr(),
+                             torch.cuda.current_stream().cuda_stream)
+
+    def cst(x, out):
+        cost.compute_cost_async(x, out.data_ptr() + 42 * 8,
+                                torch.cuda.current_stream().cuda_stream)
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    return ShardedSweep(lin, cst, device=dev)

@@ -1,0 +1,71 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see cost_computation.hpp).
+//
+// Matrix-form restatement of the two so3 functions on the path, written independently of the
+// product's closed-form include/moptimizer_amd/so3.hpp so that each checks the other:
+//   so3::convert6DOFParameterToMatrix   /root/reference/src/so3.cpp:7-19
+//   so3::Exp(Ref, Ref)                  /root/reference/src/so3.cpp:43-57
+//   SKEW_SYMMETRIC_FROM                 /root/reference/include/moptimizer/so3.h:4
+#pragma once
+
+#include <cmath>
+#include <limits>
+
+namespace oracle {
+namespace so3 {
+
+// 3x3, indexable as M[r][c]
+template <typename Scalar>
+struct Mat3 {
+  Scalar v[3][3];
+};
+
+template <typename Scalar>
+inline Mat3<Scalar> skew(const Scalar a[3]) {
+  // 0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0   (row by row)
+  Mat3<Scalar> K;
+  K.v[0][0] = 0.0;   K.v[0][1] = -a[2]; K.v[0][2] = a[1];
+  K.v[1][0] = a[2];  K.v[1][1] = 0.0;   K.v[1][2] = -a[0];
+  K.v[2][0] = -a[1]; K.v[2][1] = a[0];  K.v[2][2] = 0.0;
+  return K;
+}
+
+template <typename Scalar>
+inline Mat3<Scalar> Exp(const Scalar delta[3]) {
+  Mat3<Scalar> R;
+  const Scalar delta_norm =
+      std::sqrt(delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2]);
+  if (delta_norm > Scalar(10.0) * std::numeric_limits<Scalar>::epsilon()) {  // :47
+    const Scalar axis[3] = {delta[0] / delta_norm, delta[1] / delta_norm, delta[2] / delta_norm};
+    const Mat3<Scalar> K = skew<Scalar>(axis);
+    const Scalar s = std::sin(delta_norm);
+    const Scalar c1 = Scalar(1.0) - std::cos(delta_norm);
+    for (int i = 0; i < 3; ++i) {
+      for (int j = 0; j < 3; ++j) {
+        Scalar kk = 0;  // ((1 - cos) K) K, coefficient by coefficient (:51-52)
+        for (int k = 0; k < 3; ++k) kk += (c1 * K.v[i][k]) * K.v[k][j];
+        R.v[i][j] = ((i == j ? Scalar(1) : Scalar(0)) + s * K.v[i][j]) + kk;
+      }
+    }
+  } else {
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) R.v[i][j] = (i == j) ? Scalar(1) : Scalar(0);  // :54
+  }
+  return R;
+}
+
+// Column-major 4x4, as Eigen::Matrix<Scalar,4,4>::data().
+template <typename Scalar>
+inline void convert6DOFParameterToMatrix(const Scalar *x, Scalar T[16]) {
+  for (int i = 0; i < 16; ++i) T[i] = 0;
+  T[0] = T[5] = T[10] = T[15] = 1;  // setIdentity (:10)
+  T[12] = x[0];                     // (0,3)
+  T[13] = x[1];                     // (1,3)
+  T[14] = x[2];                     // (2,3)
+  const Scalar delta[3] = {x[3], x[4], x[5]};
+  const Mat3<Scalar> R = Exp<Scalar>(delta);
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) T[c * 4 + r] = R.v[r][c];  // topLeftCorner (:18)
+}
+
+}  // namespace so3
+}  // namespace oracle

@@ -1,0 +1,255 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see cost_computation.hpp).
+//
+// CPU restatements of the user models the reference's tests define (the reference keeps its
+// models in tst/, not in the library):
+//   Point2Point        /root/reference/tst/point2point.cpp:24-84
+//   CameraModel        /root/reference/tst/camera_calibration.cpp:12-57
+//   CurveFittingModel  /root/reference/tst/curve_fitting.cpp:81-98 (= MOModel, multiple_objectives.cpp:81-98)
+//   PowellModel        /root/reference/tst/powell.cpp:21-60 (= Powell, differentiation.cpp:79-132)
+//   RationalModel      /root/reference/tst/test_models.h:7-20 (`Model`), with the Jacobian of
+//                      SimpleModel, tst/differentiation.cpp:15-41
+//   Point2PointDist    /root/reference/tst/parallel.cpp:12-34
+// Point data are packed xyz triples (what std::vector<Eigen::Vector3d>::data() is).
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <stdexcept>
+
+#include "moptimizer_amd/host_api.hpp"
+#include "so3_ref.hpp"
+
+namespace oracle {
+
+// How Point2Point::f_df fills the 18-entry Jacobian buffer.
+enum class P2PJacobianLayout {
+  // API-conformant row-major [I3 | -skew(p)] (model.h:35-42, differentiation.cpp:31,102).
+  kRowMajor,
+  // As written in tst/point2point.cpp:71-75: the buffer is mapped as a COLUMN-major 3x6 and
+  // filled with [I3 | -skew(p)], while the consumer reads it row-major (linearization.h:17-18).
+  kAsWrittenInTst,
+};
+
+template <typename Scalar>
+class Point2Point : public moptimizer::BaseModelJacobian<Scalar, Point2Point<Scalar>> {
+ public:
+  Point2Point(const Scalar *src_xyz, const Scalar *tgt_xyz,
+              P2PJacobianLayout layout = P2PJacobianLayout::kAsWrittenInTst)
+      : src_(src_xyz), tgt_(tgt_xyz), layout_(layout) {
+    for (int i = 0; i < 16; ++i) transform_[i] = (i % 5 == 0) ? Scalar(1) : Scalar(0);
+  }
+
+  void setup(const Scalar *x) override { so3::convert6DOFParameterToMatrix<Scalar>(x, transform_); }
+
+  bool f(const Scalar *, Scalar *f_x, unsigned int index) const override {
+    residual(index, f_x);
+    return true;
+  }
+
+  bool f_df(const Scalar *, Scalar *f_x, Scalar *jacobian, unsigned int index) const override {
+    residual(index, f_x);
+    const Scalar *p = src_ + 3 * std::size_t(index);
+    // -skew(src): rows (0, z, -y), (-z, 0, x), (y, -x, 0)
+    const Scalar neg_skew[3][3] = {{0.0, p[2], -p[1]}, {-p[2], 0.0, p[0]}, {p[1], -p[0], 0.0}};
+    if (layout_ == P2PJacobianLayout::kAsWrittenInTst) {
+      // jacobian_map(r, c) lives at jacobian[c * 3 + r]  (column-major 3x6, :18,:71)
+      for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r) jacobian[c * 3 + r] = (r == c) ? Scalar(1) : Scalar(0);
+      for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r) jacobian[(3 + c) * 3 + r] = neg_skew[r][c];
+    } else {
+      for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) jacobian[r * 6 + c] = (r == c) ? Scalar(1) : Scalar(0);
+        for (int c = 0; c < 3; ++c) jacobian[r * 6 + 3 + c] = neg_skew[r][c];
+      }
+    }
+    return true;
+  }
+
+ private:
+  // error = (T * [p;1])_{0..2} - q   (:36-49)
+  void residual(unsigned int index, Scalar *f_x) const {
+    const Scalar *p = src_ + 3 * std::size_t(index);
+    const Scalar *q = tgt_ + 3 * std::size_t(index);
+    const Scalar src4[4] = {p[0], p[1], p[2], Scalar(1.0)};
+    for (int r = 0; r < 3; ++r) {
+      Scalar warped = 0;
+      for (int c = 0; c < 4; ++c) warped += transform_[c * 4 + r] * src4[c];
+      f_x[r] = warped - q[r];
+    }
+  }
+
+  Scalar transform_[16];  // column-major 4x4
+  const Scalar *src_;
+  const Scalar *tgt_;
+  P2PJacobianLayout layout_;
+};
+
+// 2-D reprojection residual, numerical differentiation only.
+class CameraModel : public moptimizer::BaseModel<double, CameraModel> {
+ public:
+  // points: packed (x, y, z, w) doubles; pixels: packed (u, v) int32.
+  CameraModel(const double *points_xyzw, const std::int32_t *pixels_uv, std::size_t count)
+      : points_(points_xyzw), pixels_(pixels_uv) {
+    if (count == 0) throw std::runtime_error("Empty point list");
+    fillConstants(camera_, laser_to_camera_);
+    for (int i = 0; i < 16; ++i) transform_[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    rebuildProjection();
+  }
+
+  // camera matrix (row-major 3x4) and frame conversion (row-major 4x4), :22-30
+  static void fillConstants(double K[12], double C[16]) {
+    const double k[12] = {586.122314453125, 0, 638.8477694496105, 0,
+                          0, 722.3973388671875, 323.031267074588, 0,
+                          0, 0, 1, 0};
+    for (int i = 0; i < 12; ++i) K[i] = k[i];
+    // AngleAxis(pi/2, X) * AngleAxis(pi/2, Z)
+    const double a = M_PI_2;
+    const double rx[3][3] = {{1, 0, 0}, {0, std::cos(a), -std::sin(a)}, {0, std::sin(a), std::cos(a)}};
+    const double rz[3][3] = {{std::cos(a), -std::sin(a), 0}, {std::sin(a), std::cos(a), 0}, {0, 0, 1}};
+    for (int i = 0; i < 16; ++i) C[i] = 0;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) {
+        double v = 0;
+        for (int k2 = 0; k2 < 3; ++k2) v += rx[r][k2] * rz[k2][c];
+        C[r * 4 + c] = v;
+      }
+    C[15] = 1;
+  }
+
+  void setup(const double *x) override {
+    so3::convert6DOFParameterToMatrix<double>(x, transform_);
+    rebuildProjection();
+  }
+
+  bool f(const double *, double *residual, unsigned int index) const override {
+    const double *P = points_ + 4 * std::size_t(index);
+    double o[3];
+    for (int r = 0; r < 3; ++r) {
+      double v = 0;
+      for (int c = 0; c < 4; ++c) v += projection_[r * 4 + c] * P[c];
+      o[r] = v;
+    }
+    residual[0] = pixels_[2 * std::size_t(index) + 0] - (o[0] / o[2]);  // :38
+    residual[1] = pixels_[2 * std::size_t(index) + 1] - (o[1] / o[2]);  // :39
+    return true;
+  }
+
+  // ((K * T) * C), row-major 3x4 — the left-to-right matrix products of :37, hoisted out of the
+  // per-point call (the reference re-forms them for every point; same values).
+  const double *projection() const { return projection_; }
+
+ private:
+  void rebuildProjection() {
+    double kt[12];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 4; ++c) {
+        double v = 0;
+        for (int k = 0; k < 4; ++k) v += camera_[r * 4 + k] * transform_[c * 4 + k];
+        kt[r * 4 + c] = v;
+      }
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 4; ++c) {
+        double v = 0;
+        for (int k = 0; k < 4; ++k) v += kt[r * 4 + k] * laser_to_camera_[k * 4 + c];
+        projection_[r * 4 + c] = v;
+      }
+  }
+
+  const double *points_;
+  const std::int32_t *pixels_;
+  double camera_[12];
+  double laser_to_camera_[16];
+  double transform_[16];  // column-major
+  double projection_[12];
+};
+
+// y - exp(m x + c) over (x, y) pairs.
+class CurveFittingModel : public moptimizer::BaseModel<double, CurveFittingModel> {
+ public:
+  explicit CurveFittingModel(const double *dataset) : dataset_(dataset) {}
+  bool f(const double *x, double *f_x, unsigned int index) const override {
+    const double x_ = dataset_[2 * index];
+    const double y_ = dataset_[2 * index + 1];
+    f_x[0] = y_ - std::exp(x[0] * x_ + x[1]);
+    return true;
+  }
+
+ private:
+  const double *dataset_;
+};
+
+// Powell's singular function, 4 outputs, analytic row-major Jacobian.
+class PowellModel : public moptimizer::BaseModelJacobian<double, PowellModel> {
+ public:
+  bool f(const double *x, double *f_x, unsigned int) const override {
+    f_x[0] = x[0] + 10 * x[1];
+    f_x[1] = std::sqrt(5.0) * (x[2] - x[3]);
+    f_x[2] = (x[1] - 2 * x[2]) * (x[1] - 2 * x[2]);
+    f_x[3] = std::sqrt(10.0) * (x[0] - x[3]) * (x[0] - x[3]);
+    return true;
+  }
+  bool f_df(const double *x, double *f_x, double *jacobian, unsigned int index) const override {
+    f(x, f_x, index);
+    const double s5 = std::sqrt(5.0), s10 = std::sqrt(10.0);
+    // column 0
+    jacobian[0] = 1;
+    jacobian[4] = 0;
+    jacobian[8] = 0;
+    jacobian[12] = s10 * 2 * (x[0] - x[3]);
+    // column 1
+    jacobian[1] = 10;
+    jacobian[5] = 0;
+    jacobian[9] = 2 * (x[1] + 2 * x[2]);
+    jacobian[13] = 0;
+    // column 2
+    jacobian[2] = 0;
+    jacobian[6] = s5;
+    jacobian[10] = 2 * (x[1] + 2 * x[2]) * (-2);
+    jacobian[14] = 0;
+    // column 3
+    jacobian[3] = 0;
+    jacobian[7] = -s5;
+    jacobian[11] = 0;
+    jacobian[15] = s10 * 2 * (x[0] - x[3]) * (-1);
+    return true;
+  }
+};
+
+// y - a x / (b + x)
+template <typename Scalar>
+class RationalModel : public moptimizer::BaseModelJacobian<Scalar, RationalModel<Scalar>> {
+ public:
+  RationalModel(const Scalar *xs, const Scalar *ys) : data_x_(xs), data_y_(ys) {}
+  bool f(const Scalar *x, Scalar *residual, unsigned int index) const override {
+    residual[0] = data_y_[index] - (x[0] * data_x_[index]) / (x[1] + data_x_[index]);
+    return true;
+  }
+  bool f_df(const Scalar *x, Scalar *f_x, Scalar *jacobian, unsigned int index) const override {
+    const Scalar denominator = x[1] + data_x_[index];
+    f_x[0] = data_y_[index] - (x[0] * data_x_[index]) / (x[1] + data_x_[index]);
+    jacobian[0] = -data_x_[index] / denominator;
+    jacobian[1] = (x[0] * data_x_[index]) / (denominator * denominator);
+    return true;
+  }
+
+ private:
+  const Scalar *data_x_;
+  const Scalar *data_y_;
+};
+
+// src - tgt, no parameters.
+class Point2PointDist : public moptimizer::BaseModel<double, Point2PointDist> {
+ public:
+  Point2PointDist(const double *src_xyz, const double *tgt_xyz) : src_(src_xyz), tgt_(tgt_xyz) {}
+  bool f(const double *, double *f_x, unsigned int index) const override {
+    for (int k = 0; k < 3; ++k) f_x[k] = src_[3 * std::size_t(index) + k] - tgt_[3 * std::size_t(index) + k];
+    return true;
+  }
+
+ private:
+  const double *src_;
+  const double *tgt_;
+};
+
+}  // namespace oracle

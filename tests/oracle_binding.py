@@ -1,0 +1,158 @@
+"""ctypes access to oracle/_build/liboracle.so — the CPU restatement of the reference path.
+Test infrastructure: used by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+only, never by the product."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
+REPLAY = os.path.join(ORACLE_DIR, "_build", "replay_reference_tests")
+
+ANALYTIC_DYN, NUMERIC_DYN, ANALYTIC_STATIC, NUMERIC_STATIC = 0, 1, 2, 3
+LAYOUT_ROW_MAJOR, LAYOUT_TST = 0, 1
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-C", ORACLE_DIR, "all"], stdout=subprocess.DEVNULL)
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not (os.path.exists(LIB) and os.path.exists(REPLAY)):
+            build()
+        _lib = Oracle(ctypes.CDLL(LIB))
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Oracle:
+    def __init__(self, lib):
+        self.lib = lib
+        lib.oracle_p2p_linearize_threads.argtypes = [
+            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+            ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_double,
+            ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        lib.oracle_p2p_linearize.argtypes = [
+            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+            ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_double,
+            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        lib.oracle_p2p_cost.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                        ctypes.c_void_p]
+        lib.oracle_p2p_minimize.argtypes = [
+            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+            ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+            ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_int),
+            ctypes.POINTER(ctypes.c_int)]
+        lib.oracle_camera_linearize.argtypes = [
+            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+            ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        lib.oracle_camera_cost.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                           ctypes.c_void_p, ctypes.c_void_p]
+        lib.oracle_camera_minimize.argtypes = [
+            ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
+            ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+            ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+        lib.oracle_se3_from_x.argtypes = [ctypes.c_void_p] * 4
+
+    @staticmethod
+    def _prep(src, tgt, x, cov, dtype):
+        src = np.ascontiguousarray(src, dtype=dtype).reshape(-1, 3)
+        tgt = np.ascontiguousarray(tgt, dtype=dtype).reshape(-1, 3)
+        x = np.ascontiguousarray(x, dtype=dtype)
+        cov = None if cov is None else np.asfortranarray(np.asarray(cov, dtype=dtype))
+        return src, tgt, x, cov
+
+    def p2p_linearize(self, src, tgt, x, cost_class=ANALYTIC_DYN, layout=LAYOUT_ROW_MAJOR,
+                      cov=None, loss_kind=0, loss_param=0.0, dtype=np.float64, threads=0):
+        src, tgt, x, cov = self._prep(src, tgt, x, cov, dtype)
+        sb = np.dtype(dtype).itemsize
+        H = np.zeros((6, 6), dtype=dtype, order="F")
+        b = np.zeros(6, dtype=dtype)
+        s = np.zeros(1, dtype=dtype)
+        if threads and threads > 0:
+            rc = self.lib.oracle_p2p_linearize_threads(
+                sb, cost_class, layout, _p(src), _p(tgt), src.shape[0], _p(x), _p(cov), loss_kind,
+                loss_param, threads, _p(H), _p(b), _p(s))
+        else:
+            rc = self.lib.oracle_p2p_linearize(sb, cost_class, layout, _p(src), _p(tgt),
+                                               src.shape[0], _p(x), _p(cov), loss_kind,
+                                               loss_param, _p(H), _p(b), _p(s))
+        assert rc == 0, rc
+        return H, b, s[0]
+
+    def p2p_cost(self, src, tgt, x, dtype=np.float64, threads=0):
+        src, tgt, x, _ = self._prep(src, tgt, x, None, dtype)
+        s = np.zeros(1, dtype=dtype)
+        rc = self.lib.oracle_p2p_cost(np.dtype(dtype).itemsize, _p(src), _p(tgt), src.shape[0],
+                                      _p(x), threads, _p(s))
+        assert rc == 0, rc
+        return s[0]
+
+    def p2p_minimize(self, src, tgt, x0, cost_class=NUMERIC_DYN, layout=LAYOUT_TST, max_iter=15,
+                     lm_iter=0, cov=None, loss_kind=0, loss_param=0.0, dtype=np.float64):
+        src, tgt, x, cov = self._prep(src, tgt, x0, cov, dtype)
+        x = x.copy()
+        status, iters = ctypes.c_int(), ctypes.c_int()
+        rc = self.lib.oracle_p2p_minimize(np.dtype(dtype).itemsize, cost_class, layout, _p(src),
+                                          _p(tgt), src.shape[0], _p(x), max_iter, lm_iter, _p(cov),
+                                          loss_kind, loss_param, ctypes.byref(status),
+                                          ctypes.byref(iters))
+        assert rc == 0, rc
+        return x, status.value, iters.value
+
+    def camera_linearize(self, pts, pix, x, cov=None, loss_kind=0, loss_param=0.0):
+        pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 4)
+        pix = np.ascontiguousarray(pix, dtype=np.int32).reshape(-1, 2)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        cov = None if cov is None else np.asfortranarray(np.asarray(cov, dtype=np.float64))
+        H = np.zeros((6, 6), order="F")
+        b = np.zeros(6)
+        s = np.zeros(1)
+        rc = self.lib.oracle_camera_linearize(_p(pts), _p(pix), pts.shape[0], _p(x), _p(cov),
+                                              loss_kind, loss_param, _p(H), _p(b), _p(s))
+        assert rc == 0, rc
+        return H, b, s[0]
+
+    def camera_cost(self, pts, pix, x):
+        pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 4)
+        pix = np.ascontiguousarray(pix, dtype=np.int32).reshape(-1, 2)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        s = np.zeros(1)
+        rc = self.lib.oracle_camera_cost(_p(pts), _p(pix), pts.shape[0], _p(x), _p(s))
+        assert rc == 0, rc
+        return s[0]
+
+    def camera_minimize(self, pts, pix, counts, x0, max_iter=15, loss_kind=0, loss_param=0.0):
+        pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 4)
+        pix = np.ascontiguousarray(pix, dtype=np.int32).reshape(-1, 2)
+        x = np.ascontiguousarray(x0, dtype=np.float64).copy()
+        cnt = (ctypes.c_int * len(counts))(*counts)
+        status, iters = ctypes.c_int(), ctypes.c_int()
+        rc = self.lib.oracle_camera_minimize(_p(pts), _p(pix), cnt, len(counts), _p(x), max_iter,
+                                             loss_kind, loss_param, ctypes.byref(status),
+                                             ctypes.byref(iters))
+        assert rc == 0, rc
+        return x, status.value, iters.value
+
+    def se3_from_x(self, x, with_steps=False):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        T = np.zeros(16)
+        if with_steps:
+            Tp = np.zeros(96)
+            h = np.zeros(6)
+            self.lib.oracle_se3_from_x(_p(x), _p(T), _p(Tp), _p(h))
+            return (T.reshape(4, 4, order="F"),
+                    [Tp[16 * j:16 * j + 16].reshape(4, 4, order="F") for j in range(6)], h)
+        self.lib.oracle_se3_from_x(_p(x), _p(T), None, None)
+        return T.reshape(4, 4, order="F")

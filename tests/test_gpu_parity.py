@@ -1,0 +1,230 @@
+"""Parity of the HIP path (through the C ABI) with the CPU restatement of the reference.
+
+Bar (BASELINE.json north_star): J^T J and J^T r within 1e-6 relative, norm-wise
+(max|dH| / max|H|), same for the cost; fp32 instantiations are judged against the fp64 oracle
+with the looser bound written at the test.
+"""
+import numpy as np
+import pytest
+
+from tests import datasets as ds
+from tests import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-6  # north_star tolerance on H, b, cost (fp64)
+
+
+def rel_err(got, want):
+    scale = np.abs(want).max()
+    return np.abs(np.asarray(got, dtype=np.float64) - want).max() / (scale if scale > 0 else 1.0)
+
+
+def oracle_ref(oracle, src, tgt, x, jac_mode, **kw):
+    """The reference computation a jacobian_mode stands for."""
+    if jac_mode == 2:
+        return oracle.p2p_linearize(src, tgt, x, cost_class=ob.NUMERIC_DYN, **kw)
+    layout = ob.LAYOUT_TST if jac_mode == 1 else ob.LAYOUT_ROW_MAJOR
+    return oracle.p2p_linearize(src, tgt, x, cost_class=ob.ANALYTIC_DYN, layout=layout, **kw)
+
+
+def check(got, want, tol=REL):
+    H, b, s = got
+    Hr, br, sr = want
+    assert rel_err(H, Hr) <= tol, ("H", rel_err(H, Hr))
+    assert rel_err(b, br) <= tol, ("b", rel_err(b, br))
+    assert abs(float(s) - float(sr)) <= tol * abs(float(sr)) + 1e-300, ("cost", s, sr)
+
+
+@pytest.fixture(scope="module")
+def cloud_1k():
+    return ds.synthetic_pair(1000, seed=42, noise=0.01)
+
+
+@pytest.mark.parametrize("jac_mode", [0, 1, 2])
+@pytest.mark.parametrize("xname", ["zero", "generic"])
+@pytest.mark.parametrize("variant", [1, 2])
+def test_p2p_1k_matches_oracle(hip_lib, oracle, cloud_1k, jac_mode, xname, variant):
+    src, tgt = cloud_1k
+    x = ds.X_ZERO if xname == "zero" else ds.X_GENERIC
+    cost = hip_lib.Point2PointCost(src, tgt)
+    cost.set_kernel_variant(variant)
+    check(cost.linearize(x, jac_mode), oracle_ref(oracle, src, tgt, x, jac_mode))
+    assert abs(cost.compute_cost(x) - oracle.p2p_cost(src, tgt, x)) <= REL * oracle.p2p_cost(src, tgt, x)
+
+
+@pytest.mark.parametrize("jac_mode", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_p2p_loss_and_covariance(hip_lib, oracle, cloud_1k, jac_mode, variant):
+    src, tgt = cloud_1k
+    x = ds.X_GENERIC
+    cov_sym = np.array([[2.0, 0.3, -0.1], [0.3, 0.5, 0.2], [-0.1, 0.2, 1.5]])
+    cov_gen = np.array([[2.0, 0.7, -0.1], [0.3, 0.5, 0.9], [-0.4, 0.2, 1.5]])
+    for cov in (None, np.diag([0.5, 2.0, 3.0]), cov_sym, cov_gen):
+        for loss_kind, loss_param in ((0, 0.0), (1, 100.0), (1, 0.5)):
+            cost = hip_lib.Point2PointCost(src, tgt)
+            cost.set_kernel_variant(variant)
+            cost.set_covariance(cov)
+            cost.set_loss(loss_kind, loss_param)
+            want = oracle_ref(oracle, src, tgt, x, jac_mode, cov=cov, loss_kind=loss_kind,
+                              loss_param=loss_param)
+            check(cost.linearize(x, jac_mode), want)
+
+
+def test_facade_consistency_over_cost_classes(hip_lib, oracle, facade):
+    """tst/point2point.cpp:142-184 with the HIP cost in place of each CPU class."""
+    src, tgt = facade
+    x0 = np.zeros(6)
+    cost = hip_lib.Point2PointCost(src, tgt)
+    H_an, b_an, s_an = cost.linearize(x0, 1)   # analytic, as written in the test
+    H_nu, b_nu, s_nu = cost.linearize(x0, 2)   # numeric
+    for cc, (H, s) in ((ob.ANALYTIC_STATIC, (H_an, s_an)), (ob.ANALYTIC_DYN, (H_an, s_an)),
+                       (ob.NUMERIC_STATIC, (H_nu, s_nu)), (ob.NUMERIC_DYN, (H_nu, s_nu))):
+        Hr, br, sr = oracle.p2p_linearize(src, tgt, x0, cost_class=cc, layout=ob.LAYOUT_TST)
+        assert abs(s - sr) <= REL * sr
+        assert rel_err(H, Hr) <= REL
+    assert abs(s_an - 11726562.6975) < 1e-3
+    assert abs(H_nu[0, 0] - 29310.0) < 1e-3
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 511, 512, 513, 1023, 1025, 4097])
+def test_ragged_sizes(hip_lib, oracle, n):
+    src, tgt = ds.synthetic_pair(max(n, 1), seed=n + 1, noise=0.05)
+    src, tgt = src[:n], tgt[:n]
+    cost = hip_lib.Point2PointCost(src, tgt)
+    for jac_mode in (0, 2):
+        H, b, s = cost.linearize(ds.X_GENERIC, jac_mode)
+        if n == 0:
+            assert not H.any() and not b.any() and s == 0.0
+        else:
+            check((H, b, s), oracle_ref(oracle, src, tgt, ds.X_GENERIC, jac_mode))
+    c = cost.compute_cost(ds.X_GENERIC)
+    want = oracle.p2p_cost(src, tgt, ds.X_GENERIC) if n else 0.0
+    assert abs(c - want) <= REL * abs(want)
+
+
+def test_p2p_100k_all_modes(hip_lib, oracle):
+    src, tgt = ds.synthetic_pair(100_000, seed=3, noise=0.02)
+    cost = hip_lib.Point2PointCost(src, tgt)
+    for jac_mode in (0, 1, 2):
+        for variant in (1, 2):
+            cost.set_kernel_variant(variant)
+            check(cost.linearize(ds.X_GENERIC, jac_mode),
+                  oracle_ref(oracle, src, tgt, ds.X_GENERIC, jac_mode))
+
+
+def test_p2p_float32(hip_lib, oracle):
+    """fp32 instantiation (src/linearization.cpp:4): judged against the fp64 oracle on the same
+    fp32-rounded inputs; 2e-4 covers fp32 residual/Jacobian rounding (the kernel accumulates in
+    fp64, the reference's own fp32 sums are worse)."""
+    src, tgt = ds.synthetic_pair(20_000, seed=5, noise=0.02, dtype=np.float32)
+    cost = hip_lib.Point2PointCost(src, tgt, dtype=np.float32)
+    x = ds.X_GENERIC.astype(np.float32)
+    want = oracle_ref(oracle, src.astype(np.float64), tgt.astype(np.float64),
+                      x.astype(np.float64), 0)
+    check(cost.linearize(x, 0), want, tol=2e-4)
+    c = cost.compute_cost(x)
+    assert abs(c - want[2]) <= 2e-4 * want[2]
+
+
+def test_lm_converges_to_fixture_pose(hip_lib, oracle, facade):
+    """tst/point2point.cpp:192-217 (LM over the numerical cost) driven by the HIP cost: same pose
+    as the CPU path and as the fixture's ground truth (t, log R)."""
+    src, tgt = facade
+    cost = hip_lib.Point2PointCost(src, tgt)
+    x = np.zeros(6)
+    lam, it_done = -1.0, 0
+    for it in range(50):
+        H, b, y0 = cost.linearize(x, 2)
+        if abs(y0) < 8 * np.finfo(np.float64).eps:
+            break
+        D = np.diag(np.diag(H))
+        if lam < 0:
+            lam = 1e-9 * np.abs(np.diag(H)).max()
+        nu, accepted = 2.0, False
+        for k in range(3):
+            delta = np.linalg.solve(H + lam * D, -b)
+            xi = x + delta
+            yi = cost.compute_cost(xi)
+            rho = (y0 - yi) / delta.dot(lam * delta - b)
+            if rho < 0:
+                if np.abs(delta).max() < np.sqrt(np.finfo(np.float64).eps):
+                    accepted = None
+                    break
+                lam *= nu
+                nu *= 2
+                continue
+            x = xi
+            lam *= max(1.0 / 3.0, 1 - (2 * rho - 1) ** 3)
+            accepted = True
+            break
+        it_done = it + 1
+        if accepted is None:
+            break
+    x_cpu, status, iters = oracle.p2p_minimize(src, tgt, np.zeros(6), cost_class=ob.NUMERIC_DYN,
+                                               max_iter=50)
+    assert np.abs(x - ds.FIXTURE_X).max() < 1e-6, x
+    assert np.abs(x - x_cpu).max() < 1e-6, (x, x_cpu)
+
+
+def test_reprojection_matches_oracle(hip_lib, oracle):
+    pts, pix = ds.synthetic_camera(10_000)
+    cost = hip_lib.ReprojectionCost(pts, pix)
+    for x in (np.zeros(6), np.array([0.05, -0.02, 0.03, 0.02, -0.01, 0.03])):
+        for cov in (None, np.array([[2.0, 0.25], [0.25, 0.5]]), np.array([[2.0, 0.5], [0.1, 0.7]])):
+            for loss_kind, loss_param in ((0, 0.0), (1, 100.0)):
+                cost.set_covariance(cov)
+                cost.set_loss(loss_kind, loss_param)
+                want = oracle.camera_linearize(pts, pix, x, cov=cov, loss_kind=loss_kind,
+                                               loss_param=loss_param)
+                check(cost.linearize(x, 2), want)
+        assert abs(cost.compute_cost(x) - oracle.camera_cost(pts, pix, x)) <= REL * oracle.camera_cost(pts, pix, x)
+
+
+def test_reprojection_reference_five_points(hip_lib, oracle):
+    """The five correspondences of tst/camera_calibration.cpp:77-87."""
+    pts = np.array([[2.055643, 0.065643, 0.684357, 1], [1.963083, -0.765833, 0.653833, 1],
+                    [2.927500, 0.707000, 0.125250, 1], [2.957833, 0.384667, 0.123667, 1],
+                    [2.756000, 0.712000, -0.298000, 1]])
+    pix = np.array([[621, 67], [878, 76], [491, 279], [559, 282], [481, 388]], dtype=np.int32)
+    cost = hip_lib.ReprojectionCost(pts, pix)
+    for x in (np.zeros(6), np.array([0.5, 0.5, 0.5, 0.2, 0.5, 0.5])):
+        check(cost.linearize(x, 2), oracle.camera_linearize(pts, pix, x))
+
+
+def test_group_of_one_device(hip_lib, oracle, cloud_1k):
+    src, tgt = cloud_1k
+    grp = hip_lib.Point2PointGroup(src, tgt, devices=[0])
+    check(grp.linearize(ds.X_GENERIC, 0), oracle_ref(oracle, src, tgt, ds.X_GENERIC, 0))
+    want = oracle.p2p_cost(src, tgt, ds.X_GENERIC)
+    assert abs(grp.compute_cost(ds.X_GENERIC) - want) <= REL * want
+
+
+def test_full_size_properties(hip_lib):
+    """BASELINE sizes (1M): properties that need no CPU sweep — additivity over a split of the
+    index range, analytic == moments == literal, and exact translation structure
+    H_tt = N I, b_t = sum r at x with loss off."""
+    n = 1_000_000
+    src, tgt = ds.synthetic_pair(n, seed=11, noise=0.01)
+    x = ds.X_GENERIC
+    whole = hip_lib.Point2PointCost(src, tgt)
+    H, b, s = whole.linearize(x, 0)
+    k = 377_123
+    a = hip_lib.Point2PointCost(src[:k], tgt[:k])
+    c = hip_lib.Point2PointCost(src[k:], tgt[k:])
+    Ha, ba, sa = a.linearize(x, 0)
+    Hc, bc, sc = c.linearize(x, 0)
+    assert rel_err(Ha + Hc, H) < 1e-12
+    assert rel_err(ba + bc, b) < 1e-12
+    assert abs(sa + sc - s) < 1e-12 * s
+    whole.set_kernel_variant(1)
+    Hl, bl, sl = whole.linearize(x, 0)
+    assert rel_err(Hl, H) < 1e-11 and rel_err(bl, b) < 1e-11 and abs(sl - s) < 1e-11 * s
+    assert np.allclose(np.diag(H)[:3], n, rtol=0, atol=1e-6)
+    assert abs(whole.compute_cost(x) - s) < 1e-12 * s
+    # forward differences: literal per-point evaluation vs the affine-basis moments
+    whole.set_kernel_variant(1)
+    Hn, bn, sn = whole.linearize(x, 2)
+    whole.set_kernel_variant(2)
+    Hm, bm, sm = whole.linearize(x, 2)
+    assert rel_err(Hm, Hn) < 1e-6 and rel_err(bm, bn) < 1e-6 and abs(sm - sn) < 1e-12 * sn
