@@ -236,18 +236,18 @@ int p2pLinearizeAsync(mopt_cost *c, int jac_mode, const S *x, double *d_result, 
   switch (c->variant) {
     case MOPT_KERNEL_LITERAL: moments = false; break;
     case MOPT_KERNEL_MOMENTS: moments = true; break;
-    default: moments = (jac_mode != MOPT_JAC_NUMERIC); break;
+    default: moments = true; break;
   }
   if (moments) {
     mopt::AffineBasis basis;
     fillBasis<S>(c, jac_mode, args, basis);
-    const int grid = gridFor(c, envInt("MOPT_BLOCKS_PER_CU", 4));
+    const int grid = gridFor(c, envInt("MOPT_BLOCKS_PER_CU", 2));
     SweepTimer timer(c, s);
     MOPT_HIP_TRY(mopt::launchP2PMoments<S>(args, grid, s));
     timer.stop();
     MOPT_HIP_TRY(mopt::launchFinalizeMoments(c->d_partials, grid, basis, d_result, s));
   } else {
-    const int grid = gridFor(c, envInt("MOPT_BLOCKS_PER_CU", 4));
+    const int grid = gridFor(c, envInt("MOPT_BLOCKS_PER_CU", 2));
     const int nacc = c->cov_mode == mopt::kCovGeneral ? mopt::kAccFull : mopt::kAccSym;
     SweepTimer timer(c, s);
     MOPT_HIP_TRY(mopt::launchP2PLinearizeLiteral<S>(args, jac_mode, c->cov_mode, grid, s));
@@ -261,7 +261,7 @@ template <typename S>
 int p2pCostAsync(mopt_cost *c, const S *x, double *d_sum, hipStream_t s) {
   mopt::P2PSweepArgs<S> args;
   fillP2PArgs<S>(c, x, false, args);
-  const int grid = gridFor(c, envInt("MOPT_BLOCKS_PER_CU", 8));
+  const int grid = gridFor(c, envInt("MOPT_BLOCKS_PER_CU", 2));
   SweepTimer timer(c, s);
   MOPT_HIP_TRY(mopt::launchP2PCost<S>(args, grid, s));
   timer.stop();
@@ -325,7 +325,7 @@ int reprojLinearizeAsync(mopt_cost *c, int jac_mode, const double *x, double *d_
                 "the reprojection model has no analytic Jacobian (BaseModel, numeric only)");
   mopt::ReprojSweepArgs args;
   fillReprojArgs(c, x, true, args);
-  const int grid = gridFor(c, envInt("MOPT_BLOCKS_PER_CU", 4));
+  const int grid = gridFor(c, envInt("MOPT_BLOCKS_PER_CU", 2));
   const int nacc = c->cov_mode == mopt::kCovGeneral ? mopt::kAccFull : mopt::kAccSym;
   SweepTimer timer(c, s);
   MOPT_HIP_TRY(mopt::launchReprojLinearize(args, c->cov_mode, grid, s));
@@ -337,7 +337,7 @@ int reprojLinearizeAsync(mopt_cost *c, int jac_mode, const double *x, double *d_
 int reprojCostAsync(mopt_cost *c, const double *x, double *d_sum, hipStream_t s) {
   mopt::ReprojSweepArgs args;
   fillReprojArgs(c, x, false, args);
-  const int grid = gridFor(c, envInt("MOPT_BLOCKS_PER_CU", 8));
+  const int grid = gridFor(c, envInt("MOPT_BLOCKS_PER_CU", 2));
   SweepTimer timer(c, s);
   MOPT_HIP_TRY(mopt::launchReprojCost(args, grid, s));
   timer.stop();

@@ -61,24 +61,50 @@ __device__ __forceinline__ double waveSum(double v) {
   return v;
 }
 
-// Per-thread accumulators -> one row of `NACC` doubles per workgroup.
+// Per-thread accumulators -> one row of `NACC` doubles per workgroup, through an LDS transpose.
+//
+// Cross-lane shuffles (ds_bpermute) go through the CU's single LDS crossbar: 6 steps x 2 dwords
+// x NACC values x 4 waves of them cost microseconds per workgroup (measured: the 23-value
+// epilogue took as long as ~4 tiles of streaming).  Instead every lane stores its values once
+// (conflict-free ds_write_b64, row of 64 lanes per value, rows padded to 72 doubles so that four
+// consecutive value-rows tile the 64 banks), then thread (k, part) adds the 4 waves x 8 lanes of
+// value k whose lane index is = part (mod 8) and the 8 parts are combined with three xor
+// shuffles.  Order of additions is fixed, so the row is reproducible bit for bit.  Values are
+// processed in chunks of 23 to bound LDS at 53 KB per workgroup.
+constexpr int kReduceChunk = 23;
+constexpr int kReduceRow = 72;
+
 template <int NACC>
 __device__ __forceinline__ void blockReduceStore(double (&acc)[NACC], double *out_row) {
   constexpr int kWaves = kBlockThreads / 64;
-  __shared__ double lds[kWaves][NACC];
+  constexpr int kChunk = NACC < kReduceChunk ? NACC : kReduceChunk;
+  constexpr int kPasses = (NACC + kChunk - 1) / kChunk;
+  __shared__ double lds[kWaves][kChunk][kReduceRow];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
+  const int k_read = threadIdx.x >> 3;  // value handled in the read phase (0..31)
+  const int part = threadIdx.x & 7;
 #pragma unroll
-  for (int k = 0; k < NACC; ++k) {
-    const double v = waveSum(acc[k]);
-    if (lane == 0) lds[wave][k] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < NACC) {
-    double v = lds[0][threadIdx.x];
+  for (int pass = 0; pass < kPasses; ++pass) {
+    if (pass > 0) __syncthreads();
 #pragma unroll
-    for (int w = 1; w < kWaves; ++w) v += lds[w][threadIdx.x];
-    out_row[threadIdx.x] = v;
+    for (int kk = 0; kk < kChunk; ++kk) {
+      const int k = pass * kChunk + kk;
+      if (k < NACC) lds[wave][kk][lane] = acc[k];
+    }
+    __syncthreads();
+    const int k_out = pass * kChunk + k_read;
+    if (k_read < kChunk && k_out < NACC) {
+      double v = 0.0;
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v += lds[w][k_read][j * 8 + part];
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      if (part == 0) out_row[k_out] = v;
+    }
   }
 }
 
@@ -416,24 +442,37 @@ __global__ void relayoutReprojKernel(const double *__restrict__ pts, const int *
 }
 
 // ---- finalisation: workgroup partials -> H | b | sum_sq -----------------------------------------
+// One workgroup of 1024 threads.  partials[grid][nacc] is read as a flat array with a stride that
+// is a multiple of nacc, so each thread stays in one column and all of its (few) loads are
+// independent and in flight together — the kernel costs about one memory round trip, not one
+// per row.  Column totals are then formed in a fixed order (bitwise reproducible).
 constexpr int kFinalThreads = 1024;
-constexpr int kFinalGroups = kFinalThreads / 64;
 
-// Column sums of partials[grid][nacc] (nacc <= 64) in a fixed order; totals land in `total`.
 __device__ __forceinline__ void columnTotals(const double *partials, int grid, int nacc,
-                                             double (&lds)[kFinalGroups][64], double (&total)[64]) {
-  const int c = threadIdx.x & 63;
-  const int g = threadIdx.x >> 6;
-  double s = 0.0;
-  if (c < nacc)
-    for (int row = g; row < grid; row += kFinalGroups) s += partials[size_t(row) * nacc + c];
-  lds[g][c] = s;
+                                             double (&scratch)[kFinalThreads], double (&total)[64]) {
+  const int per_col = kFinalThreads / nacc;  // threads per column
+  const int stride = per_col * nacc;
+  const int total_elems = grid * nacc;
+  const int t = threadIdx.x;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (t < stride) {
+    int idx = t;
+    for (; idx + 3 * stride < total_elems; idx += 4 * stride) {
+      const double a = partials[idx], b = partials[idx + stride], c = partials[idx + 2 * stride],
+                   d = partials[idx + 3 * stride];
+      s0 += a;
+      s1 += b;
+      s2 += c;
+      s3 += d;
+    }
+    for (; idx < total_elems; idx += stride) s0 += partials[idx];
+  }
+  scratch[t] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (threadIdx.x < 64) {
-    double t = 0.0;
-#pragma unroll
-    for (int k = 0; k < kFinalGroups; ++k) t += lds[k][threadIdx.x];
-    total[threadIdx.x] = t;
+  if (t < nacc) {
+    double v = 0.0;
+    for (int g = 0; g < per_col; ++g) v += scratch[t + g * nacc];
+    total[t] = v;
   }
   __syncthreads();
 }
@@ -441,9 +480,9 @@ __device__ __forceinline__ void columnTotals(const double *partials, int grid, i
 __global__ __launch_bounds__(kFinalThreads) void finalizeDenseKernel(const double *partials,
                                                                       int grid, int nacc,
                                                                       double *result) {
-  __shared__ double lds[kFinalGroups][64];
+  __shared__ double scratch[kFinalThreads];
   __shared__ double total[64];
-  columnTotals(partials, grid, nacc, lds, total);
+  columnTotals(partials, grid, nacc, scratch, total);
   const int k = threadIdx.x;
   if (k >= kResultDoubles) return;
   const bool full = (nacc == kAccFull);
@@ -461,63 +500,80 @@ __global__ __launch_bounds__(kFinalThreads) void finalizeDenseKernel(const doubl
   }
 }
 
+// Moments -> H, b.  With p_0 = 1:  W(a,b) = sum w p_a p_b,  V(a,c) = sum w p_a r_c  and
+//   H(i,j) = sum_{a,b} W(a,b) (J_a^T S J_b)(i,j),   b(i) = sum_a (J_a^T S V(a,.))(i).
+// 576 threads form one (a,b) term of one H entry each, 24 threads one (a) term of one b entry.
 __global__ __launch_bounds__(kFinalThreads) void finalizeMomentsKernel(const double *partials,
                                                                         int grid,
                                                                         const AffineBasis B,
                                                                         double *result) {
-  __shared__ double lds[kFinalGroups][64];
+  __shared__ double scratch[kFinalThreads];
   __shared__ double total[64];
-  columnTotals(partials, grid, kAccMoments, lds, total);
-  const int k = threadIdx.x;
-  if (k >= kResultDoubles) return;
-  // W(a, b) = sum w p_a p_b with p_0 = 1;  V(a, c) = sum w p_a r_c
-  auto W = [&](int a, int b) -> double {
-    if (a > b) {
-      const int t = a;
-      a = b;
-      b = t;
+  __shared__ double terms[36 * 16 + 6 * 4];
+  columnTotals(partials, grid, kAccMoments, scratch, total);
+  const int t = threadIdx.x;
+  if (t < 36 * 16) {
+    const int o = t >> 4, ab = t & 15;
+    const int i = o % 6, j = o / 6;
+    int a = ab >> 2, b = ab & 3;
+    double form = 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      double sj = 0.0;  // (S J_b)(r, j)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) sj += B.cov[r * 3 + c] * B.J[b][c * 6 + j];
+      form += B.J[a][r * 6 + i] * sj;
     }
-    if (a == 0) return b == 0 ? total[0] : total[b];
-    // (1,1)=4 (1,2)=5 (1,3)=6 (2,2)=7 (2,3)=8 (3,3)=9
-    return a == 1 ? total[3 + b] : (a == 2 ? total[5 + b] : total[9]);
-  };
-  auto V = [&](int a, int c) -> double { return a == 0 ? total[10 + c] : total[13 + 3 * (a - 1) + c]; };
-  if (k < 36) {
-    const int i = k % 6, j = k / 6;
-    double h = 0.0;
-    for (int a = 0; a < 4; ++a)
-      for (int b = 0; b < 4; ++b) {
-        double form = 0.0;  // (J_a^T S J_b)(i, j)
-        for (int r = 0; r < 3; ++r)
-          for (int c = 0; c < 3; ++c) form += B.J[a][r * 6 + i] * B.cov[r * 3 + c] * B.J[b][c * 6 + j];
-        h += W(a, b) * form;
-      }
-    result[k] = h;
-  } else if (k < 42) {
-    const int i = k - 36;
+    if (a > b) {
+      const int tmp = a;
+      a = b;
+      b = tmp;
+    }
+    // (0,0)=0 (0,b)=b (1,1)=4 (1,2)=5 (1,3)=6 (2,2)=7 (2,3)=8 (3,3)=9
+    const int wi = a == 0 ? b : (a == 1 ? 3 + b : (a == 2 ? 5 + b : 9));
+    terms[t] = total[wi] * form;
+  } else if (t < 36 * 16 + 24) {
+    const int u = t - 36 * 16;
+    const int i = u >> 2, a = u & 3;
     double g = 0.0;
-    for (int a = 0; a < 4; ++a)
-      for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) g += B.J[a][r * 6 + i] * B.cov[r * 3 + c] * V(a, c);
-    result[k] = g;
-  } else {
-    result[k] = total[22];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      double sv = 0.0;  // (S V(a, .))(r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        sv += B.cov[r * 3 + c] * (a == 0 ? total[10 + c] : total[13 + 3 * (a - 1) + c]);
+      g += B.J[a][r * 6 + i] * sv;
+    }
+    terms[t] = g;
+  }
+  __syncthreads();
+  if (t < 36) {
+    double h = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) h += terms[t * 16 + q];
+    result[t] = h;
+  } else if (t < 42) {
+    const int i = t - 36;
+    result[t] = ((terms[576 + i * 4] + terms[576 + i * 4 + 1]) + terms[576 + i * 4 + 2]) +
+                terms[576 + i * 4 + 3];
+  } else if (t == 42) {
+    result[42] = total[22];
   }
 }
 
 __global__ __launch_bounds__(kFinalThreads) void finalizeCostKernel(const double *partials,
                                                                      int grid, double *result) {
-  __shared__ double lds[kFinalGroups];
+  __shared__ double lds[kFinalThreads / 64];
   double s = 0.0;
   for (int row = threadIdx.x; row < grid; row += kFinalThreads) s += partials[row];
   s = waveSum(s);
   if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) {
-    double t = 0.0;
+    double v = 0.0;
 #pragma unroll
-    for (int k = 0; k < kFinalGroups; ++k) t += lds[k];
-    result[0] = t;
+    for (int k = 0; k < kFinalThreads / 64; ++k) v += lds[k];
+    result[0] = v;
   }
 }
 

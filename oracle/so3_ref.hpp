@@ -41,9 +41,12 @@ inline Mat3<Scalar> Exp(const Scalar delta[3]) {
     const Scalar c1 = Scalar(1.0) - std::cos(delta_norm);
     for (int i = 0; i < 3; ++i) {
       for (int j = 0; j < 3; ++j) {
-        Scalar kk = 0;  // ((1 - cos) K) K, coefficient by coefficient (:51-52)
-        for (int k = 0; k < 3; ++k) kk += (c1 * K.v[i][k]) * K.v[k][j];
-        R.v[i][j] = ((i == j ? Scalar(1) : Scalar(0)) + s * K.v[i][j]) + kk;
+        // :51-52.  Association as Eigen 3.4.0 (what ubuntu-22.04's libeigen3-dev, the CI's
+        // Eigen, ships; the reference pins no version) evaluates `A + (c K) K` into a noalias
+        // destination: dst = A, then dst += c * (K.lazyProduct(K)) with the scalar factored out.
+        Scalar kk = 0;
+        for (int k = 0; k < 3; ++k) kk += K.v[i][k] * K.v[k][j];
+        R.v[i][j] = ((i == j ? Scalar(1) : Scalar(0)) + s * K.v[i][j]) + c1 * kk;
       }
     }
   } else {
