@@ -1,0 +1,60 @@
+"""The C-ABI library loads on a machine without a GPU, exports every entry point that
+include/moptimizer_hip.h declares, and refuses (rather than falls back) when no device exists."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests import datasets as ds
+
+HEADER = os.path.join(ds.ROOT, "include", "moptimizer_hip.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    return sorted(set(re.findall(r"MOPT_API\s+[\w\s\*]+?\b(mopt_\w+)\s*\(", text)))
+
+
+def test_header_declares_the_boundary():
+    names = declared_functions()
+    for required in ("mopt_point2point_create", "mopt_reprojection_create", "mopt_cost_linearize",
+                     "mopt_cost_compute", "mopt_cost_set_covariance", "mopt_cost_set_loss",
+                     "mopt_cost_destroy", "mopt_cost_linearize_async", "mopt_group_linearize",
+                     "mopt_last_error"):
+        assert required in names
+    assert len(names) >= 25
+
+
+def test_library_exports_every_declared_symbol():
+    import moptimizer_0_amd as mo
+    lib = mo.capi.load()
+    for name in declared_functions():
+        assert hasattr(lib, name), "libmoptimizer_hip.so does not export %s" % name
+
+
+def test_every_cited_reference_interface_is_in_the_header():
+    text = open(HEADER).read()
+    for cite in ("include/moptimizer/cost_function.h:50", "include/moptimizer/cost_function.h:49",
+                 "linearization.h:65-158", "tst/point2point.cpp"):
+        assert cite in text
+
+
+def test_no_device_means_error_not_fallback():
+    import moptimizer_0_amd as mo
+    if mo.capi.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(mo.MoptError) as e:
+        mo.Point2PointCost(np.zeros((8, 3)), np.zeros((8, 3)))
+    assert "no HIP device" in str(e.value)
+
+
+def test_argument_validation_without_device():
+    import moptimizer_0_amd as mo
+    lib = mo.capi.load()
+    h = ctypes.c_void_p()
+    rc = lib.mopt_point2point_create(ctypes.byref(h), 0, 3, None, None, 0, 0)
+    assert rc == 1 and b"scalar_bytes" in lib.mopt_last_error()
+    assert lib.mopt_cost_set_loss(None, 0, 0.0) == 1
+    assert lib.mopt_cost_linearize(None, 0, None, None, None, None) == 1

@@ -1,0 +1,24 @@
+"""C++ side of the drop-in: the reference's point2point / camera tests with the HIP-backed cost
+classes under the unchanged LM loop (tests/cpp/dropin_point2point.cpp), run on the GPU box."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import datasets as ds
+
+pytestmark = pytest.mark.gpu
+
+EXE = os.path.join(ds.ROOT, "tests", "cpp", "_build", "dropin_point2point")
+
+
+def test_cpp_dropin_program(hip_lib, facade, tmp_path):
+    assert os.path.exists(EXE), "build it with `make cpptests` (done by __graft_entry__.build())"
+    src, _ = facade
+    path = os.path.join(tmp_path, "facade.f64")
+    np.ascontiguousarray(src, dtype="<f8").tofile(path)
+    out = subprocess.run([EXE, path], capture_output=True, text=True, timeout=600)
+    print(out.stdout[-4000:])
+    assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-2000:]
+    assert "SUMMARY failures=0" in out.stdout
