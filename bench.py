@@ -44,6 +44,9 @@ def parse_args():
     ap.add_argument("--mode", choices=["analytic", "analytic_tst", "numeric"], default="analytic")
     ap.add_argument("--variant", choices=["auto", "literal", "moments"], default="auto")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--collective", choices=["rccl", "torch"], default="rccl",
+                    help="N>1: all-reduce inside the C-ABI library on the cost's stream (rccl), or "
+                         "torch.distributed.all_reduce on the async result (torch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="target CPU time of the cpu_baseline sample")
@@ -128,12 +131,32 @@ def main():
     del src, tgt
     torch.cuda.empty_cache()
 
-    sweep = gpu_point2point_sweep(cost)
+    # N > 1: one RCCL all-reduce of the 43 partial sums per sweep.  Preferred form: the library's own
+    # communicator (id from rank 0, spread with torch.distributed), so kernel, finalize, all-reduce
+    # and the publish to host memory are queued back to back on one stream by one C call.
+    collective = "none"
+    sweep = None
+    if world > 1:
+        collective = args.collective
+        if collective == "rccl":
+            try:
+                ids = [mo.capi.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                cost.comm_init_rank(ids[0], rank, world)
+            except Exception as e:  # fall back to the torch.distributed collective (still RCCL)
+                if rank == 0:
+                    print("library communicator unavailable (%s); using torch.distributed" % e,
+                          file=sys.stderr)
+                collective = "torch"
+        if collective == "torch":
+            sweep = gpu_point2point_sweep(cost)
     x_base = ds.X_GENERIC.astype(np_dtype)
 
     def step(k):
         x = x_base + np_dtype(1e-4) * np_dtype(k % 16)
-        return sweep.linearize(x, jac_mode)
+        if sweep is not None:
+            return sweep.linearize(x, jac_mode)
+        return cost.linearize(x, jac_mode)
 
     def barrier():
         if world > 1:
@@ -191,6 +214,7 @@ def main():
                 "correspondences_per_gpu": args.n,
                 "total_correspondences": total,
                 "parallelism": "shard%d" % world,
+                "collective": collective,
                 "kernel_variant": args.variant,
             },
             "roofline": {

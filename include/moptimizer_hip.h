@@ -142,6 +142,19 @@ MOPT_API int mopt_cost_compute_async(mopt_cost *cost, const void *x, double *d_s
 MOPT_API int mopt_cost_stream(mopt_cost *cost, void **hip_stream);
 MOPT_API int mopt_cost_synchronize(mopt_cost *cost);
 
+/* ---- multi-process shard group: one rank (process) per GPU, RCCL over xGMI ----------------- */
+
+/* Rank 0 obtains an id (MOPT_COMM_ID_BYTES bytes) and hands it to every rank by any means
+ * (torch.distributed broadcast, MPI, a file).  After mopt_cost_comm_init_rank, the blocking
+ * mopt_cost_linearize / mopt_cost_compute of this cost sum the n*n + n + 1 (or 1) partial results
+ * of all ranks with one ncclAllReduce(sum, fp64) on the cost's stream before publishing them to
+ * the host, so every rank returns the whole-data-set H, b, sum_sq.  Collective: all ranks must
+ * make the same calls in the same order.  Replaces the host accumulation
+ * `hessian_ += cost_hessian_` (src/levenberg_marquadt_dyn.cpp:57-59) across shards. */
+#define MOPT_COMM_ID_BYTES 128
+MOPT_API int mopt_comm_unique_id(void *id_out, int id_bytes);
+MOPT_API int mopt_cost_comm_init_rank(mopt_cost *cost, const void *id, int rank, int num_ranks);
+
 /* ---- measurement -------------------------------------------------------------------------- */
 
 /* With profiling on, every sweep kernel launch is bracketed by HIP events on its stream.

@@ -66,6 +66,8 @@ def load():
                                     ctypes.c_void_p],
         "mopt_cost_stream": [ctypes.c_void_p, c_void_pp],
         "mopt_cost_synchronize": [ctypes.c_void_p],
+        "mopt_comm_unique_id": [ctypes.c_void_p, ctypes.c_int],
+        "mopt_cost_comm_init_rank": [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int],
         "mopt_cost_set_profiling": [ctypes.c_void_p, ctypes.c_int],
         "mopt_cost_profile": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
                               ctypes.POINTER(ctypes.c_int64)],
@@ -95,6 +97,16 @@ def load():
 def check(rc):
     if rc != MOPT_OK:
         raise MoptError("moptimizer_hip error %d: %s" % (rc, load().mopt_last_error().decode()))
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """RCCL unique id (bytes) for mopt_cost_comm_init_rank; call on one rank and broadcast."""
+    buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+    check(load().mopt_comm_unique_id(buf, COMM_ID_BYTES))
+    return buf.raw
 
 
 def device_count():
@@ -162,6 +174,12 @@ class _CostBase:
         x = np.ascontiguousarray(x, dtype=_dtype_of(self.scalar_bytes))
         check(load().mopt_cost_compute_async(self._h, _ptr(x), ctypes.c_void_p(d_sum_ptr),
                                              ctypes.c_void_p(stream_ptr or 0)))
+
+    def comm_init_rank(self, unique_id, rank, num_ranks):
+        """Attach this cost (one shard) to the multi-process RCCL group: afterwards the blocking
+        linearize / compute_cost return the sums over all ranks."""
+        buf = ctypes.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
+        check(load().mopt_cost_comm_init_rank(self._h, buf, int(rank), int(num_ranks)))
 
     def synchronize(self):
         check(load().mopt_cost_synchronize(self._h))

@@ -68,8 +68,15 @@ struct mopt_cost {
   void *d_tiles = nullptr;
   double *d_partials = nullptr;
   double *d_result = nullptr;  // kResultDoubles
-  double *h_result = nullptr;  // pinned
+  // Mapped, fine-grained host memory the finalize kernel publishes into: 43 results + flag word.
+  double *h_result = nullptr;
+  unsigned long long *h_flag = nullptr;
+  double *h_result_dev = nullptr;  // the same memory as the device addresses it
+  unsigned long long *h_flag_dev = nullptr;
+  unsigned long long sequence = 0;
   hipStream_t stream = nullptr;
+  ncclComm_t comm = nullptr;  // multi-process shard group (one rank per GPU), optional
+  int comm_size = 1;
 
   double cov[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // row-major m x m, as double
   int cov_mode = mopt::kCovIdentity;
@@ -82,6 +89,7 @@ struct mopt_cost {
 
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
+  std::vector<hipEvent_t> free_events;
   double sweep_ms_total = 0.0;
   long long sweep_launches = 0;
 };
@@ -106,30 +114,38 @@ int resolvePendingEvents(mopt_cost *c) {
     MOPT_HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
     c->sweep_ms_total += double(ms);
     c->sweep_launches += 1;
-    hipEventDestroy(pr.first);
-    hipEventDestroy(pr.second);
+    c->free_events.push_back(pr.first);
+    c->free_events.push_back(pr.second);
   }
   c->pending_events.clear();
   return MOPT_OK;
 }
 
-// Brackets the dominant kernel of a sweep with events when profiling is on.
+// Launch site of the dominant kernel of a sweep.  With profiling on, the dispatch carries a
+// start/stop event pair (timestamps of the kernel itself, as a profiler's kernel trace reports).
 struct SweepTimer {
   mopt_cost *c;
-  hipStream_t s;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  bool on;
-  SweepTimer(mopt_cost *cost, hipStream_t stream) : c(cost), s(stream), on(cost->profiling) {
-    if (on) {
-      if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) on = false;
-      if (on) hipEventRecord(e0, s);
+  mopt::LaunchSite site;
+  SweepTimer(mopt_cost *cost, hipStream_t stream) : c(cost) {
+    site.stream = stream;
+    if (!cost->profiling) return;
+    if (cost->pending_events.size() >= 4096 && resolvePendingEvents(cost) != MOPT_OK) return;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    for (auto &e : ev) {
+      if (!cost->free_events.empty()) {
+        e = cost->free_events.back();
+        cost->free_events.pop_back();
+      } else if (hipEventCreate(&e) != hipSuccess) {
+        e = nullptr;
+      }
+    }
+    if (ev[0] && ev[1]) {
+      site.start = ev[0];
+      site.stop = ev[1];
     }
   }
   void stop() {
-    if (!on) return;
-    hipEventRecord(e1, s);
-    c->pending_events.emplace_back(e0, e1);
-    on = false;
+    if (site.start && site.stop) c->pending_events.emplace_back(site.start, site.stop);
   }
 };
 
@@ -229,7 +245,8 @@ void fillBasis(const mopt_cost *c, int jac_mode, const mopt::P2PSweepArgs<S> &a,
 }
 
 template <typename S>
-int p2pLinearizeAsync(mopt_cost *c, int jac_mode, const S *x, double *d_result, hipStream_t s) {
+int p2pLinearizeAsync(mopt_cost *c, int jac_mode, const S *x, double *d_result, hipStream_t s,
+                      const mopt::HostPublish &pub) {
   mopt::P2PSweepArgs<S> args;
   fillP2PArgs<S>(c, x, jac_mode == MOPT_JAC_NUMERIC, args);
   bool moments;
@@ -243,29 +260,31 @@ int p2pLinearizeAsync(mopt_cost *c, int jac_mode, const S *x, double *d_result, 
     fillBasis<S>(c, jac_mode, args, basis);
     const int grid = gridFor(c, envInt("MOPT_BLOCKS_PER_CU", 2));
     SweepTimer timer(c, s);
-    MOPT_HIP_TRY(mopt::launchP2PMoments<S>(args, grid, s));
+    MOPT_HIP_TRY(mopt::launchP2PMoments<S>(args, grid, timer.site));
     timer.stop();
-    MOPT_HIP_TRY(mopt::launchFinalizeMoments(c->d_partials, grid, basis, d_result, s));
+    MOPT_HIP_TRY(mopt::launchFinalizeMoments(c->d_partials, grid, basis, d_result, pub, s));
   } else {
     const int grid = gridFor(c, envInt("MOPT_BLOCKS_PER_CU", 2));
     const int nacc = c->cov_mode == mopt::kCovGeneral ? mopt::kAccFull : mopt::kAccSym;
     SweepTimer timer(c, s);
-    MOPT_HIP_TRY(mopt::launchP2PLinearizeLiteral<S>(args, jac_mode, c->cov_mode, grid, s));
+    MOPT_HIP_TRY(mopt::launchP2PLinearizeLiteral<S>(args, jac_mode, c->cov_mode, grid, timer.site));
     timer.stop();
-    MOPT_HIP_TRY(mopt::launchFinalizeDense(c->d_partials, grid, nacc, kNumParams, d_result, s));
+    MOPT_HIP_TRY(
+        mopt::launchFinalizeDense(c->d_partials, grid, nacc, kNumParams, d_result, pub, s));
   }
   return MOPT_OK;
 }
 
 template <typename S>
-int p2pCostAsync(mopt_cost *c, const S *x, double *d_sum, hipStream_t s) {
+int p2pCostAsync(mopt_cost *c, const S *x, double *d_sum, hipStream_t s,
+                 const mopt::HostPublish &pub) {
   mopt::P2PSweepArgs<S> args;
   fillP2PArgs<S>(c, x, false, args);
   const int grid = gridFor(c, envInt("MOPT_BLOCKS_PER_CU", 2));
   SweepTimer timer(c, s);
-  MOPT_HIP_TRY(mopt::launchP2PCost<S>(args, grid, s));
+  MOPT_HIP_TRY(mopt::launchP2PCost<S>(args, grid, timer.site));
   timer.stop();
-  MOPT_HIP_TRY(mopt::launchFinalizeCost(c->d_partials, grid, d_sum, s));
+  MOPT_HIP_TRY(mopt::launchFinalizeCost(c->d_partials, grid, d_sum, pub, s));
   return MOPT_OK;
 }
 
@@ -319,7 +338,7 @@ void fillReprojArgs(const mopt_cost *c, const double *x, bool with_steps,
 }
 
 int reprojLinearizeAsync(mopt_cost *c, int jac_mode, const double *x, double *d_result,
-                         hipStream_t s) {
+                         hipStream_t s, const mopt::HostPublish &pub) {
   if (jac_mode != MOPT_JAC_NUMERIC)
     return fail(MOPT_ERR_UNSUPPORTED,
                 "the reprojection model has no analytic Jacobian (BaseModel, numeric only)");
@@ -328,39 +347,94 @@ int reprojLinearizeAsync(mopt_cost *c, int jac_mode, const double *x, double *d_
   const int grid = gridFor(c, envInt("MOPT_BLOCKS_PER_CU", 2));
   const int nacc = c->cov_mode == mopt::kCovGeneral ? mopt::kAccFull : mopt::kAccSym;
   SweepTimer timer(c, s);
-  MOPT_HIP_TRY(mopt::launchReprojLinearize(args, c->cov_mode, grid, s));
+  MOPT_HIP_TRY(mopt::launchReprojLinearize(args, c->cov_mode, grid, timer.site));
   timer.stop();
-  MOPT_HIP_TRY(mopt::launchFinalizeDense(c->d_partials, grid, nacc, kNumParams, d_result, s));
+  MOPT_HIP_TRY(
+      mopt::launchFinalizeDense(c->d_partials, grid, nacc, kNumParams, d_result, pub, s));
   return MOPT_OK;
 }
 
-int reprojCostAsync(mopt_cost *c, const double *x, double *d_sum, hipStream_t s) {
+int reprojCostAsync(mopt_cost *c, const double *x, double *d_sum, hipStream_t s,
+                    const mopt::HostPublish &pub) {
   mopt::ReprojSweepArgs args;
   fillReprojArgs(c, x, false, args);
   const int grid = gridFor(c, envInt("MOPT_BLOCKS_PER_CU", 2));
   SweepTimer timer(c, s);
-  MOPT_HIP_TRY(mopt::launchReprojCost(args, grid, s));
+  MOPT_HIP_TRY(mopt::launchReprojCost(args, grid, timer.site));
   timer.stop();
-  MOPT_HIP_TRY(mopt::launchFinalizeCost(c->d_partials, grid, d_sum, s));
+  MOPT_HIP_TRY(mopt::launchFinalizeCost(c->d_partials, grid, d_sum, pub, s));
   return MOPT_OK;
 }
 
-int linearizeAsyncImpl(mopt_cost *c, int jac_mode, const void *x, double *d_result,
-                       hipStream_t s) {
+int linearizeAsyncImpl(mopt_cost *c, int jac_mode, const void *x, double *d_result, hipStream_t s,
+                       const mopt::HostPublish &pub = mopt::HostPublish()) {
   if (jac_mode < MOPT_JAC_ANALYTIC || jac_mode > MOPT_JAC_NUMERIC)
     return fail(MOPT_ERR_INVALID_ARGUMENT, "unknown jacobian_mode");
   if (c->model == kModelReprojection)
-    return reprojLinearizeAsync(c, jac_mode, static_cast<const double *>(x), d_result, s);
+    return reprojLinearizeAsync(c, jac_mode, static_cast<const double *>(x), d_result, s, pub);
   if (c->scalar_bytes == 8)
-    return p2pLinearizeAsync<double>(c, jac_mode, static_cast<const double *>(x), d_result, s);
-  return p2pLinearizeAsync<float>(c, jac_mode, static_cast<const float *>(x), d_result, s);
+    return p2pLinearizeAsync<double>(c, jac_mode, static_cast<const double *>(x), d_result, s, pub);
+  return p2pLinearizeAsync<float>(c, jac_mode, static_cast<const float *>(x), d_result, s, pub);
 }
 
-int costAsyncImpl(mopt_cost *c, const void *x, double *d_sum, hipStream_t s) {
+int costAsyncImpl(mopt_cost *c, const void *x, double *d_sum, hipStream_t s,
+                  const mopt::HostPublish &pub = mopt::HostPublish()) {
   if (c->model == kModelReprojection)
-    return reprojCostAsync(c, static_cast<const double *>(x), d_sum, s);
-  if (c->scalar_bytes == 8) return p2pCostAsync<double>(c, static_cast<const double *>(x), d_sum, s);
-  return p2pCostAsync<float>(c, static_cast<const float *>(x), d_sum, s);
+    return reprojCostAsync(c, static_cast<const double *>(x), d_sum, s, pub);
+  if (c->scalar_bytes == 8)
+    return p2pCostAsync<double>(c, static_cast<const double *>(x), d_sum, s, pub);
+  return p2pCostAsync<float>(c, static_cast<const float *>(x), d_sum, s, pub);
+}
+
+// Blocking completion without a copy or a stream synchronisation: the last kernel of the call
+// stores the results into mapped host memory and then releases `sequence` into the flag word;
+// the host polls that word.  The stream is queried now and then so that a faulted kernel turns
+// into an error instead of an endless wait.
+int waitPublished(mopt_cost *c, unsigned long long sequence) {
+  unsigned long long spins = 0;
+  while (__atomic_load_n(c->h_flag, __ATOMIC_ACQUIRE) != sequence) {
+    if ((++spins & 0x3fff) == 0) {
+      const hipError_t q = hipStreamQuery(c->stream);
+      if (q == hipSuccess) {
+        if (__atomic_load_n(c->h_flag, __ATOMIC_ACQUIRE) == sequence) break;
+        return fail(MOPT_ERR_HIP, "stream drained without publishing a result");
+      }
+      if (q != hipErrorNotReady)
+        return fail(MOPT_ERR_HIP, std::string("sweep failed: ") + hipGetErrorString(q));
+    }
+    __builtin_ia32_pause();
+  }
+  return MOPT_OK;
+}
+
+mopt::HostPublish nextPublish(mopt_cost *c, int offset) {
+  mopt::HostPublish pub;
+  pub.host_result = c->h_result_dev + offset;
+  pub.host_flag = c->h_flag_dev;
+  pub.sequence = ++c->sequence;
+  return pub;
+}
+
+// One blocking sweep on the cost's own stream: kernels (+ all-reduce over the attached
+// communicator) and the published result in c->h_result[offset .. offset + count).
+int blockingSweep(mopt_cost *c, bool cost_only, int jac_mode, const void *x) {
+  const int offset = cost_only ? 42 : 0;
+  const int count = cost_only ? 1 : kResultDoubles;
+  mopt::HostPublish pub = nextPublish(c, offset);
+  int rc;
+  if (c->comm && c->comm_size > 1) {
+    rc = cost_only ? costAsyncImpl(c, x, c->d_result + 42, c->stream)
+                   : linearizeAsyncImpl(c, jac_mode, x, c->d_result, c->stream);
+    if (rc != MOPT_OK) return rc;
+    MOPT_NCCL_TRY(ncclAllReduce(c->d_result + offset, c->d_result + offset, count, ncclDouble,
+                                ncclSum, c->comm, c->stream));
+    MOPT_HIP_TRY(mopt::launchPublish(c->d_result + offset, count, pub, c->stream));
+  } else {
+    rc = cost_only ? costAsyncImpl(c, x, c->d_result + 42, c->stream, pub)
+                   : linearizeAsyncImpl(c, jac_mode, x, c->d_result, c->stream, pub);
+    if (rc != MOPT_OK) return rc;
+  }
+  return waitPublished(c, pub.sequence);
 }
 
 void storeResult(const mopt_cost *c, const double *res, void *hessian, void *b, void *sum_sq) {
@@ -393,24 +467,31 @@ int commonCreate(mopt_cost *c, int device) {
   MOPT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_partials),
                          size_t(c->max_grid) * mopt::kAccFull * sizeof(double)));
   MOPT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_result), kResultDoubles * sizeof(double)));
-  MOPT_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_result),
-                             kResultDoubles * sizeof(double), hipHostMallocDefault));
+  // results (43) + padding + flag word in one mapped, coherent host allocation
+  MOPT_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_result), 64 * sizeof(double),
+                             hipHostMallocMapped | hipHostMallocCoherent));
+  std::memset(c->h_result, 0, 64 * sizeof(double));
+  c->h_flag = reinterpret_cast<unsigned long long *>(c->h_result + 48);
+  MOPT_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->h_result_dev), c->h_result, 0));
+  c->h_flag_dev = reinterpret_cast<unsigned long long *>(c->h_result_dev + 48);
   return MOPT_OK;
 }
 
 void destroyCost(mopt_cost *c) {
   if (!c) return;
-  hipSetDevice(c->device);
-  if (c->stream) hipStreamSynchronize(c->stream);
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto &pr : c->pending_events) {
-    hipEventDestroy(pr.first);
-    hipEventDestroy(pr.second);
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
   }
-  if (c->d_tiles) hipFree(c->d_tiles);
-  if (c->d_partials) hipFree(c->d_partials);
-  if (c->d_result) hipFree(c->d_result);
-  if (c->h_result) hipHostFree(c->h_result);
-  if (c->stream) hipStreamDestroy(c->stream);
+  for (auto e : c->free_events) (void)hipEventDestroy(e);
+  if (c->comm) ncclCommDestroy(c->comm);
+  if (c->d_tiles) (void)hipFree(c->d_tiles);
+  if (c->d_partials) (void)hipFree(c->d_partials);
+  if (c->d_result) (void)hipFree(c->d_result);
+  if (c->h_result) (void)hipHostFree(c->h_result);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
 
@@ -420,8 +501,8 @@ struct Staging {
   bool owned = false;
   ~Staging() {
     if (owned) {
-      if (a) hipFree(a);
-      if (b) hipFree(b);
+      if (a) (void)hipFree(a);
+      if (b) (void)hipFree(b);
     }
   }
 };
@@ -621,11 +702,8 @@ int mopt_cost_linearize(mopt_cost *c, int jacobian_mode, const void *x, void *he
                         void *sum_sq) {
   if (!c || !x) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
   MOPT_HIP_TRY(hipSetDevice(c->device));
-  const int rc = linearizeAsyncImpl(c, jacobian_mode, x, c->d_result, c->stream);
+  const int rc = blockingSweep(c, false, jacobian_mode, x);
   if (rc != MOPT_OK) return rc;
-  MOPT_HIP_TRY(hipMemcpyAsync(c->h_result, c->d_result, kResultDoubles * sizeof(double),
-                              hipMemcpyDeviceToHost, c->stream));
-  MOPT_HIP_TRY(hipStreamSynchronize(c->stream));
   storeResult(c, c->h_result, hessian, b, sum_sq);
   return MOPT_OK;
 }
@@ -633,12 +711,32 @@ int mopt_cost_linearize(mopt_cost *c, int jacobian_mode, const void *x, void *he
 int mopt_cost_compute(mopt_cost *c, const void *x, void *sum_sq) {
   if (!c || !x || !sum_sq) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
   MOPT_HIP_TRY(hipSetDevice(c->device));
-  const int rc = costAsyncImpl(c, x, c->d_result + 42, c->stream);
+  const int rc = blockingSweep(c, true, 0, x);
   if (rc != MOPT_OK) return rc;
-  MOPT_HIP_TRY(hipMemcpyAsync(c->h_result + 42, c->d_result + 42, sizeof(double),
-                              hipMemcpyDeviceToHost, c->stream));
-  MOPT_HIP_TRY(hipStreamSynchronize(c->stream));
   storeResult(c, c->h_result, nullptr, nullptr, sum_sq);
+  return MOPT_OK;
+}
+
+// ---- multi-process shard group: one rank per GPU, RCCL over xGMI ----------------------------
+int mopt_comm_unique_id(void *id_out, int id_bytes) {
+  if (!id_out || id_bytes < int(sizeof(ncclUniqueId)))
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "id buffer must hold MOPT_COMM_ID_BYTES bytes");
+  ncclUniqueId id;
+  MOPT_NCCL_TRY(ncclGetUniqueId(&id));
+  std::memset(id_out, 0, size_t(id_bytes));
+  std::memcpy(id_out, &id, sizeof id);
+  return MOPT_OK;
+}
+
+int mopt_cost_comm_init_rank(mopt_cost *c, const void *id, int rank, int num_ranks) {
+  if (!c || !id || num_ranks < 1 || rank < 0 || rank >= num_ranks)
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "bad communicator arguments");
+  if (c->comm) return fail(MOPT_ERR_INVALID_ARGUMENT, "a communicator is already attached");
+  MOPT_HIP_TRY(hipSetDevice(c->device));
+  ncclUniqueId uid;
+  std::memcpy(&uid, id, sizeof uid);
+  MOPT_NCCL_TRY(ncclCommInitRank(&c->comm, num_ranks, uid, rank));
+  c->comm_size = num_ranks;
   return MOPT_OK;
 }
 

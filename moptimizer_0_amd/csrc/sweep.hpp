@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdint>
 
@@ -73,6 +74,23 @@ struct AffineBasis {
   double cov[9];
 };
 
+// Where a sweep kernel is launched.  With `start`/`stop` set, the dispatch itself is timestamped
+// (hipExtLaunchKernelGGL), which is the duration a profiler's kernel trace reports.
+struct LaunchSite {
+  hipStream_t stream = nullptr;
+  hipEvent_t start = nullptr;
+  hipEvent_t stop = nullptr;
+};
+
+// Optional hand-over of a finalize kernel's 43 (or 1) results straight into mapped host memory:
+// the values are stored, fenced at system scope, and then `*flag = sequence` is released, so a
+// host thread polling the flag needs neither a copy nor a stream synchronisation.
+struct HostPublish {
+  double *host_result = nullptr;           // mapped, fine-grained host memory (device pointer)
+  unsigned long long *host_flag = nullptr;
+  unsigned long long sequence = 0;
+};
+
 // ---- launches (all asynchronous on `stream`) ------------------------------------------------
 template <typename S>
 hipError_t launchRelayoutP2P(const S *src_xyz, const S *tgt_xyz, long long count, S *tiles,
@@ -84,23 +102,26 @@ hipError_t launchRelayoutReproj(const double *points_xyzw, const int32_t *pixels
 // literal per-point evaluation; partials: [grid][kAccSym or kAccFull]
 template <typename S>
 hipError_t launchP2PLinearizeLiteral(const P2PSweepArgs<S> &args, int jac_mode, int cov_mode,
-                                     int grid, hipStream_t stream);
+                                     int grid, const LaunchSite &site);
 // moment accumulation (analytic modes; numeric via the affine forward-difference basis)
 template <typename S>
-hipError_t launchP2PMoments(const P2PSweepArgs<S> &args, int grid, hipStream_t stream);
+hipError_t launchP2PMoments(const P2PSweepArgs<S> &args, int grid, const LaunchSite &site);
 template <typename S>
-hipError_t launchP2PCost(const P2PSweepArgs<S> &args, int grid, hipStream_t stream);
+hipError_t launchP2PCost(const P2PSweepArgs<S> &args, int grid, const LaunchSite &site);
 
 hipError_t launchReprojLinearize(const ReprojSweepArgs &args, int cov_mode, int grid,
-                                 hipStream_t stream);
-hipError_t launchReprojCost(const ReprojSweepArgs &args, int grid, hipStream_t stream);
+                                 const LaunchSite &site);
+hipError_t launchReprojCost(const ReprojSweepArgs &args, int grid, const LaunchSite &site);
 
 // partials[grid][nacc] -> result[n*n + n + 1] (H column-major | b | sum_sq)
 hipError_t launchFinalizeDense(const double *partials, int grid, int nacc, int n, double *result,
-                               hipStream_t stream);
+                               const HostPublish &pub, hipStream_t stream);
 hipError_t launchFinalizeMoments(const double *partials, int grid, const AffineBasis &basis,
-                                 double *result, hipStream_t stream);
+                                 double *result, const HostPublish &pub, hipStream_t stream);
 hipError_t launchFinalizeCost(const double *partials, int grid, double *result,
-                              hipStream_t stream);
+                              const HostPublish &pub, hipStream_t stream);
+// device result (count doubles) -> mapped host memory + flag (after a collective)
+hipError_t launchPublish(const double *d_values, int count, const HostPublish &pub,
+                         hipStream_t stream);
 
 }  // namespace mopt

@@ -448,6 +448,16 @@ __global__ void relayoutReprojKernel(const double *__restrict__ pts, const int *
 // per row.  Column totals are then formed in a fixed order (bitwise reproducible).
 constexpr int kFinalThreads = 1024;
 
+// Called by every thread of the (single) finalize workgroup after it has stored its result
+// element (if any) to pub.host_result: orders those stores before the flag at system scope.
+__device__ __forceinline__ void publishFlag(const HostPublish &pub) {
+  if (pub.host_flag == nullptr) return;
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0)
+    __hip_atomic_store(pub.host_flag, pub.sequence, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __device__ __forceinline__ void columnTotals(const double *partials, int grid, int nacc,
                                              double (&scratch)[kFinalThreads], double (&total)[64]) {
   const int per_col = kFinalThreads / nacc;  // threads per column
@@ -479,25 +489,31 @@ __device__ __forceinline__ void columnTotals(const double *partials, int grid, i
 
 __global__ __launch_bounds__(kFinalThreads) void finalizeDenseKernel(const double *partials,
                                                                       int grid, int nacc,
-                                                                      double *result) {
+                                                                      double *result,
+                                                                      const HostPublish pub) {
   __shared__ double scratch[kFinalThreads];
   __shared__ double total[64];
   columnTotals(partials, grid, nacc, scratch, total);
   const int k = threadIdx.x;
-  if (k >= kResultDoubles) return;
-  const bool full = (nacc == kAccFull);
-  const int nh = full ? 36 : 21;
-  if (k < 36) {
-    const int i = k % 6, j = k / 6;  // column-major H(i, j)
-    if (full) {
-      result[k] = total[j * 6 + i];
+  if (k < kResultDoubles) {
+    const bool full = (nacc == kAccFull);
+    const int nh = full ? 36 : 21;
+    double v;
+    if (k < 36) {
+      const int i = k % 6, j = k / 6;  // column-major H(i, j)
+      if (full) {
+        v = total[j * 6 + i];
+      } else {
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        v = total[hi * (hi + 1) / 2 + lo];
+      }
     } else {
-      const int lo = i < j ? i : j, hi = i < j ? j : i;
-      result[k] = total[hi * (hi + 1) / 2 + lo];
+      v = total[nh + (k - 36)];  // b (6) then sum_sq
     }
-  } else {
-    result[k] = total[nh + (k - 36)];  // b (6) then sum_sq
+    result[k] = v;
+    if (pub.host_result) pub.host_result[k] = v;
   }
+  publishFlag(pub);
 }
 
 // Moments -> H, b.  With p_0 = 1:  W(a,b) = sum w p_a p_b,  V(a,c) = sum w p_a r_c  and
@@ -506,7 +522,8 @@ __global__ __launch_bounds__(kFinalThreads) void finalizeDenseKernel(const doubl
 __global__ __launch_bounds__(kFinalThreads) void finalizeMomentsKernel(const double *partials,
                                                                         int grid,
                                                                         const AffineBasis B,
-                                                                        double *result) {
+                                                                        double *result,
+                                                                        const HostPublish pub) {
   __shared__ double scratch[kFinalThreads];
   __shared__ double total[64];
   __shared__ double terms[36 * 16 + 6 * 4];
@@ -547,22 +564,28 @@ __global__ __launch_bounds__(kFinalThreads) void finalizeMomentsKernel(const dou
     terms[t] = g;
   }
   __syncthreads();
-  if (t < 36) {
-    double h = 0.0;
+  if (t < kResultDoubles) {
+    double v;
+    if (t < 36) {
+      v = 0.0;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) h += terms[t * 16 + q];
-    result[t] = h;
-  } else if (t < 42) {
-    const int i = t - 36;
-    result[t] = ((terms[576 + i * 4] + terms[576 + i * 4 + 1]) + terms[576 + i * 4 + 2]) +
-                terms[576 + i * 4 + 3];
-  } else if (t == 42) {
-    result[42] = total[22];
+      for (int q = 0; q < 16; ++q) v += terms[t * 16 + q];
+    } else if (t < 42) {
+      const int i = t - 36;
+      v = ((terms[576 + i * 4] + terms[576 + i * 4 + 1]) + terms[576 + i * 4 + 2]) +
+          terms[576 + i * 4 + 3];
+    } else {
+      v = total[22];
+    }
+    result[t] = v;
+    if (pub.host_result) pub.host_result[t] = v;
   }
+  publishFlag(pub);
 }
 
 __global__ __launch_bounds__(kFinalThreads) void finalizeCostKernel(const double *partials,
-                                                                     int grid, double *result) {
+                                                                     int grid, double *result,
+                                                                     const HostPublish pub) {
   __shared__ double lds[kFinalThreads / 64];
   double s = 0.0;
   for (int row = threadIdx.x; row < grid; row += kFinalThreads) s += partials[row];
@@ -574,7 +597,14 @@ __global__ __launch_bounds__(kFinalThreads) void finalizeCostKernel(const double
 #pragma unroll
     for (int k = 0; k < kFinalThreads / 64; ++k) v += lds[k];
     result[0] = v;
+    if (pub.host_result) pub.host_result[0] = v;
   }
+  publishFlag(pub);
+}
+
+__global__ void publishKernel(const double *values, int count, const HostPublish pub) {
+  if (int(threadIdx.x) < count && pub.host_result) pub.host_result[threadIdx.x] = values[threadIdx.x];
+  publishFlag(pub);
 }
 
 }  // namespace
@@ -607,106 +637,107 @@ hipError_t launchRelayoutReproj(const double *points_xyzw, const int32_t *pixels
 }
 
 namespace {
+// Plain launch, or a timestamped one when the site carries events.
+template <typename Kernel, typename Args>
+hipError_t launchSweep(Kernel kernel, int grid, const LaunchSite &site, const Args &args) {
+  if (site.start && site.stop)
+    hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(kBlockThreads), 0, site.stream, site.start,
+                          site.stop, 0, args);
+  else
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlockThreads), 0, site.stream, args);
+  return hipGetLastError();
+}
+
 template <typename S, int JAC>
 hipError_t launchLiteralCov(const P2PSweepArgs<S> &args, int cov_mode, int grid,
-                            hipStream_t stream) {
+                            const LaunchSite &site) {
   switch (cov_mode) {
     case kCovIdentity:
-      hipLaunchKernelGGL((p2pLinearizeLiteralKernel<S, JAC, kCovIdentity>), dim3(grid),
-                         dim3(kBlockThreads), 0, stream, args);
-      break;
+      return launchSweep(p2pLinearizeLiteralKernel<S, JAC, kCovIdentity>, grid, site, args);
     case kCovSymmetric:
-      hipLaunchKernelGGL((p2pLinearizeLiteralKernel<S, JAC, kCovSymmetric>), dim3(grid),
-                         dim3(kBlockThreads), 0, stream, args);
-      break;
+      return launchSweep(p2pLinearizeLiteralKernel<S, JAC, kCovSymmetric>, grid, site, args);
     default:
-      hipLaunchKernelGGL((p2pLinearizeLiteralKernel<S, JAC, kCovGeneral>), dim3(grid),
-                         dim3(kBlockThreads), 0, stream, args);
-      break;
+      return launchSweep(p2pLinearizeLiteralKernel<S, JAC, kCovGeneral>, grid, site, args);
   }
-  return hipGetLastError();
 }
 }  // namespace
 
 template <typename S>
 hipError_t launchP2PLinearizeLiteral(const P2PSweepArgs<S> &args, int jac_mode, int cov_mode,
-                                     int grid, hipStream_t stream) {
+                                     int grid, const LaunchSite &site) {
   switch (jac_mode) {
     case kJacAnalytic:
-      return launchLiteralCov<S, kJacAnalytic>(args, cov_mode, grid, stream);
+      return launchLiteralCov<S, kJacAnalytic>(args, cov_mode, grid, site);
     case kJacAnalyticTst:
-      return launchLiteralCov<S, kJacAnalyticTst>(args, cov_mode, grid, stream);
+      return launchLiteralCov<S, kJacAnalyticTst>(args, cov_mode, grid, site);
     case kJacNumeric:
-      return launchLiteralCov<S, kJacNumeric>(args, cov_mode, grid, stream);
+      return launchLiteralCov<S, kJacNumeric>(args, cov_mode, grid, site);
     default:
       return hipErrorInvalidValue;
   }
 }
 template hipError_t launchP2PLinearizeLiteral<float>(const P2PSweepArgs<float> &, int, int, int,
-                                                     hipStream_t);
+                                                     const LaunchSite &);
 template hipError_t launchP2PLinearizeLiteral<double>(const P2PSweepArgs<double> &, int, int, int,
-                                                      hipStream_t);
+                                                      const LaunchSite &);
 
 template <typename S>
-hipError_t launchP2PMoments(const P2PSweepArgs<S> &args, int grid, hipStream_t stream) {
-  hipLaunchKernelGGL((p2pMomentsKernel<S>), dim3(grid), dim3(kBlockThreads), 0, stream, args);
-  return hipGetLastError();
+hipError_t launchP2PMoments(const P2PSweepArgs<S> &args, int grid, const LaunchSite &site) {
+  return launchSweep(p2pMomentsKernel<S>, grid, site, args);
 }
-template hipError_t launchP2PMoments<float>(const P2PSweepArgs<float> &, int, hipStream_t);
-template hipError_t launchP2PMoments<double>(const P2PSweepArgs<double> &, int, hipStream_t);
+template hipError_t launchP2PMoments<float>(const P2PSweepArgs<float> &, int, const LaunchSite &);
+template hipError_t launchP2PMoments<double>(const P2PSweepArgs<double> &, int,
+                                             const LaunchSite &);
 
 template <typename S>
-hipError_t launchP2PCost(const P2PSweepArgs<S> &args, int grid, hipStream_t stream) {
-  hipLaunchKernelGGL((p2pCostKernel<S>), dim3(grid), dim3(kBlockThreads), 0, stream, args);
-  return hipGetLastError();
+hipError_t launchP2PCost(const P2PSweepArgs<S> &args, int grid, const LaunchSite &site) {
+  return launchSweep(p2pCostKernel<S>, grid, site, args);
 }
-template hipError_t launchP2PCost<float>(const P2PSweepArgs<float> &, int, hipStream_t);
-template hipError_t launchP2PCost<double>(const P2PSweepArgs<double> &, int, hipStream_t);
+template hipError_t launchP2PCost<float>(const P2PSweepArgs<float> &, int, const LaunchSite &);
+template hipError_t launchP2PCost<double>(const P2PSweepArgs<double> &, int, const LaunchSite &);
 
 hipError_t launchReprojLinearize(const ReprojSweepArgs &args, int cov_mode, int grid,
-                                 hipStream_t stream) {
+                                 const LaunchSite &site) {
   switch (cov_mode) {
     case kCovIdentity:
-      hipLaunchKernelGGL((reprojKernel<kCovIdentity, false>), dim3(grid), dim3(kBlockThreads), 0,
-                         stream, args);
-      break;
+      return launchSweep(reprojKernel<kCovIdentity, false>, grid, site, args);
     case kCovSymmetric:
-      hipLaunchKernelGGL((reprojKernel<kCovSymmetric, false>), dim3(grid), dim3(kBlockThreads), 0,
-                         stream, args);
-      break;
+      return launchSweep(reprojKernel<kCovSymmetric, false>, grid, site, args);
     default:
-      hipLaunchKernelGGL((reprojKernel<kCovGeneral, false>), dim3(grid), dim3(kBlockThreads), 0,
-                         stream, args);
-      break;
+      return launchSweep(reprojKernel<kCovGeneral, false>, grid, site, args);
   }
-  return hipGetLastError();
 }
 
-hipError_t launchReprojCost(const ReprojSweepArgs &args, int grid, hipStream_t stream) {
-  hipLaunchKernelGGL((reprojKernel<kCovIdentity, true>), dim3(grid), dim3(kBlockThreads), 0,
-                     stream, args);
-  return hipGetLastError();
+hipError_t launchReprojCost(const ReprojSweepArgs &args, int grid, const LaunchSite &site) {
+  return launchSweep(reprojKernel<kCovIdentity, true>, grid, site, args);
 }
 
 hipError_t launchFinalizeDense(const double *partials, int grid, int nacc, int n, double *result,
-                               hipStream_t stream) {
+                               const HostPublish &pub, hipStream_t stream) {
   if (n != kNumParams || (nacc != kAccSym && nacc != kAccFull)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(finalizeDenseKernel, dim3(1), dim3(kFinalThreads), 0, stream, partials, grid,
-                     nacc, result);
+                     nacc, result, pub);
   return hipGetLastError();
 }
 
 hipError_t launchFinalizeMoments(const double *partials, int grid, const AffineBasis &basis,
-                                 double *result, hipStream_t stream) {
+                                 double *result, const HostPublish &pub, hipStream_t stream) {
   hipLaunchKernelGGL(finalizeMomentsKernel, dim3(1), dim3(kFinalThreads), 0, stream, partials,
-                     grid, basis, result);
+                     grid, basis, result, pub);
   return hipGetLastError();
 }
 
 hipError_t launchFinalizeCost(const double *partials, int grid, double *result,
-                              hipStream_t stream) {
+                              const HostPublish &pub, hipStream_t stream) {
   hipLaunchKernelGGL(finalizeCostKernel, dim3(1), dim3(kFinalThreads), 0, stream, partials, grid,
-                     result);
+                     result, pub);
+  return hipGetLastError();
+}
+
+hipError_t launchPublish(const double *d_values, int count, const HostPublish &pub,
+                         hipStream_t stream) {
+  if (count < 0 || count > 64) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(publishKernel, dim3(1), dim3(64), 0, stream, d_values, count, pub);
   return hipGetLastError();
 }
 

@@ -242,3 +242,30 @@ def test_full_size_properties(hip_lib):
     whole.set_kernel_variant(2)
     Hm, bm, sm = whole.linearize(x, 2)
     assert rel_err(Hm, Hn) < 1e-6 and rel_err(bm, bn) < 1e-6 and abs(sm - sn) < 1e-12 * sn
+
+
+def test_single_rank_communicator(hip_lib, oracle, cloud_1k):
+    """mopt_cost_comm_init_rank with one rank: the collective path degenerates to the plain sweep."""
+    src, tgt = cloud_1k
+    cost = hip_lib.Point2PointCost(src, tgt)
+    cost.comm_init_rank(hip_lib.capi.comm_unique_id(), 0, 1)
+    check(cost.linearize(ds.X_GENERIC, 0), oracle_ref(oracle, src, tgt, ds.X_GENERIC, 0))
+    want = oracle.p2p_cost(src, tgt, ds.X_GENERIC)
+    assert abs(cost.compute_cost(ds.X_GENERIC) - want) <= REL * want
+
+
+def test_repeated_blocking_calls_are_reproducible(hip_lib, cloud_1k):
+    """The published-result path (mapped host memory + flag) under back-to-back calls with
+    alternating sweeps: every call returns its own result, bit-identical on repetition."""
+    src, tgt = ds.synthetic_pair(200_000, seed=8, noise=0.02)
+    cost = hip_lib.Point2PointCost(src, tgt)
+    xs = [ds.X_GENERIC + 1e-3 * k for k in range(4)]
+    first = [(cost.linearize(x, 0), cost.compute_cost(x), cost.linearize(x, 2)) for x in xs]
+    for _ in range(20):
+        for x, (l0, c0, l2) in zip(xs, first):
+            H, b, s = cost.linearize(x, 0)
+            assert np.array_equal(H, l0[0]) and np.array_equal(b, l0[1]) and s == l0[2]
+            assert cost.compute_cost(x) == c0
+            H, b, s = cost.linearize(x, 2)
+            assert np.array_equal(H, l2[0]) and np.array_equal(b, l2[1]) and s == l2[2]
+            assert abs(s - c0) <= 1e-12 * c0
