@@ -156,6 +156,24 @@ class _CostBase:
         check(load().mopt_cost_linearize(self._h, int(jac_mode), _ptr(x), _ptr(H), _ptr(b), _ptr(s)))
         return H, b, s[0]
 
+    def bound_linearize(self, jac_mode):
+        """Pre-bound form for tight loops (bench): returns (call, x, H, b, s) where x is a reusable
+        input array, H/b/s are reused outputs and call() runs one blocking linearize."""
+        dt = _dtype_of(self.scalar_bytes)
+        x = np.zeros(6, dtype=dt)
+        H = np.zeros((6, 6), dtype=dt, order="F")
+        b = np.zeros(6, dtype=dt)
+        s = np.zeros(1, dtype=dt)
+        fn = load().mopt_cost_linearize
+        args = (self._h, int(jac_mode), _ptr(x), _ptr(H), _ptr(b), _ptr(s))
+
+        def call():
+            rc = fn(*args)
+            if rc != MOPT_OK:
+                check(rc)
+
+        return call, x, H, b, s
+
     def compute_cost(self, x):
         dt = _dtype_of(self.scalar_bytes)
         x = np.ascontiguousarray(x, dtype=dt)
@@ -284,6 +302,24 @@ class Point2PointGroup:
         check(load().mopt_group_linearize(self._h, int(jac_mode), _ptr(x), _ptr(H), _ptr(b),
                                           _ptr(s)))
         return H, b, s[0]
+
+    def bound_linearize(self, jac_mode):
+        """Pre-bound form for tight loops (bench): returns (call, x, H, b, s) where x is a reusable
+        input array, H/b/s are reused outputs and call() runs one blocking linearize."""
+        dt = _dtype_of(self.scalar_bytes)
+        x = np.zeros(6, dtype=dt)
+        H = np.zeros((6, 6), dtype=dt, order="F")
+        b = np.zeros(6, dtype=dt)
+        s = np.zeros(1, dtype=dt)
+        fn = load().mopt_cost_linearize
+        args = (self._h, int(jac_mode), _ptr(x), _ptr(H), _ptr(b), _ptr(s))
+
+        def call():
+            rc = fn(*args)
+            if rc != MOPT_OK:
+                check(rc)
+
+        return call, x, H, b, s
 
     def compute_cost(self, x):
         dt = _dtype_of(self.scalar_bytes)

@@ -2,7 +2,6 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
 
 #include <cstdint>
 
@@ -74,12 +73,9 @@ struct AffineBasis {
   double cov[9];
 };
 
-// Where a sweep kernel is launched.  With `start`/`stop` set, the dispatch itself is timestamped
-// (hipExtLaunchKernelGGL), which is the duration a profiler's kernel trace reports.
+// Where a sweep kernel is launched.
 struct LaunchSite {
   hipStream_t stream = nullptr;
-  hipEvent_t start = nullptr;
-  hipEvent_t stop = nullptr;
 };
 
 // Optional hand-over of a finalize kernel's 43 (or 1) results straight into mapped host memory:

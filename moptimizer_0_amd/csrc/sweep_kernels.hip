@@ -55,6 +55,43 @@ __device__ __forceinline__ void p2pResidual(const S (&T)[12], const S (&p)[3], c
   }
 }
 
+// Walks this workgroup's tiles (blockIdx.x, + gridDim.x, ...) with two register sets used in
+// ping-pong: the six 16-byte loads of the NEXT tile are issued into the idle set before the
+// arithmetic of the current one starts, and nothing is ever copied between the sets.
+//
+// Two details matter to the generated waits (checked in the ISA):
+//  * a copy `cur = nxt` at the loop end forces `s_waitcnt vmcnt(0)` there, leaving one tile in
+//    flight per wave;
+//  * a *conditional* prefetch (`if (next < n) load`) makes the wait at the join conservative
+//    (vmcnt(0) again), because on the not-taken path the needed loads are the youngest.  So the
+//    prefetch is unconditional and, past the end, re-reads this workgroup's last tile (an L2 hit).
+// body(packs, first): packs[plane].v[e] is coordinate `plane` of correspondence first + e.
+template <typename S, typename Body>
+__device__ __forceinline__ void sweepTiles(const S *tiles, int num_tiles, Body &&body) {
+  constexpr int V = TileShape<S>::kVec;
+  constexpr int TP = TileShape<S>::kPoints;
+  const int stride = gridDim.x;
+  const int first_tile = blockIdx.x;
+  if (first_tile >= num_tiles) return;
+  const int mine = (num_tiles - first_tile + stride - 1) / stride;  // tiles of this workgroup
+  const S *lane_base = tiles + threadIdx.x * V;
+  auto tileOf = [&](int i) { return first_tile + (i < mine ? i : mine - 1) * stride; };
+  auto load = [&](Pack<S>(&dst)[6], int tile) {
+    const S *base = lane_base + size_t(tile) * TileShape<S>::kP2PScalars;
+#pragma unroll
+    for (int pl = 0; pl < 6; ++pl) dst[pl] = loadPack<S>(base + pl * TP);
+  };
+  Pack<S> a[6], b[6];
+  load(a, tileOf(0));
+  for (int i = 0; i < mine; i += 2) {
+    load(b, tileOf(i + 1));
+    body(a, (long long)tileOf(i) * TP + threadIdx.x * V);
+    if (i + 1 >= mine) break;
+    load(a, tileOf(i + 2));
+    body(b, (long long)tileOf(i + 1) * TP + threadIdx.x * V);
+  }
+}
+
 __device__ __forceinline__ double waveSum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -213,39 +250,18 @@ __global__ __launch_bounds__(kBlockThreads) void p2pLinearizeLiteralKernel(
     const P2PSweepArgs<S> A) {
   constexpr int NACC = (COV == kCovGeneral) ? kAccFull : kAccSym;
   constexpr int V = TileShape<S>::kVec;
-  constexpr int TP = TileShape<S>::kPoints;
   double acc[NACC];
 #pragma unroll
   for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
 
-  int tile = blockIdx.x;
-  Pack<S> cur[6];
-  if (tile < A.num_tiles) {
-    const S *base = A.tiles + size_t(tile) * TileShape<S>::kP2PScalars + threadIdx.x * V;
-#pragma unroll
-    for (int pl = 0; pl < 6; ++pl) cur[pl] = loadPack<S>(base + pl * TP);
-  }
-  while (tile < A.num_tiles) {
-    const int next = tile + gridDim.x;
-    Pack<S> nxt[6];
-    if (next < A.num_tiles) {
-      const S *base = A.tiles + size_t(next) * TileShape<S>::kP2PScalars + threadIdx.x * V;
-#pragma unroll
-      for (int pl = 0; pl < 6; ++pl) nxt[pl] = loadPack<S>(base + pl * TP);
-    }
-    const long long first = (long long)tile * TP + threadIdx.x * V;
+  sweepTiles<S>(A.tiles, A.num_tiles, [&](const Pack<S>(&cur)[6], long long first) {
 #pragma unroll
     for (int e = 0; e < V; ++e) {
       const S p[3] = {cur[0].v[e], cur[1].v[e], cur[2].v[e]};
       const S q[3] = {cur[3].v[e], cur[4].v[e], cur[5].v[e]};
       p2pPointLiteral<S, JAC, COV>(A, p, q, first + e < A.count, acc);
     }
-    if (next < A.num_tiles) {
-#pragma unroll
-      for (int pl = 0; pl < 6; ++pl) cur[pl] = nxt[pl];
-    }
-    tile = next;
-  }
+  });
   blockReduceStore<NACC>(acc, A.partials + size_t(blockIdx.x) * NACC);
 }
 
@@ -258,27 +274,11 @@ __global__ __launch_bounds__(kBlockThreads) void p2pLinearizeLiteralKernel(
 template <typename S>
 __global__ __launch_bounds__(kBlockThreads) void p2pMomentsKernel(const P2PSweepArgs<S> A) {
   constexpr int V = TileShape<S>::kVec;
-  constexpr int TP = TileShape<S>::kPoints;
   double acc[kAccMoments];
 #pragma unroll
   for (int k = 0; k < kAccMoments; ++k) acc[k] = 0.0;
 
-  int tile = blockIdx.x;
-  Pack<S> cur[6];
-  if (tile < A.num_tiles) {
-    const S *base = A.tiles + size_t(tile) * TileShape<S>::kP2PScalars + threadIdx.x * V;
-#pragma unroll
-    for (int pl = 0; pl < 6; ++pl) cur[pl] = loadPack<S>(base + pl * TP);
-  }
-  while (tile < A.num_tiles) {
-    const int next = tile + gridDim.x;
-    Pack<S> nxt[6];
-    if (next < A.num_tiles) {
-      const S *base = A.tiles + size_t(next) * TileShape<S>::kP2PScalars + threadIdx.x * V;
-#pragma unroll
-      for (int pl = 0; pl < 6; ++pl) nxt[pl] = loadPack<S>(base + pl * TP);
-    }
-    const long long first = (long long)tile * TP + threadIdx.x * V;
+  sweepTiles<S>(A.tiles, A.num_tiles, [&](const Pack<S>(&cur)[6], long long first) {
 #pragma unroll
     for (int e = 0; e < V; ++e) {
       const S p[3] = {cur[0].v[e], cur[1].v[e], cur[2].v[e]};
@@ -311,12 +311,7 @@ __global__ __launch_bounds__(kBlockThreads) void p2pMomentsKernel(const P2PSweep
         for (int c = 0; c < 3; ++c) acc[13 + 3 * k + c] += double(p[k] * wr[c]);
       acc[22] += double(rr);
     }
-    if (next < A.num_tiles) {
-#pragma unroll
-      for (int pl = 0; pl < 6; ++pl) cur[pl] = nxt[pl];
-    }
-    tile = next;
-  }
+  });
   blockReduceStore<kAccMoments>(acc, A.partials + size_t(blockIdx.x) * kAccMoments);
 }
 
@@ -324,14 +319,8 @@ __global__ __launch_bounds__(kBlockThreads) void p2pMomentsKernel(const P2PSweep
 template <typename S>
 __global__ __launch_bounds__(kBlockThreads) void p2pCostKernel(const P2PSweepArgs<S> A) {
   constexpr int V = TileShape<S>::kVec;
-  constexpr int TP = TileShape<S>::kPoints;
   double acc[1] = {0.0};
-  for (int tile = blockIdx.x; tile < A.num_tiles; tile += gridDim.x) {
-    const S *base = A.tiles + size_t(tile) * TileShape<S>::kP2PScalars + threadIdx.x * V;
-    Pack<S> cur[6];
-#pragma unroll
-    for (int pl = 0; pl < 6; ++pl) cur[pl] = loadPack<S>(base + pl * TP);
-    const long long first = (long long)tile * TP + threadIdx.x * V;
+  sweepTiles<S>(A.tiles, A.num_tiles, [&](const Pack<S>(&cur)[6], long long first) {
 #pragma unroll
     for (int e = 0; e < V; ++e) {
       const S p[3] = {cur[0].v[e], cur[1].v[e], cur[2].v[e]};
@@ -341,7 +330,7 @@ __global__ __launch_bounds__(kBlockThreads) void p2pCostKernel(const P2PSweepArg
       const S rr = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
       acc[0] += (first + e < A.count) ? double(rr) : 0.0;
     }
-  }
+  });
   blockReduceStore<1>(acc, A.partials + blockIdx.x);
 }
 
@@ -448,14 +437,25 @@ __global__ void relayoutReprojKernel(const double *__restrict__ pts, const int *
 // per row.  Column totals are then formed in a fixed order (bitwise reproducible).
 constexpr int kFinalThreads = 1024;
 
-// Called by every thread of the (single) finalize workgroup after it has stored its result
-// element (if any) to pub.host_result: orders those stores before the flag at system scope.
-__device__ __forceinline__ void publishFlag(const HostPublish &pub) {
+// Write-through store at system scope (sc0 sc1): straight to mapped host memory, nothing left
+// dirty in L2, so publishing needs no L2 write-back (a system-scope release fence costs two).
+__device__ __forceinline__ void storeSystem(double *p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p),
+                     static_cast<unsigned long long>(__double_as_longlong(v)), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Called by every thread of the (single) finalize workgroup; threads k < count hold result k in
+// `v`.  Payload goes out write-through, every storing wave drains it (s_waitcnt vmcnt(0)), the
+// workgroup meets at a barrier, then one lane stores the sequence word — the payload is complete
+// before the flag is issued (cdna_hip_programming.md Guideline 16, form R1, at system scope).
+__device__ __forceinline__ void publishToHost(const HostPublish &pub, int count, double v) {
   if (pub.host_flag == nullptr) return;
-  __threadfence_system();
+  if (int(threadIdx.x) < count && pub.host_result) storeSystem(pub.host_result + threadIdx.x, v);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0)
-    __hip_atomic_store(pub.host_flag, pub.sequence, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(pub.host_flag, pub.sequence, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __device__ __forceinline__ void columnTotals(const double *partials, int grid, int nacc,
@@ -495,10 +495,10 @@ __global__ __launch_bounds__(kFinalThreads) void finalizeDenseKernel(const doubl
   __shared__ double total[64];
   columnTotals(partials, grid, nacc, scratch, total);
   const int k = threadIdx.x;
+  double v = 0.0;
   if (k < kResultDoubles) {
     const bool full = (nacc == kAccFull);
     const int nh = full ? 36 : 21;
-    double v;
     if (k < 36) {
       const int i = k % 6, j = k / 6;  // column-major H(i, j)
       if (full) {
@@ -511,9 +511,8 @@ __global__ __launch_bounds__(kFinalThreads) void finalizeDenseKernel(const doubl
       v = total[nh + (k - 36)];  // b (6) then sum_sq
     }
     result[k] = v;
-    if (pub.host_result) pub.host_result[k] = v;
   }
-  publishFlag(pub);
+  publishToHost(pub, kResultDoubles, v);
 }
 
 // Moments -> H, b.  With p_0 = 1:  W(a,b) = sum w p_a p_b,  V(a,c) = sum w p_a r_c  and
@@ -564,10 +563,9 @@ __global__ __launch_bounds__(kFinalThreads) void finalizeMomentsKernel(const dou
     terms[t] = g;
   }
   __syncthreads();
+  double v = 0.0;
   if (t < kResultDoubles) {
-    double v;
     if (t < 36) {
-      v = 0.0;
 #pragma unroll
       for (int q = 0; q < 16; ++q) v += terms[t * 16 + q];
     } else if (t < 42) {
@@ -578,9 +576,8 @@ __global__ __launch_bounds__(kFinalThreads) void finalizeMomentsKernel(const dou
       v = total[22];
     }
     result[t] = v;
-    if (pub.host_result) pub.host_result[t] = v;
   }
-  publishFlag(pub);
+  publishToHost(pub, kResultDoubles, v);
 }
 
 __global__ __launch_bounds__(kFinalThreads) void finalizeCostKernel(const double *partials,
@@ -597,14 +594,15 @@ __global__ __launch_bounds__(kFinalThreads) void finalizeCostKernel(const double
 #pragma unroll
     for (int k = 0; k < kFinalThreads / 64; ++k) v += lds[k];
     result[0] = v;
-    if (pub.host_result) pub.host_result[0] = v;
+    lds[0] = v;
   }
-  publishFlag(pub);
+  __syncthreads();
+  publishToHost(pub, 1, lds[0]);
 }
 
 __global__ void publishKernel(const double *values, int count, const HostPublish pub) {
-  if (int(threadIdx.x) < count && pub.host_result) pub.host_result[threadIdx.x] = values[threadIdx.x];
-  publishFlag(pub);
+  const double v = int(threadIdx.x) < count ? values[threadIdx.x] : 0.0;
+  publishToHost(pub, count, v);
 }
 
 }  // namespace
@@ -637,14 +635,9 @@ hipError_t launchRelayoutReproj(const double *points_xyzw, const int32_t *pixels
 }
 
 namespace {
-// Plain launch, or a timestamped one when the site carries events.
 template <typename Kernel, typename Args>
 hipError_t launchSweep(Kernel kernel, int grid, const LaunchSite &site, const Args &args) {
-  if (site.start && site.stop)
-    hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(kBlockThreads), 0, site.stream, site.start,
-                          site.stop, 0, args);
-  else
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlockThreads), 0, site.stream, args);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlockThreads), 0, site.stream, args);
   return hipGetLastError();
 }
 
