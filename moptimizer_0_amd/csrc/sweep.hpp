@@ -76,6 +76,7 @@ struct AffineBasis {
 // Where a sweep kernel is launched.
 struct LaunchSite {
   hipStream_t stream = nullptr;
+  bool streaming = false;  // non-temporal loads: data set larger than the Infinity Cache
 };
 
 // Optional hand-over of a finalize kernel's 43 (or 1) results straight into mapped host memory:

@@ -33,6 +33,18 @@ __device__ __forceinline__ Pack<S> loadPack(const S *p) {
   return *reinterpret_cast<const Pack<S> *>(p);
 }
 
+// Streaming (non-temporal) 16-byte load: the line is not kept in L2 / Infinity Cache.  Used when
+// the data set is larger than the 256 MiB Infinity Cache, where a sweep can never re-use a line
+// of the previous sweep anyway and allocating them only costs fill bandwidth.
+template <typename S>
+__device__ __forceinline__ Pack<S> loadPackStreaming(const S *p) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 raw = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+  Pack<S> out;
+  __builtin_memcpy(&out, &raw, sizeof out);
+  return out;
+}
+
 template <typename S>
 __device__ __forceinline__ S lossWeight(int kind, S param, S s) {
   if (kind == kLossGemanMcClure) {
@@ -66,7 +78,7 @@ __device__ __forceinline__ void p2pResidual(const S (&T)[12], const S (&p)[3], c
 //    (vmcnt(0) again), because on the not-taken path the needed loads are the youngest.  So the
 //    prefetch is unconditional and, past the end, re-reads this workgroup's last tile (an L2 hit).
 // body(packs, first): packs[plane].v[e] is coordinate `plane` of correspondence first + e.
-template <typename S, typename Body>
+template <typename S, bool STREAMING, typename Body>
 __device__ __forceinline__ void sweepTiles(const S *tiles, int num_tiles, Body &&body) {
   constexpr int V = TileShape<S>::kVec;
   constexpr int TP = TileShape<S>::kPoints;
@@ -79,7 +91,8 @@ __device__ __forceinline__ void sweepTiles(const S *tiles, int num_tiles, Body &
   auto load = [&](Pack<S>(&dst)[6], int tile) {
     const S *base = lane_base + size_t(tile) * TileShape<S>::kP2PScalars;
 #pragma unroll
-    for (int pl = 0; pl < 6; ++pl) dst[pl] = loadPack<S>(base + pl * TP);
+    for (int pl = 0; pl < 6; ++pl)
+      dst[pl] = STREAMING ? loadPackStreaming<S>(base + pl * TP) : loadPack<S>(base + pl * TP);
   };
   Pack<S> a[6], b[6];
   load(a, tileOf(0));
@@ -254,7 +267,7 @@ __global__ __launch_bounds__(kBlockThreads) void p2pLinearizeLiteralKernel(
 #pragma unroll
   for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
 
-  sweepTiles<S>(A.tiles, A.num_tiles, [&](const Pack<S>(&cur)[6], long long first) {
+  sweepTiles<S, false>(A.tiles, A.num_tiles, [&](const Pack<S>(&cur)[6], long long first) {
 #pragma unroll
     for (int e = 0; e < V; ++e) {
       const S p[3] = {cur[0].v[e], cur[1].v[e], cur[2].v[e]};
@@ -271,14 +284,14 @@ __global__ __launch_bounds__(kBlockThreads) void p2pLinearizeLiteralKernel(
 //   sum_i w_i J_i^T S J_i  and  sum_i w_i J_i^T S r_i
 // are linear in the 22 moments  sum w, sum w p, sum w p p^T, sum w r, sum w p r^T.  The sweep
 // accumulates those (plus sum r^T r); finalizeMomentsKernel contracts them with the basis.
-template <typename S>
+template <typename S, bool STREAMING>
 __global__ __launch_bounds__(kBlockThreads) void p2pMomentsKernel(const P2PSweepArgs<S> A) {
   constexpr int V = TileShape<S>::kVec;
   double acc[kAccMoments];
 #pragma unroll
   for (int k = 0; k < kAccMoments; ++k) acc[k] = 0.0;
 
-  sweepTiles<S>(A.tiles, A.num_tiles, [&](const Pack<S>(&cur)[6], long long first) {
+  sweepTiles<S, STREAMING>(A.tiles, A.num_tiles, [&](const Pack<S>(&cur)[6], long long first) {
 #pragma unroll
     for (int e = 0; e < V; ++e) {
       const S p[3] = {cur[0].v[e], cur[1].v[e], cur[2].v[e]};
@@ -316,11 +329,11 @@ __global__ __launch_bounds__(kBlockThreads) void p2pMomentsKernel(const P2PSweep
 }
 
 // ---- point-to-point, cost only (linearization.h:36-63) ----------------------------------------
-template <typename S>
+template <typename S, bool STREAMING>
 __global__ __launch_bounds__(kBlockThreads) void p2pCostKernel(const P2PSweepArgs<S> A) {
   constexpr int V = TileShape<S>::kVec;
   double acc[1] = {0.0};
-  sweepTiles<S>(A.tiles, A.num_tiles, [&](const Pack<S>(&cur)[6], long long first) {
+  sweepTiles<S, STREAMING>(A.tiles, A.num_tiles, [&](const Pack<S>(&cur)[6], long long first) {
 #pragma unroll
     for (int e = 0; e < V; ++e) {
       const S p[3] = {cur[0].v[e], cur[1].v[e], cur[2].v[e]};
@@ -676,7 +689,8 @@ template hipError_t launchP2PLinearizeLiteral<double>(const P2PSweepArgs<double>
 
 template <typename S>
 hipError_t launchP2PMoments(const P2PSweepArgs<S> &args, int grid, const LaunchSite &site) {
-  return launchSweep(p2pMomentsKernel<S>, grid, site, args);
+  return site.streaming ? launchSweep(p2pMomentsKernel<S, true>, grid, site, args)
+                        : launchSweep(p2pMomentsKernel<S, false>, grid, site, args);
 }
 template hipError_t launchP2PMoments<float>(const P2PSweepArgs<float> &, int, const LaunchSite &);
 template hipError_t launchP2PMoments<double>(const P2PSweepArgs<double> &, int,
@@ -684,7 +698,8 @@ template hipError_t launchP2PMoments<double>(const P2PSweepArgs<double> &, int,
 
 template <typename S>
 hipError_t launchP2PCost(const P2PSweepArgs<S> &args, int grid, const LaunchSite &site) {
-  return launchSweep(p2pCostKernel<S>, grid, site, args);
+  return site.streaming ? launchSweep(p2pCostKernel<S, true>, grid, site, args)
+                        : launchSweep(p2pCostKernel<S, false>, grid, site, args);
 }
 template hipError_t launchP2PCost<float>(const P2PSweepArgs<float> &, int, const LaunchSite &);
 template hipError_t launchP2PCost<double>(const P2PSweepArgs<double> &, int, const LaunchSite &);
