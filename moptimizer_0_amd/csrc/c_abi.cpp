@@ -268,7 +268,7 @@ int p2pLinearizeAsync(mopt_cost *c, int jac_mode, const S *x, double *d_result, 
   if (moments) {
     mopt::AffineBasis basis;
     fillBasis<S>(c, jac_mode, args, basis);
-    const int grid = gridFor(c, envInt("MOPT_BLOCKS_PER_CU", 2));
+    const int grid = gridFor(c, envInt("MOPT_BLOCKS_PER_CU", 1));
     SweepTimer timer(c, s);
     MOPT_HIP_TRY(mopt::launchP2PMoments<S>(args, grid, timer.site));
     timer.stop();
@@ -290,7 +290,7 @@ int p2pCostAsync(mopt_cost *c, const S *x, double *d_sum, hipStream_t s,
                  const mopt::HostPublish &pub) {
   mopt::P2PSweepArgs<S> args;
   fillP2PArgs<S>(c, x, false, args);
-  const int grid = gridFor(c, envInt("MOPT_BLOCKS_PER_CU", 2));
+  const int grid = gridFor(c, envInt("MOPT_BLOCKS_PER_CU", 1));
   SweepTimer timer(c, s);
   MOPT_HIP_TRY(mopt::launchP2PCost<S>(args, grid, timer.site));
   timer.stop();

@@ -21,13 +21,15 @@ for n in (1000, 1_000_000, 10_000_000):
             f = (lambda: cost.linearize(x, 0)) if what == "linearize" else (lambda: cost.compute_cost(x))
             for _ in range(20):
                 f()
-            t0 = time.perf_counter()
             iters = 300
+            ts = []
             for _ in range(iters):
+                t0 = time.perf_counter()
                 f()
-            dt = (time.perf_counter() - t0) / iters
+                ts.append(time.perf_counter() - t0)
+            dt = float(np.median(ts))
             ms, cnt = cost.profile() if prof else (0.0, 1)
-            print("n=%9d profiling=%-5s %-9s wall %8.2f us/call   kernel %8.2f us" %
+            print("n=%9d profiling=%-5s %-9s median wall %8.2f us/call   kernel %8.2f us" %
                   (n, prof, what, dt * 1e6, ms / max(cnt, 1) * 1e3), flush=True)
             if prof:
                 cost.set_profiling(True)
