@@ -41,6 +41,12 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--n", type=int, default=10_000_000, help="correspondences PER GPU")
+    ap.add_argument("--total-n", type=int, default=0,
+                    help="strong scaling: shard this many correspondences over the GPUs "
+                         "(BASELINE config 4: 10000000 over 8); overrides --n")
+    ap.add_argument("--workload", choices=["point2point", "camera"], default="point2point",
+                    help="camera = BASELINE config 5: reprojection cost, 100k elements as two costs "
+                         "(40k + 60k) with Geman-McClure, numeric Jacobian, 1 GPU")
     ap.add_argument("--mode", choices=["analytic", "analytic_tst", "numeric"], default="analytic")
     ap.add_argument("--variant", choices=["auto", "literal", "moments"], default="auto")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
@@ -67,6 +73,20 @@ def make_shard_on_gpu(torch, n, rank, dtype):
     return src.to(dtype).contiguous(), tgt.to(dtype).contiguous()
 
 
+def prewarm_runtime(mo, device=0, calls=450):
+    """The HIP runtime stalls once for ~40 ms around this process's ~690th kernel launch (measured:
+    always call #345 of a two-kernel blocking sweep, never again in 3000 calls) — a one-time pool
+    growth inside the runtime, independent of this library.  Get past it on a throw-away 1 k-point
+    cost during (untimed) setup so that it cannot land in the timed steps."""
+    from tests import datasets as ds
+    src, tgt = ds.synthetic_pair(1000, seed=3)
+    dummy = mo.Point2PointCost(src, tgt, device=device)
+    x = ds.X_GENERIC
+    for _ in range(calls):
+        dummy.linearize(x, mo.JAC_ANALYTIC)
+    dummy.close()
+
+
 def cpu_baseline(src_host, tgt_host, x, jac_mode, target_seconds):
     """Single-threaded restatement of the reference's linearize (the reference loop is
     single-threaded: linearization.h:97,142) on a bounded prefix of the same workload."""
@@ -91,8 +111,59 @@ def cpu_baseline(src_host, tgt_host, x, jac_mode, target_seconds):
     }
 
 
+def camera_main(args):
+    """BASELINE config 5 (latency-dominated: 4 MB of input): one step = the multi-objective
+    linearization of levenberg_marquadt_dyn.cpp:48-60 — linearize both costs, add H, b, cost on the
+    host."""
+    import moptimizer_0_amd as mo
+    from tests import datasets as ds
+    prewarm_runtime(mo)
+    n, split = 100_000, 40_000
+    pts, pix = ds.synthetic_camera(n, seed=17)
+    costs = [mo.ReprojectionCost(pts[:split], pix[:split]), mo.ReprojectionCost(pts[split:], pix[split:])]
+    for c in costs:
+        c.set_loss(mo.LOSS_GEMAN_MCCLURE, 100.0)
+        c.set_profiling(True)
+    x = np.zeros(6)
+
+    def step(k):
+        xs = x + 1e-4 * (k % 16)
+        H = np.zeros((6, 6)); b = np.zeros(6); y = 0.0
+        for c in costs:
+            Hc, bc, yc = c.linearize(xs, mo.JAC_NUMERIC)
+            H += Hc; b += bc; y += yc
+        return H, b, y
+
+    for k in range(args.warmup):
+        step(k)
+    for c in costs:
+        c.set_profiling(True)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        H, b, y = step(k)
+    elapsed = time.perf_counter() - t0
+    prof = [c.profile() for c in costs]
+    kernel_ms = sum(p[0] for p in prof) / max(prof[0][1], 1)  # both costs' sweeps per step
+    achieved = n * 40 / (kernel_ms * 1e-3) / 1e9
+    print(json.dumps({
+        "metric": "point-correspondences/sec per LM linearization sweep; % HBM peak",
+        "value": n * args.steps / elapsed, "unit": "residual-blocks/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "camera-calibration reprojection cost (config 5): 100000 elements as "
+                               "two costs (40k + 60k), Geman-McClure(100), forward differences, "
+                               "both linearized and summed per step"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kernel_ms,
+                     "note": "4 MB of input: launch-latency-bound, not bandwidth-bound"},
+        "check": {"sum_sq": float(y)}, "cpu_baseline": None}), flush=True)
+
+
 def main():
     args = parse_args()
+    if args.workload == "camera":
+        return camera_main(args)
     import torch
     import torch.distributed as dist
 
@@ -111,12 +182,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    if args.total_n:
+        lo, hi = args.total_n * rank // world, args.total_n * (rank + 1) // world
+        args.n = hi - lo
     np_dtype = np.float64 if args.dtype == "f64" else np.float32
     t_dtype = torch.float64 if args.dtype == "f64" else torch.float32
     scalar_bytes = np.dtype(np_dtype).itemsize
     jac_mode = {"analytic": mo.JAC_ANALYTIC, "analytic_tst": mo.JAC_ANALYTIC_TST_LAYOUT,
                 "numeric": mo.JAC_NUMERIC}[args.mode]
 
+    prewarm_runtime(mo, device=local_rank)
     src, tgt = make_shard_on_gpu(torch, args.n, rank, t_dtype)
     torch.cuda.synchronize()
     cost = mo.Point2PointCost(src.data_ptr(), tgt.data_ptr(), device=local_rank, dtype=np_dtype,
@@ -184,7 +259,7 @@ def main():
         elapsed = float(tmax.item())
 
     if rank == 0:
-        total = args.n * world
+        total = args.total_n if args.total_n else args.n * world
         ms_per_step = elapsed / args.steps * 1e3
         value = total * args.steps / elapsed
         kernel_ms = sweep_ms / max(launches, 1)
@@ -205,7 +280,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.total_n else "weak",
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",

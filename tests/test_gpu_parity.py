@@ -269,3 +269,66 @@ def test_repeated_blocking_calls_are_reproducible(hip_lib, cloud_1k):
             H, b, s = cost.linearize(x, 2)
             assert np.array_equal(H, l2[0]) and np.array_equal(b, l2[1]) and s == l2[2]
             assert abs(s - c0) <= 1e-12 * c0
+
+
+def _lm_minimize(costs, x0, max_iter=15, lm_iter=3):
+    """levenberg_marquadt_dyn.cpp:34-119 over a list of (linearize, compute_cost) pairs."""
+    x = np.array(x0, dtype=np.float64)
+    lam = -1.0
+    eps = np.finfo(np.float64).eps
+    for it in range(max_iter):
+        H = np.zeros((6, 6))
+        b = np.zeros(6)
+        y0 = 0.0
+        for lin, _ in costs:
+            Hc, bc, yc = lin(x)
+            H += Hc
+            b += bc
+            y0 += yc
+        if abs(y0) < 8 * eps:
+            return x, 0, it
+        D = np.diag(np.diag(H))
+        if lam < 0:
+            lam = 1e-9 * np.abs(np.diag(H)).max()
+        nu = 2.0
+        for k in range(lm_iter):
+            delta = np.linalg.solve(H + lam * D, -b)
+            xi = x + delta
+            yi = sum(cc(xi) for _, cc in costs)
+            rho = (y0 - yi) / delta.dot(lam * delta - b)
+            if rho < 0:
+                if np.abs(delta).max() < np.sqrt(eps):
+                    return x, (0 if abs(yi) < 8 * eps else 2), it
+                lam *= nu
+                nu *= 2
+                continue
+            x = xi
+            lam *= max(1.0 / 3.0, 1 - (2 * rho - 1) ** 3)
+            break
+    return x, 1, max_iter
+
+
+def test_config5_camera_100k_two_costs_robust_loss(hip_lib, oracle):
+    """BASELINE config 5: bundle-adjustment-style reprojection cost, 100 k residual blocks split
+    into two costs (40 k + 60 k, as tst/multiple_objectives.cpp:110-117 splits its data), each with
+    Geman-McClure (tst/loss_function.cpp:31-32).  Per-cost H, b, cost against the oracle at the
+    start point, then the LM solve against the oracle's LM on the same problem."""
+    n, split = 100_000, 40_000
+    pts, pix = ds.synthetic_camera(n, seed=17)
+    parts = [(pts[:split], pix[:split]), (pts[split:], pix[split:])]
+    gpu = [hip_lib.ReprojectionCost(p, q) for p, q in parts]
+    for c in gpu:
+        c.set_loss(1, 100.0)
+    x0 = np.zeros(6)
+    for c, (p, q) in zip(gpu, parts):
+        check(c.linearize(x0, 2), oracle.camera_linearize(p, q, x0, loss_kind=1, loss_param=100.0))
+        want = oracle.camera_cost(p, q, x0)
+        assert abs(c.compute_cost(x0) - want) <= REL * want
+    costs = [((lambda x, c=c: c.linearize(x, 2)), (lambda x, c=c: c.compute_cost(x))) for c in gpu]
+    x_gpu, status, iters = _lm_minimize(costs, x0, max_iter=15)
+    x_cpu, st_cpu, it_cpu = oracle.camera_minimize(pts, pix, [split, n - split], x0, max_iter=15,
+                                                   loss_kind=1, loss_param=100.0)
+    assert np.abs(x_gpu - x_cpu).max() < 1e-6, (x_gpu, x_cpu)
+    # pixels were generated from x_true and rounded: the solve must land next to it
+    x_true = np.array([-0.01, 0.02, -0.058, 0.018, -0.0013, 0.027])
+    assert np.abs(x_gpu - x_true).max() < 5e-3, x_gpu
