@@ -130,6 +130,18 @@ MOPT_API int mopt_cost_linearize(mopt_cost *cost, int jacobian_mode, const void 
                                  void *b, void *sum_sq);
 MOPT_API int mopt_cost_compute(mopt_cost *cost, const void *x, void *sum_sq);
 
+/* Speculation (on by default).  The LM loop evaluates computeCost(xi) for a trial point and, when the
+ * step is accepted, linearize(xi) at the very same point in the next outer iteration
+ * (src/levenberg_marquadt_dyn.cpp:86,112 then :55).  The linearization sweep reads the same bytes as
+ * the cost sweep and also yields sum_sq, so with speculation mopt_cost_compute runs the
+ * linearization sweep (in the mode of the most recent mopt_cost_linearize) and keeps H | b | sum_sq;
+ * a following mopt_cost_linearize with bit-identical x, mode, loss and covariance returns them
+ * without touching HBM — one sweep per accepted LM iteration instead of two.  Values equal those of
+ * the un-speculated calls up to the summation order of sum_sq (1e-15 relative). */
+MOPT_API int mopt_cost_set_speculation(mopt_cost *cost, int enabled);
+/* sweeps launched and calls answered from the kept result since creation */
+MOPT_API int mopt_cost_stats(const mopt_cost *cost, int64_t *sweeps, int64_t *cache_hits);
+
 /* ---- asynchronous sweeps (shard partials stay in HBM) -------------------------------------- */
 
 /* Enqueue on `hip_stream` (a hipStream_t; NULL = the cost's own stream) and return at once.

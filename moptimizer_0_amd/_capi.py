@@ -66,6 +66,9 @@ def load():
                                     ctypes.c_void_p],
         "mopt_cost_stream": [ctypes.c_void_p, c_void_pp],
         "mopt_cost_synchronize": [ctypes.c_void_p],
+        "mopt_cost_set_speculation": [ctypes.c_void_p, ctypes.c_int],
+        "mopt_cost_stats": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64),
+                            ctypes.POINTER(ctypes.c_int64)],
         "mopt_comm_unique_id": [ctypes.c_void_p, ctypes.c_int],
         "mopt_cost_comm_init_rank": [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int],
         "mopt_cost_set_profiling": [ctypes.c_void_p, ctypes.c_int],
@@ -145,6 +148,14 @@ class _CostBase:
 
     def set_kernel_variant(self, variant):
         check(load().mopt_cost_set_kernel_variant(self._h, int(variant)))
+
+    def set_speculation(self, enabled):
+        check(load().mopt_cost_set_speculation(self._h, 1 if enabled else 0))
+
+    def stats(self):
+        sweeps, hits = ctypes.c_int64(0), ctypes.c_int64(0)
+        check(load().mopt_cost_stats(self._h, ctypes.byref(sweeps), ctypes.byref(hits)))
+        return sweeps.value, hits.value
 
     # -- CostFunctionBase::linearize / computeCost ------------------------------------------
     def linearize(self, x, jac_mode):

@@ -45,6 +45,7 @@ int fail(int code, const std::string &msg) {
   } while (0)
 
 enum ModelKind { kModelPoint2Point = 1, kModelReprojection = 2 };
+constexpr int kMaxParamBytes = 6 * 8;
 
 int envInt(const char *name, int fallback) {
   const char *v = std::getenv(name);
@@ -86,6 +87,23 @@ struct mopt_cost {
 
   double camera[12];
   double frame[16];
+
+  // LM calls computeCost(xi) and, when the step is accepted, linearize(xi) right after
+  // (levenberg_marquadt_dyn.cpp:86,112 then :55): with speculation on, computeCost runs the
+  // linearization sweep (same HBM traffic as the cost sweep) and keeps its H | b | sum_sq, so the
+  // following linearize at the same x costs no sweep at all.
+  bool speculate = true;
+  int last_jac_mode = -1;
+  unsigned long long state_version = 0;  // bumped when loss / covariance / variant change
+  struct {
+    bool valid = false;
+    int mode = -1;
+    unsigned long long version = 0;
+    unsigned char x[kMaxParamBytes] = {0};
+    double result[64] = {0};
+  } cache;
+  long long stat_sweeps = 0;
+  long long stat_cache_hits = 0;
 
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
@@ -431,6 +449,7 @@ int blockingSweep(mopt_cost *c, bool cost_only, int jac_mode, const void *x) {
   const int offset = cost_only ? 42 : 0;
   const int count = cost_only ? 1 : kResultDoubles;
   mopt::HostPublish pub = nextPublish(c, offset);
+  c->stat_sweeps += 1;
   int rc;
   if (c->comm && c->comm_size > 1) {
     rc = cost_only ? costAsyncImpl(c, x, c->d_result + 42, c->stream)
@@ -640,6 +659,8 @@ int mopt_cost_destroy(mopt_cost *cost) {
 int mopt_cost_set_covariance(mopt_cost *c, const void *cov_colmajor) {
   if (!c) return fail(MOPT_ERR_INVALID_ARGUMENT, "cost is NULL");
   const int m = c->n_out;
+  double previous[9];
+  std::memcpy(previous, c->cov, sizeof previous);
   for (int k = 0; k < 9; ++k) c->cov[k] = 0.0;
   for (int a = 0; a < 3; ++a) c->cov[a * 3 + a] = 1.0;
   if (cov_colmajor) {
@@ -660,6 +681,7 @@ int mopt_cost_set_covariance(mopt_cost *c, const void *cov_colmajor) {
     }
   c->cov_mode = identity ? mopt::kCovIdentity
                          : (symmetric ? mopt::kCovSymmetric : mopt::kCovGeneral);
+  if (std::memcmp(previous, c->cov, sizeof previous) != 0) c->state_version += 1;
   return MOPT_OK;
 }
 
@@ -667,6 +689,7 @@ int mopt_cost_set_loss(mopt_cost *c, int loss_kind, double parameter) {
   if (!c) return fail(MOPT_ERR_INVALID_ARGUMENT, "cost is NULL");
   if (loss_kind != MOPT_LOSS_NONE && loss_kind != MOPT_LOSS_GEMAN_MCCLURE)
     return fail(MOPT_ERR_INVALID_ARGUMENT, "unknown loss_kind");
+  if (c->loss_kind != loss_kind || c->loss_param != parameter) c->state_version += 1;
   c->loss_kind = loss_kind;
   c->loss_param = parameter;
   return MOPT_OK;
@@ -678,6 +701,7 @@ int mopt_cost_set_kernel_variant(mopt_cost *c, int variant) {
     return fail(MOPT_ERR_INVALID_ARGUMENT, "unknown kernel variant");
   if (variant == MOPT_KERNEL_MOMENTS && c->model != kModelPoint2Point)
     return fail(MOPT_ERR_UNSUPPORTED, "the reprojection Jacobian is not affine in the point");
+  if (c->variant != variant) c->state_version += 1;
   c->variant = variant;
   return MOPT_OK;
 }
@@ -708,22 +732,73 @@ int mopt_cost_compute_async(mopt_cost *c, const void *x, double *d_sum_sq, void 
   return costAsyncImpl(c, x, d_sum_sq, s);
 }
 
+namespace {
+bool cacheMatches(const mopt_cost *c, const void *x, int mode_or_any) {
+  return c->cache.valid && c->cache.version == c->state_version &&
+         (mode_or_any < 0 || c->cache.mode == mode_or_any) &&
+         std::memcmp(c->cache.x, x, size_t(kNumParams) * c->scalar_bytes) == 0;
+}
+void cacheStore(mopt_cost *c, const void *x, int mode) {
+  c->cache.valid = true;
+  c->cache.mode = mode;
+  c->cache.version = c->state_version;
+  std::memcpy(c->cache.x, x, size_t(kNumParams) * c->scalar_bytes);
+  std::memcpy(c->cache.result, c->h_result, kResultDoubles * sizeof(double));
+}
+}  // namespace
+
 int mopt_cost_linearize(mopt_cost *c, int jacobian_mode, const void *x, void *hessian, void *b,
                         void *sum_sq) {
   if (!c || !x) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (jacobian_mode < MOPT_JAC_ANALYTIC || jacobian_mode > MOPT_JAC_NUMERIC)
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "unknown jacobian_mode");
+  if (c->speculate && cacheMatches(c, x, jacobian_mode)) {
+    c->stat_cache_hits += 1;
+    c->last_jac_mode = jacobian_mode;
+    storeResult(c, c->cache.result, hessian, b, sum_sq);
+    return MOPT_OK;
+  }
   MOPT_HIP_TRY(hipSetDevice(c->device));
   const int rc = blockingSweep(c, false, jacobian_mode, x);
   if (rc != MOPT_OK) return rc;
+  c->last_jac_mode = jacobian_mode;
+  if (c->speculate) cacheStore(c, x, jacobian_mode);
   storeResult(c, c->h_result, hessian, b, sum_sq);
   return MOPT_OK;
 }
 
 int mopt_cost_compute(mopt_cost *c, const void *x, void *sum_sq) {
   if (!c || !x || !sum_sq) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (c->speculate && cacheMatches(c, x, -1)) {
+    c->stat_cache_hits += 1;
+    storeResult(c, c->cache.result, nullptr, nullptr, sum_sq);
+    return MOPT_OK;
+  }
   MOPT_HIP_TRY(hipSetDevice(c->device));
-  const int rc = blockingSweep(c, true, 0, x);
-  if (rc != MOPT_OK) return rc;
+  if (c->speculate && c->last_jac_mode >= 0) {
+    // the linearization sweep also yields sum r^T r; keep all of it for the linearize that follows
+    const int rc = blockingSweep(c, false, c->last_jac_mode, x);
+    if (rc != MOPT_OK) return rc;
+    cacheStore(c, x, c->last_jac_mode);
+  } else {
+    const int rc = blockingSweep(c, true, 0, x);
+    if (rc != MOPT_OK) return rc;
+  }
   storeResult(c, c->h_result, nullptr, nullptr, sum_sq);
+  return MOPT_OK;
+}
+
+int mopt_cost_set_speculation(mopt_cost *c, int enabled) {
+  if (!c) return fail(MOPT_ERR_INVALID_ARGUMENT, "cost is NULL");
+  c->speculate = enabled != 0;
+  c->cache.valid = false;
+  return MOPT_OK;
+}
+
+int mopt_cost_stats(const mopt_cost *c, int64_t *sweeps, int64_t *cache_hits) {
+  if (!c) return fail(MOPT_ERR_INVALID_ARGUMENT, "cost is NULL");
+  if (sweeps) *sweeps = c->stat_sweeps;
+  if (cache_hits) *cache_hits = c->stat_cache_hits;
   return MOPT_OK;
 }
 

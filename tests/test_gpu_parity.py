@@ -332,3 +332,42 @@ def test_config5_camera_100k_two_costs_robust_loss(hip_lib, oracle):
     # pixels were generated from x_true and rounded: the solve must land next to it
     x_true = np.array([-0.01, 0.02, -0.058, 0.018, -0.0013, 0.027])
     assert np.abs(x_gpu - x_true).max() < 5e-3, x_gpu
+
+
+def test_speculative_linearization_halves_lm_sweeps(hip_lib, facade):
+    """computeCost(xi) keeps the linearization at xi; an accepted LM step then needs no new sweep.
+    Same pose with and without, about half the sweeps."""
+    src, tgt = facade
+    out = {}
+    for spec in (False, True):
+        cost = hip_lib.Point2PointCost(src, tgt)
+        cost.set_speculation(spec)
+        pair = [((lambda x: cost.linearize(x, 2)), (lambda x: cost.compute_cost(x)))]
+        x, status, iters = _lm_minimize(pair, np.zeros(6), max_iter=50)
+        out[spec] = (x, iters, cost.stats())
+    assert np.abs(out[True][0] - out[False][0]).max() < 1e-9
+    assert np.abs(out[True][0] - ds.FIXTURE_X).max() < 1e-6
+    assert out[True][1] == out[False][1]
+    sweeps_off, hits_off = out[False][2]
+    sweeps_on, hits_on = out[True][2]
+    assert hits_off == 0 and hits_on >= out[True][1] - 2
+    assert sweeps_on <= 0.7 * sweeps_off, (sweeps_on, sweeps_off)
+
+
+def test_speculation_respects_state_changes(hip_lib, oracle, cloud_1k):
+    """A kept linearization must not survive a change of loss, covariance, mode or x."""
+    src, tgt = cloud_1k
+    cost = hip_lib.Point2PointCost(src, tgt)
+    x = ds.X_GENERIC
+    cost.linearize(x, 0)
+    cost.compute_cost(x)                      # served from the kept result
+    cost.set_loss(1, 0.5)
+    check(cost.linearize(x, 0), oracle_ref(oracle, src, tgt, x, 0, loss_kind=1, loss_param=0.5))
+    cov = np.diag([0.5, 2.0, 3.0])
+    cost.set_covariance(cov)
+    check(cost.linearize(x, 0), oracle_ref(oracle, src, tgt, x, 0, cov=cov, loss_kind=1, loss_param=0.5))
+    check(cost.linearize(x, 1), oracle_ref(oracle, src, tgt, x, 1, cov=cov, loss_kind=1, loss_param=0.5))
+    x2 = x + 1e-9
+    cost.compute_cost(x2)
+    check(cost.linearize(x2, 1), oracle_ref(oracle, src, tgt, x2, 1, cov=cov, loss_kind=1, loss_param=0.5))
+    check(cost.linearize(x, 1), oracle_ref(oracle, src, tgt, x, 1, cov=cov, loss_kind=1, loss_param=0.5))
