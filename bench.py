@@ -101,7 +101,7 @@ def cpu_baseline(src_host, tgt_host, x, jac_mode, target_seconds):
         oracle.p2p_linearize(src_host, tgt_host, x, cost_class=cost_class, layout=layout)
         sweeps += 1
         dt = time.perf_counter() - t0
-    return {
+    out = {
         "value": sample * sweeps / dt,
         "unit": "correspondences/s",
         "cores": 1,
@@ -109,6 +109,14 @@ def cpu_baseline(src_host, tgt_host, x, jac_mode, target_seconds):
         "sample": "%d sweeps over the first %d correspondences of rank 0's shard, %.1f s of CPU "
                   "work (single thread, as the reference's linearize loop)" % (sweeps, sample, dt),
     }
+    # for orientation only: the same sweep split over every host core (the reference parallelises
+    # only its cost-only sweep, linearization.h:52)
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    oracle.p2p_linearize(src_host, tgt_host, x, cost_class=cost_class, layout=layout, threads=cores)
+    dt = time.perf_counter() - t0
+    out["all_cores"] = {"value": sample / dt, "cores": cores}
+    return out
 
 
 def camera_main(args):
@@ -214,14 +222,19 @@ def main():
     if world > 1:
         collective = args.collective
         if collective == "rccl":
+            ok = 1
             try:
                 ids = [mo.capi.comm_unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(ids, src=0)
                 cost.comm_init_rank(ids[0], rank, world)
-            except Exception as e:  # fall back to the torch.distributed collective (still RCCL)
-                if rank == 0:
-                    print("library communicator unavailable (%s); using torch.distributed" % e,
-                          file=sys.stderr)
+            except Exception as e:
+                ok = 0
+                print("rank %d: library communicator unavailable (%s)" % (rank, e), file=sys.stderr)
+            # every rank must take the same path: fall back to the torch.distributed collective
+            # (still RCCL) if any rank failed
+            agreed = torch.tensor([ok], device="cuda", dtype=torch.int32)
+            dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+            if int(agreed.item()) == 0:
                 collective = "torch"
         if collective == "torch":
             sweep = gpu_point2point_sweep(cost)
