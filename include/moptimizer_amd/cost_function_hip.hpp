@@ -201,5 +201,33 @@ using CostFunctionAnalyticalTstLayoutHip = CostFunctionHip<Scalar, MOPT_JAC_ANAL
 template <class Scalar = double>
 using CostFunctionNumericalHip = CostFunctionHip<Scalar, MOPT_JAC_NUMERIC>;
 
+// The reference's four class names, one namespace down: switching a cost to the GPU is
+// `moptimizer::CostFunctionNumerical<double, 6, 3>` -> `moptimizer::hip::CostFunctionNumerical<...>`
+// with the same constructor arguments (plus an optional device index).
+//   cost_function_analytical_dyn.h:17-18 / cost_function_numerical_dyn.h:19-20: (model, n, m, N)
+//   cost_function_analytical.h:21-25 / cost_function_numerical.h:24-28:          (model, N)
+template <class Scalar = double>
+using CostFunctionAnalyticalDynamic = CostFunctionHip<Scalar, MOPT_JAC_ANALYTIC>;
+template <class Scalar = double>
+using CostFunctionNumericalDynamic = CostFunctionHip<Scalar, MOPT_JAC_NUMERIC>;
+
+template <class Scalar = double, int model_parameter_dim = 6, int model_output_dim = 3>
+class CostFunctionAnalytical : public CostFunctionHip<Scalar, MOPT_JAC_ANALYTIC> {
+ public:
+  using typename CostFunctionHip<Scalar, MOPT_JAC_ANALYTIC>::ModelPtr;
+  CostFunctionAnalytical(ModelPtr model, int num_residuals, int device = 0)
+      : CostFunctionHip<Scalar, MOPT_JAC_ANALYTIC>(model, model_parameter_dim, model_output_dim,
+                                                   num_residuals, device) {}
+};
+
+template <class Scalar = double, int model_parameter_dim = 6, int model_output_dim = 3>
+class CostFunctionNumerical : public CostFunctionHip<Scalar, MOPT_JAC_NUMERIC> {
+ public:
+  using typename CostFunctionHip<Scalar, MOPT_JAC_NUMERIC>::ModelPtr;
+  CostFunctionNumerical(ModelPtr model, int num_residuals, int device = 0)
+      : CostFunctionHip<Scalar, MOPT_JAC_NUMERIC>(model, model_parameter_dim, model_output_dim,
+                                                  num_residuals, device) {}
+};
+
 }  // namespace hip
 }  // namespace moptimizer

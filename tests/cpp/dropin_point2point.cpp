@@ -172,6 +172,20 @@ int main(int argc, char **argv) {
       expectTrue(e < 5e-5, "CameraCalibration.GoodWeather with the HIP cost", e, 5e-5);
     }
 
+    // ---- the compile-time-dimension twins (tst/point2point.cpp:149,151,211) ------------------
+    {
+      mh::CostFunctionAnalytical<Scalar, 6, 3> an_s(gpu_model, n);
+      mh::CostFunctionNumerical<Scalar, 6, 3> nu_s(gpu_model, n);
+      mh::CostFunctionAnalyticalDynamic<Scalar> an_d(gpu_model, 6, 3, n);
+      mh::CostFunctionNumericalDynamic<Scalar> nu_d(gpu_model, 6, 3, n);
+      Scalar Ha[36], Hb[36], ba[6], bb[6];
+      const Scalar sa = an_s.linearize(x0, Ha, ba), sb = an_d.linearize(x0, Hb, bb);
+      expectTrue(sa == sb && relErr(Ha, Hb, 36) == 0.0, "static == dynamic analytic (HIP)", sa, sb);
+      const Scalar sc = nu_s.linearize(x0, Ha, ba), sd = nu_d.linearize(x0, Hb, bb);
+      expectTrue(sc == sd && relErr(Ha, Hb, 36) == 0.0, "static == dynamic numeric (HIP)", sc, sd);
+      expectTrue(std::fabs(sa - sc) <= 1e-7 * sa, "sum analytic == sum numeric (1e-7 rel)", sa, sc);
+    }
+
     // ---- a host model is refused, not silently run on the CPU ----------------------------
     {
       bool threw = false;
