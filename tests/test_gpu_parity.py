@@ -371,3 +371,58 @@ def test_speculation_respects_state_changes(hip_lib, oracle, cloud_1k):
     cost.compute_cost(x2)
     check(cost.linearize(x2, 1), oracle_ref(oracle, src, tgt, x2, 1, cov=cov, loss_kind=1, loss_param=0.5))
     check(cost.linearize(x, 1), oracle_ref(oracle, src, tgt, x, 1, cov=cov, loss_kind=1, loss_param=0.5))
+
+
+def test_hundred_million_correspondences(hip_lib):
+    """Maximum-size case: 1e8 correspondences (4.8 GB of input, byte offsets beyond 2^32, 195 313
+    tiles) generated on the device.  No CPU sweep at this size; checked through additivity over
+    ten 1e7 chunks, the exact translation block H_tt = N I, and analytic == moments == literal."""
+    import torch
+    n, chunk = 100_000_000, 10_000_000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    src = torch.rand((n, 3), generator=g, device="cuda", dtype=torch.float64) * 10.0
+    R = torch.tensor(ds.fixture_rotation(), device="cuda", dtype=torch.float64)
+    t = torch.tensor(ds.FIXTURE_T, device="cuda", dtype=torch.float64)
+    tgt = (src @ R.T + t).contiguous()
+    torch.cuda.synchronize()
+    x = ds.X_GENERIC
+    whole = hip_lib.Point2PointCost(src.data_ptr(), tgt.data_ptr(), device_ptrs=True, count=n)
+    H, b, s = whole.linearize(x, 0)
+    Hs, bs, ss = np.zeros((6, 6)), np.zeros(6), 0.0
+    for k in range(0, n, chunk):
+        part = hip_lib.Point2PointCost(src[k:k + chunk].data_ptr(), tgt[k:k + chunk].data_ptr(),
+                                       device_ptrs=True, count=chunk)
+        Hk, bk, sk = part.linearize(x, 0)
+        Hs += Hk
+        bs += bk
+        ss += sk
+        part.close()
+    assert rel_err(Hs, H) < 1e-12 and rel_err(bs, b) < 1e-12 and abs(ss - s) < 1e-12 * s
+    assert np.array_equal(np.diag(H)[:3], np.full(3, float(n)))
+    whole.set_kernel_variant(1)
+    Hl, bl, sl = whole.linearize(x, 0)
+    assert rel_err(Hl, H) < 1e-11 and rel_err(bl, b) < 1e-11 and abs(sl - s) < 1e-11 * s
+    whole.set_speculation(False)
+    assert abs(whole.compute_cost(x) - s) < 1e-12 * s
+    whole.close()
+    del src, tgt
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("jac_mode", [0, 1, 2])
+def test_p2p_float32_all_modes_against_float_oracle(hip_lib, oracle, jac_mode):
+    """fp32 instantiation against the reference's own fp32 arithmetic (oracle run in float, as
+    CostFunction*Dynamic<float>, src/cost_function_*_dyn.cpp:32).  At 1 k points the reference's
+    float running sums are still accurate to ~1e-5; forward differences in float carry
+    eps_f |r| / h ~ 1e-3 of noise per Jacobian entry, hence the looser bound there."""
+    src, tgt = ds.synthetic_pair(1000, seed=21, noise=0.02, dtype=np.float32)
+    x = np.array([0.5, -0.3, 0.2, 0.1, -0.2, 0.3], dtype=np.float32)
+    cost = hip_lib.Point2PointCost(src, tgt, dtype=np.float32)
+    cost.set_loss(1, 100.0)
+    cc = ob.NUMERIC_DYN if jac_mode == 2 else ob.ANALYTIC_DYN
+    layout = ob.LAYOUT_TST if jac_mode == 1 else ob.LAYOUT_ROW_MAJOR
+    want = oracle.p2p_linearize(src, tgt, x, cost_class=cc, layout=layout, loss_kind=1,
+                                loss_param=100.0, dtype=np.float32)
+    tol = 2e-3 if jac_mode == 2 else 2e-5
+    check(cost.linearize(x, jac_mode), tuple(np.asarray(v, dtype=np.float64) for v in want), tol=tol)
