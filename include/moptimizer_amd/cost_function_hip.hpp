@@ -67,6 +67,7 @@ class DeviceModel : public IBaseModel<Scalar> {
   // creates the mopt_cost for this model on `device`
   virtual mopt_cost *createDeviceCost(int device, int num_residuals) const = 0;
   virtual int numOutputs() const = 0;
+  virtual int numParameters() const { return 6; }
 };
 
 // The Point2Point model of tst/point2point.cpp:24-84: residual R(x) p + t(x) - q over
@@ -126,6 +127,71 @@ class ReprojectionDeviceModel : public DeviceModel<double> {
   std::size_t count_;
 };
 
+// The small parametric models of the reference's other tests (n != 6), as device models.
+// y - exp(x0 t + x1) over interleaved (t, y) pairs — CurveFittingModel, tst/curve_fitting.cpp:81-98.
+class ExpCurveDeviceModel : public DeviceModel<double> {
+ public:
+  using Ptr = std::shared_ptr<ExpCurveDeviceModel>;
+  explicit ExpCurveDeviceModel(const double *interleaved_ty) : data_(interleaved_ty) {}
+  IBaseModel<double>::Ptr clone() const override {
+    return std::make_shared<ExpCurveDeviceModel>(*this);
+  }
+  mopt_cost *createDeviceCost(int device, int num_residuals) const override {
+    mopt_cost *h = nullptr;
+    throwOnError(mopt_scalar_model_create(&h, device, 8, MOPT_MODEL_EXP_CURVE, data_, data_ + 1, 2,
+                                          num_residuals),
+                 "mopt_scalar_model_create");
+    return h;
+  }
+  int numOutputs() const override { return 1; }
+  int numParameters() const override { return 2; }
+
+ private:
+  const double *data_;
+};
+
+// y - x0 t / (x1 + t) over separate t and y arrays — `Model`, tst/test_models.h:7-20.
+template <typename Scalar>
+class RationalDeviceModel : public DeviceModel<Scalar> {
+ public:
+  using Ptr = std::shared_ptr<RationalDeviceModel>;
+  RationalDeviceModel(const Scalar *t, const Scalar *y) : t_(t), y_(y) {}
+  typename IBaseModel<Scalar>::Ptr clone() const override {
+    return std::make_shared<RationalDeviceModel>(*this);
+  }
+  mopt_cost *createDeviceCost(int device, int num_residuals) const override {
+    mopt_cost *h = nullptr;
+    throwOnError(mopt_scalar_model_create(&h, device, int(sizeof(Scalar)), MOPT_MODEL_RATIONAL, t_,
+                                          y_, 1, num_residuals),
+                 "mopt_scalar_model_create");
+    return h;
+  }
+  int numOutputs() const override { return 1; }
+  int numParameters() const override { return 2; }
+
+ private:
+  const Scalar *t_;
+  const Scalar *y_;
+};
+
+// Powell's singular function — PowellModel, tst/powell.cpp:21-60 (one residual block of 4).
+class PowellDeviceModel : public DeviceModel<double> {
+ public:
+  using Ptr = std::shared_ptr<PowellDeviceModel>;
+  IBaseModel<double>::Ptr clone() const override {
+    return std::make_shared<PowellDeviceModel>(*this);
+  }
+  mopt_cost *createDeviceCost(int device, int num_residuals) const override {
+    mopt_cost *h = nullptr;
+    throwOnError(mopt_scalar_model_create(&h, device, 8, MOPT_MODEL_POWELL, nullptr, nullptr, 1,
+                                          num_residuals),
+                 "mopt_scalar_model_create");
+    return h;
+  }
+  int numOutputs() const override { return 4; }
+  int numParameters() const override { return 4; }
+};
+
 // ---- cost functions ---------------------------------------------------------------------------
 // Shared implementation; JacobianMode selects what linearize() means.
 template <class Scalar, int JacobianMode>
@@ -142,8 +208,8 @@ class CostFunctionHip : public CostFunctionBase<Scalar> {
       throw Exception(
           "CostFunctionHip needs a device model (Point2PointDeviceModel / "
           "ReprojectionDeviceModel); arbitrary host IBaseModel objects cannot run on the GPU");
-    if (num_parameters != 6 || num_outputs != dm->numOutputs())
-      throw Exception("CostFunctionHip: model dimensions do not match (n must be 6)");
+    if (num_parameters != dm->numParameters() || num_outputs != dm->numOutputs())
+      throw Exception("CostFunctionHip: (num_parameters, num_outputs) do not match the device model");
     handle_ = dm->createDeviceCost(device, num_residuals);
     this->covariance_->resize(num_outputs_, num_outputs_);
     this->covariance_->setIdentity();
@@ -211,7 +277,7 @@ using CostFunctionAnalyticalDynamic = CostFunctionHip<Scalar, MOPT_JAC_ANALYTIC>
 template <class Scalar = double>
 using CostFunctionNumericalDynamic = CostFunctionHip<Scalar, MOPT_JAC_NUMERIC>;
 
-template <class Scalar = double, int model_parameter_dim = 6, int model_output_dim = 3>
+template <class Scalar = double, int model_parameter_dim = 1, int model_output_dim = 1>
 class CostFunctionAnalytical : public CostFunctionHip<Scalar, MOPT_JAC_ANALYTIC> {
  public:
   using typename CostFunctionHip<Scalar, MOPT_JAC_ANALYTIC>::ModelPtr;
@@ -220,7 +286,7 @@ class CostFunctionAnalytical : public CostFunctionHip<Scalar, MOPT_JAC_ANALYTIC>
                                                    num_residuals, device) {}
 };
 
-template <class Scalar = double, int model_parameter_dim = 6, int model_output_dim = 3>
+template <class Scalar = double, int model_parameter_dim = 1, int model_output_dim = 1>
 class CostFunctionNumerical : public CostFunctionHip<Scalar, MOPT_JAC_NUMERIC> {
  public:
   using typename CostFunctionHip<Scalar, MOPT_JAC_NUMERIC>::ModelPtr;

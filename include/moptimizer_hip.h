@@ -114,6 +114,19 @@ MOPT_API int mopt_reprojection_create(mopt_cost **out, int device, const double 
                                       const double *camera_3x4, const double *frame_4x4,
                                       unsigned flags);
 
+/* The other parametric models the reference's tests drive through the same cost classes (n != 6):
+ *   MOPT_MODEL_EXP_CURVE  y - exp(x0 t + x1)       n = 2, m = 1   tst/curve_fitting.cpp:81-98
+ *   MOPT_MODEL_RATIONAL   y - x0 t / (x1 + t)      n = 2, m = 1   tst/test_models.h:7-20 (Jacobian:
+ *                                                                 tst/differentiation.cpp:26-38)
+ *   MOPT_MODEL_POWELL     Powell's function        n = 4, m = 4   tst/powell.cpp:21-60 (count = 1)
+ * t / y: arrays of `count` scalars read with a stride of `stride_scalars` (the curve-fitting data are
+ * interleaved pairs: t = data, y = data + 1, stride 2); ignored for MOPT_MODEL_POWELL.  All the cost
+ * calls above apply; x, hessian, b have n, n*n, n entries; async results n*n + n + 1 doubles. */
+enum mopt_scalar_model { MOPT_MODEL_EXP_CURVE = 1, MOPT_MODEL_RATIONAL = 2, MOPT_MODEL_POWELL = 3 };
+MOPT_API int mopt_scalar_model_create(mopt_cost **out, int device, int scalar_bytes, int model_kind,
+                                      const void *t, const void *y, int64_t stride_scalars,
+                                      int64_t count);
+
 MOPT_API int mopt_cost_destroy(mopt_cost *cost);
 
 MOPT_API int mopt_cost_set_covariance(mopt_cost *cost, const void *cov_colmajor);

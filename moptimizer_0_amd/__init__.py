@@ -19,5 +19,6 @@ from ._capi import (  # noqa: F401
     Point2PointCost,
     Point2PointGroup,
     ReprojectionCost,
+    ScalarModelCost,
 )
 from .sharded import ShardedSweep, shard_range  # noqa: F401

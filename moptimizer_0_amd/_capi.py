@@ -50,6 +50,9 @@ def load():
         "mopt_reprojection_create": [c_void_pp, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_uint],
+        "mopt_scalar_model_create": [c_void_pp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                     ctypes.c_int64],
         "mopt_cost_destroy": [ctypes.c_void_p],
         "mopt_cost_set_covariance": [ctypes.c_void_p, ctypes.c_void_p],
         "mopt_cost_set_loss": [ctypes.c_void_p, ctypes.c_int, ctypes.c_double],
@@ -133,6 +136,7 @@ class _CostBase:
         self._h = ctypes.c_void_p()
         self.scalar_bytes = 8
         self.n_out = 3
+        self.n_params = 6
 
     # -- CostFunctionBase::setCovariance / setLossFunction ---------------------------------
     def set_covariance(self, cov):
@@ -161,8 +165,10 @@ class _CostBase:
     def linearize(self, x, jac_mode):
         dt = _dtype_of(self.scalar_bytes)
         x = np.ascontiguousarray(x, dtype=dt)
-        H = np.zeros((6, 6), dtype=dt, order="F")
-        b = np.zeros(6, dtype=dt)
+        n = self.n_params
+        assert x.shape == (n,)
+        H = np.zeros((n, n), dtype=dt, order="F")
+        b = np.zeros(n, dtype=dt)
         s = np.zeros(1, dtype=dt)
         check(load().mopt_cost_linearize(self._h, int(jac_mode), _ptr(x), _ptr(H), _ptr(b), _ptr(s)))
         return H, b, s[0]
@@ -281,6 +287,31 @@ class ReprojectionCost(_CostBase):
             ctypes.byref(self._h), device, _ptr(pts), _ptr(pix), pts.shape[0],
             None if cam is None else _ptr(cam), None if frm is None else _ptr(frm), INPUT_HOST))
         self.count = pts.shape[0]
+
+
+MODEL_EXP_CURVE, MODEL_RATIONAL, MODEL_POWELL = 1, 2, 3
+
+
+class ScalarModelCost(_CostBase):
+    """One of the reference tests' small parametric models (exp curve, rational, Powell) on the GPU."""
+
+    _SHAPES = {MODEL_EXP_CURVE: (2, 1), MODEL_RATIONAL: (2, 1), MODEL_POWELL: (4, 4)}
+
+    def __init__(self, kind, t=None, y=None, device=0, dtype=np.float64):
+        super().__init__()
+        self.scalar_bytes = np.dtype(dtype).itemsize
+        self.n_params, self.n_out = self._SHAPES[kind]
+        if kind == MODEL_POWELL:
+            check(load().mopt_scalar_model_create(ctypes.byref(self._h), device, self.scalar_bytes,
+                                                  kind, None, None, 1, 1))
+            self.count = 1
+        else:
+            t = np.ascontiguousarray(t, dtype=dtype)
+            y = np.ascontiguousarray(y, dtype=dtype)
+            assert t.shape == y.shape and t.ndim == 1
+            check(load().mopt_scalar_model_create(ctypes.byref(self._h), device, self.scalar_bytes,
+                                                  kind, _ptr(t), _ptr(y), 1, t.shape[0]))
+            self.count = t.shape[0]
 
 
 class Point2PointGroup:

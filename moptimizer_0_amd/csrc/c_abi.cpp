@@ -44,8 +44,9 @@ int fail(int code, const std::string &msg) {
       return fail(MOPT_ERR_RCCL, std::string(#expr) + ": " + ncclGetErrorString(r_));      \
   } while (0)
 
-enum ModelKind { kModelPoint2Point = 1, kModelReprojection = 2 };
-constexpr int kMaxParamBytes = 6 * 8;
+enum ModelKind { kModelPoint2Point = 1, kModelReprojection = 2, kModelScalar = 3 };
+constexpr int kMaxParamBytes = mopt::kMaxParams * 8;
+constexpr int kResultSlots = 96;  // >= n*n + n + 1 for n <= 8 (73)
 
 int envInt(const char *name, int fallback) {
   const char *v = std::getenv(name);
@@ -60,7 +61,10 @@ struct mopt_cost {
   int device = 0;
   int scalar_bytes = 8;
   int model = kModelPoint2Point;
+  int scalar_model = 0;  // mopt::ScalarModelKind when model == kModelScalar
+  int n_params = mopt::kNumParams;
   int n_out = 3;
+  long long data_stride = 0;  // scalar models: elements per data plane
   long long count = 0;
   int num_tiles = 0;
   int num_cus = 0;
@@ -79,7 +83,8 @@ struct mopt_cost {
   ncclComm_t comm = nullptr;  // multi-process shard group (one rank per GPU), optional
   int comm_size = 1;
 
-  double cov[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // row-major m x m, as double
+  double cov[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // row-major, stride 3 (m <= 3), as double
+  double cov_m[16] = {1};                        // row-major m x m compact (scalar models, m <= 4)
   int cov_mode = mopt::kCovIdentity;
   int loss_kind = MOPT_LOSS_NONE;
   double loss_param = 0.0;
@@ -100,7 +105,7 @@ struct mopt_cost {
     int mode = -1;
     unsigned long long version = 0;
     unsigned char x[kMaxParamBytes] = {0};
-    double result[64] = {0};
+    double result[kResultSlots] = {0};
   } cache;
   long long stat_sweeps = 0;
   long long stat_cache_hits = 0;
@@ -116,6 +121,9 @@ namespace {
 
 using mopt::kNumParams;
 using mopt::kResultDoubles;
+
+inline int resultCount(const mopt_cost *c) { return c->n_params * c->n_params + c->n_params + 1; }
+inline int costOffset(const mopt_cost *c) { return c->n_params * c->n_params + c->n_params; }
 
 int gridFor(const mopt_cost *c, int blocks_per_cu) {
   long long g = (long long)c->num_cus * blocks_per_cu;
@@ -394,10 +402,66 @@ int reprojCostAsync(mopt_cost *c, const double *x, double *d_sum, hipStream_t s,
   return MOPT_OK;
 }
 
+template <typename S>
+void fillScalarArgs(const mopt_cost *c, const S *x, mopt::ScalarSweepArgs<S> &a) {
+  a.data = static_cast<const S *>(c->d_tiles);
+  a.count = c->count;
+  a.stride = c->data_stride;
+  a.loss_kind = c->loss_kind;
+  a.loss_param = S(c->loss_param);
+  a.partials = c->d_partials;
+  const S min_step = std::sqrt(std::numeric_limits<S>::epsilon());  // linearization.h:78
+  for (int j = 0; j < mopt::kMaxParams; ++j) {
+    a.x[j] = j < c->n_params ? x[j] : S(0);
+    S h = min_step * std::fabs(a.x[j]);  // :85
+    if (h == S(0)) h = min_step;         // :87
+    a.h[j] = h;
+  }
+  for (int k = 0; k < 16; ++k) a.cov[k] = S(c->cov_m[k]);
+}
+
+bool scalarModelHasJacobian(int kind) { return kind != mopt::kScalarExpCurve; }
+
+template <typename S>
+int scalarSweepAsync(mopt_cost *c, bool cost_only, int jac_mode, const S *x, double *d_out,
+                     hipStream_t s, const mopt::HostPublish &pub) {
+  if (!cost_only) {
+    if (jac_mode == MOPT_JAC_ANALYTIC_TST_LAYOUT)
+      return fail(MOPT_ERR_UNSUPPORTED, "the as-written point2point layout applies to point2point only");
+    if (jac_mode == MOPT_JAC_ANALYTIC && !scalarModelHasJacobian(c->scalar_model))
+      return fail(MOPT_ERR_UNSUPPORTED,
+                  "Non implemented non-jacobian model function `f_df` being used.");
+  }
+  mopt::ScalarSweepArgs<S> args;
+  fillScalarArgs<S>(c, x, args);
+  long long blocks = (c->count + mopt::kBlockThreads - 1) / mopt::kBlockThreads;
+  if (blocks > c->num_cus * 2) blocks = c->num_cus * 2;
+  if (blocks < 1) blocks = 1;
+  const int grid = int(blocks);
+  const int n = c->n_params;
+  SweepTimer timer(c, s);
+  MOPT_HIP_TRY(mopt::launchScalarModel<S>(args, c->scalar_model, cost_only, jac_mode, c->cov_mode,
+                                          grid, s));
+  timer.stop();
+  if (cost_only) {
+    MOPT_HIP_TRY(mopt::launchFinalizeCost(c->d_partials, grid, d_out, pub, s));
+  } else {
+    const int nacc = c->cov_mode == mopt::kCovGeneral ? n * n + n + 1 : n * (n + 1) / 2 + n + 1;
+    MOPT_HIP_TRY(mopt::launchFinalizeDense(c->d_partials, grid, nacc, n, d_out, pub, s));
+  }
+  return MOPT_OK;
+}
+
 int linearizeAsyncImpl(mopt_cost *c, int jac_mode, const void *x, double *d_result, hipStream_t s,
                        const mopt::HostPublish &pub = mopt::HostPublish()) {
   if (jac_mode < MOPT_JAC_ANALYTIC || jac_mode > MOPT_JAC_NUMERIC)
     return fail(MOPT_ERR_INVALID_ARGUMENT, "unknown jacobian_mode");
+  if (c->model == kModelScalar)
+    return c->scalar_bytes == 8
+               ? scalarSweepAsync<double>(c, false, jac_mode, static_cast<const double *>(x),
+                                          d_result, s, pub)
+               : scalarSweepAsync<float>(c, false, jac_mode, static_cast<const float *>(x),
+                                         d_result, s, pub);
   if (c->model == kModelReprojection)
     return reprojLinearizeAsync(c, jac_mode, static_cast<const double *>(x), d_result, s, pub);
   if (c->scalar_bytes == 8)
@@ -407,6 +471,10 @@ int linearizeAsyncImpl(mopt_cost *c, int jac_mode, const void *x, double *d_resu
 
 int costAsyncImpl(mopt_cost *c, const void *x, double *d_sum, hipStream_t s,
                   const mopt::HostPublish &pub = mopt::HostPublish()) {
+  if (c->model == kModelScalar)
+    return c->scalar_bytes == 8
+               ? scalarSweepAsync<double>(c, true, 0, static_cast<const double *>(x), d_sum, s, pub)
+               : scalarSweepAsync<float>(c, true, 0, static_cast<const float *>(x), d_sum, s, pub);
   if (c->model == kModelReprojection)
     return reprojCostAsync(c, static_cast<const double *>(x), d_sum, s, pub);
   if (c->scalar_bytes == 8)
@@ -446,20 +514,20 @@ mopt::HostPublish nextPublish(mopt_cost *c, int offset) {
 // One blocking sweep on the cost's own stream: kernels (+ all-reduce over the attached
 // communicator) and the published result in c->h_result[offset .. offset + count).
 int blockingSweep(mopt_cost *c, bool cost_only, int jac_mode, const void *x) {
-  const int offset = cost_only ? 42 : 0;
-  const int count = cost_only ? 1 : kResultDoubles;
+  const int offset = cost_only ? costOffset(c) : 0;
+  const int count = cost_only ? 1 : resultCount(c);
   mopt::HostPublish pub = nextPublish(c, offset);
   c->stat_sweeps += 1;
   int rc;
   if (c->comm && c->comm_size > 1) {
-    rc = cost_only ? costAsyncImpl(c, x, c->d_result + 42, c->stream)
+    rc = cost_only ? costAsyncImpl(c, x, c->d_result + offset, c->stream)
                    : linearizeAsyncImpl(c, jac_mode, x, c->d_result, c->stream);
     if (rc != MOPT_OK) return rc;
     MOPT_NCCL_TRY(ncclAllReduce(c->d_result + offset, c->d_result + offset, count, ncclDouble,
                                 ncclSum, c->comm, c->stream));
     MOPT_HIP_TRY(mopt::launchPublish(c->d_result + offset, count, pub, c->stream));
   } else {
-    rc = cost_only ? costAsyncImpl(c, x, c->d_result + 42, c->stream, pub)
+    rc = cost_only ? costAsyncImpl(c, x, c->d_result + offset, c->stream, pub)
                    : linearizeAsyncImpl(c, jac_mode, x, c->d_result, c->stream, pub);
     if (rc != MOPT_OK) return rc;
   }
@@ -467,16 +535,17 @@ int blockingSweep(mopt_cost *c, bool cost_only, int jac_mode, const void *x) {
 }
 
 void storeResult(const mopt_cost *c, const double *res, void *hessian, void *b, void *sum_sq) {
+  const int n = c->n_params, nn = n * n;
   if (c->scalar_bytes == 8) {
-    if (hessian) std::memcpy(hessian, res, 36 * sizeof(double));
-    if (b) std::memcpy(b, res + 36, 6 * sizeof(double));
-    if (sum_sq) *static_cast<double *>(sum_sq) = res[42];
+    if (hessian) std::memcpy(hessian, res, nn * sizeof(double));
+    if (b) std::memcpy(b, res + nn, n * sizeof(double));
+    if (sum_sq) *static_cast<double *>(sum_sq) = res[nn + n];
   } else {
     if (hessian)
-      for (int k = 0; k < 36; ++k) static_cast<float *>(hessian)[k] = float(res[k]);
+      for (int k = 0; k < nn; ++k) static_cast<float *>(hessian)[k] = float(res[k]);
     if (b)
-      for (int k = 0; k < 6; ++k) static_cast<float *>(b)[k] = float(res[36 + k]);
-    if (sum_sq) *static_cast<float *>(sum_sq) = float(res[42]);
+      for (int k = 0; k < n; ++k) static_cast<float *>(b)[k] = float(res[nn + k]);
+    if (sum_sq) *static_cast<float *>(sum_sq) = float(res[nn + n]);
   }
 }
 
@@ -494,15 +563,16 @@ int commonCreate(mopt_cost *c, int device) {
   c->max_grid = c->num_cus * 16;
   MOPT_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   MOPT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_partials),
-                         size_t(c->max_grid) * mopt::kAccFull * sizeof(double)));
-  MOPT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_result), kResultDoubles * sizeof(double)));
+                         size_t(c->max_grid) * kResultSlots * sizeof(double)));
+  MOPT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_result), kResultSlots * sizeof(double)));
   // results (43) + padding + flag word in one mapped, coherent host allocation
-  MOPT_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_result), 64 * sizeof(double),
+  MOPT_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_result),
+                             (kResultSlots + 16) * sizeof(double),
                              hipHostMallocMapped | hipHostMallocCoherent));
-  std::memset(c->h_result, 0, 64 * sizeof(double));
-  c->h_flag = reinterpret_cast<unsigned long long *>(c->h_result + 48);
+  std::memset(c->h_result, 0, (kResultSlots + 16) * sizeof(double));
+  c->h_flag = reinterpret_cast<unsigned long long *>(c->h_result + kResultSlots);
   MOPT_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->h_result_dev), c->h_result, 0));
-  c->h_flag_dev = reinterpret_cast<unsigned long long *>(c->h_result_dev + 48);
+  c->h_flag_dev = reinterpret_cast<unsigned long long *>(c->h_result_dev + kResultSlots);
   return MOPT_OK;
 }
 
@@ -651,6 +721,51 @@ int mopt_reprojection_create(mopt_cost **out, int device, const double *points_x
   return MOPT_OK;
 }
 
+int mopt_scalar_model_create(mopt_cost **out, int device, int scalar_bytes, int model_kind,
+                             const void *t, const void *y, int64_t stride_scalars, int64_t count) {
+  if (!out) return fail(MOPT_ERR_INVALID_ARGUMENT, "out is NULL");
+  *out = nullptr;
+  if (scalar_bytes != 4 && scalar_bytes != 8)
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "scalar_bytes must be 4 or 8");
+  int n = 0, m = 0, planes = 0;
+  switch (model_kind) {
+    case MOPT_MODEL_EXP_CURVE: n = 2; m = 1; planes = 2; break;
+    case MOPT_MODEL_RATIONAL: n = 2; m = 1; planes = 2; break;
+    case MOPT_MODEL_POWELL: n = 4; m = 4; planes = 0; break;
+    default: return fail(MOPT_ERR_INVALID_ARGUMENT, "unknown scalar model kind");
+  }
+  if (count < 1 || (planes > 0 && (!t || !y || stride_scalars < 1)))
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "bad data arrays / count");
+  std::unique_ptr<mopt_cost, void (*)(mopt_cost *)> c(new (std::nothrow) mopt_cost, destroyCost);
+  if (!c) return fail(MOPT_ERR_HIP, "out of host memory");
+  c->scalar_bytes = scalar_bytes;
+  c->model = kModelScalar;
+  c->scalar_model = model_kind;
+  c->n_params = n;
+  c->n_out = m;
+  c->count = count;
+  c->num_tiles = 1;
+  c->data_stride = count;
+  int rc = commonCreate(c.get(), device);
+  if (rc != MOPT_OK) return rc;
+  if (planes > 0) {
+    // gather the (possibly interleaved) host arrays into contiguous planes t | y
+    std::vector<unsigned char> staged(size_t(planes) * size_t(count) * scalar_bytes);
+    const unsigned char *src[2] = {static_cast<const unsigned char *>(t),
+                                   static_cast<const unsigned char *>(y)};
+    for (int p = 0; p < planes; ++p)
+      for (int64_t i = 0; i < count; ++i)
+        std::memcpy(&staged[(size_t(p) * count + size_t(i)) * scalar_bytes],
+                    src[p] + size_t(i) * size_t(stride_scalars) * scalar_bytes, scalar_bytes);
+    MOPT_HIP_TRY(hipMalloc(&c->d_tiles, staged.size()));
+    MOPT_HIP_TRY(hipMemcpy(c->d_tiles, staged.data(), staged.size(), hipMemcpyHostToDevice));
+  }
+  mopt_cost_set_covariance(c.get(), nullptr);
+  c->state_version = 0;
+  *out = c.release();
+  return MOPT_OK;
+}
+
 int mopt_cost_destroy(mopt_cost *cost) {
   destroyCost(cost);
   return MOPT_OK;
@@ -659,29 +774,32 @@ int mopt_cost_destroy(mopt_cost *cost) {
 int mopt_cost_set_covariance(mopt_cost *c, const void *cov_colmajor) {
   if (!c) return fail(MOPT_ERR_INVALID_ARGUMENT, "cost is NULL");
   const int m = c->n_out;
-  double previous[9];
-  std::memcpy(previous, c->cov, sizeof previous);
-  for (int k = 0; k < 9; ++k) c->cov[k] = 0.0;
-  for (int a = 0; a < 3; ++a) c->cov[a * 3 + a] = 1.0;
-  if (cov_colmajor) {
+  double dense[16];  // row-major m x m
+  for (int a = 0; a < m; ++a)
+    for (int b = 0; b < m; ++b) {
+      double v = (a == b) ? 1.0 : 0.0;
+      if (cov_colmajor)
+        v = c->scalar_bytes == 8 ? static_cast<const double *>(cov_colmajor)[b * m + a]
+                                 : double(static_cast<const float *>(cov_colmajor)[b * m + a]);
+      dense[a * m + b] = v;
+    }
+  double previous[16];
+  std::memcpy(previous, c->cov_m, sizeof previous);
+  for (int k = 0; k < 16; ++k) c->cov_m[k] = 0.0;
+  for (int k = 0; k < m * m; ++k) c->cov_m[k] = dense[k];
+  for (int k = 0; k < 9; ++k) c->cov[k] = (k % 4 == 0) ? 1.0 : 0.0;
+  if (m <= 3)
     for (int a = 0; a < m; ++a)
-      for (int b = 0; b < m; ++b) {
-        const double v = c->scalar_bytes == 8
-                             ? static_cast<const double *>(cov_colmajor)[b * m + a]
-                             : double(static_cast<const float *>(cov_colmajor)[b * m + a]);
-        c->cov[a * 3 + b] = v;
-      }
-    if (m == 2) c->cov[8] = 1.0;
-  }
+      for (int b = 0; b < m; ++b) c->cov[a * 3 + b] = dense[a * m + b];
   bool identity = true, symmetric = true;
   for (int a = 0; a < m; ++a)
     for (int b = 0; b < m; ++b) {
-      if (c->cov[a * 3 + b] != (a == b ? 1.0 : 0.0)) identity = false;
-      if (c->cov[a * 3 + b] != c->cov[b * 3 + a]) symmetric = false;
+      if (dense[a * m + b] != (a == b ? 1.0 : 0.0)) identity = false;
+      if (dense[a * m + b] != dense[b * m + a]) symmetric = false;
     }
   c->cov_mode = identity ? mopt::kCovIdentity
                          : (symmetric ? mopt::kCovSymmetric : mopt::kCovGeneral);
-  if (std::memcmp(previous, c->cov, sizeof previous) != 0) c->state_version += 1;
+  if (std::memcmp(previous, c->cov_m, sizeof previous) != 0) c->state_version += 1;
   return MOPT_OK;
 }
 
@@ -700,7 +818,7 @@ int mopt_cost_set_kernel_variant(mopt_cost *c, int variant) {
   if (variant < MOPT_KERNEL_AUTO || variant > MOPT_KERNEL_MOMENTS)
     return fail(MOPT_ERR_INVALID_ARGUMENT, "unknown kernel variant");
   if (variant == MOPT_KERNEL_MOMENTS && c->model != kModelPoint2Point)
-    return fail(MOPT_ERR_UNSUPPORTED, "the reprojection Jacobian is not affine in the point");
+    return fail(MOPT_ERR_UNSUPPORTED, "only point2point Jacobians are affine in the data point");
   if (c->variant != variant) c->state_version += 1;
   c->variant = variant;
   return MOPT_OK;
@@ -710,7 +828,7 @@ int mopt_cost_info(const mopt_cost *c, int64_t *count, int *n, int *m, int *scal
                    int *device) {
   if (!c) return fail(MOPT_ERR_INVALID_ARGUMENT, "cost is NULL");
   if (count) *count = c->count;
-  if (n) *n = kNumParams;
+  if (n) *n = c->n_params;
   if (m) *m = c->n_out;
   if (scalar_bytes) *scalar_bytes = c->scalar_bytes;
   if (device) *device = c->device;
@@ -736,14 +854,14 @@ namespace {
 bool cacheMatches(const mopt_cost *c, const void *x, int mode_or_any) {
   return c->cache.valid && c->cache.version == c->state_version &&
          (mode_or_any < 0 || c->cache.mode == mode_or_any) &&
-         std::memcmp(c->cache.x, x, size_t(kNumParams) * c->scalar_bytes) == 0;
+         std::memcmp(c->cache.x, x, size_t(c->n_params) * c->scalar_bytes) == 0;
 }
 void cacheStore(mopt_cost *c, const void *x, int mode) {
   c->cache.valid = true;
   c->cache.mode = mode;
   c->cache.version = c->state_version;
-  std::memcpy(c->cache.x, x, size_t(kNumParams) * c->scalar_bytes);
-  std::memcpy(c->cache.result, c->h_result, kResultDoubles * sizeof(double));
+  std::memcpy(c->cache.x, x, size_t(c->n_params) * c->scalar_bytes);
+  std::memcpy(c->cache.result, c->h_result, resultCount(c) * sizeof(double));
 }
 }  // namespace
 

@@ -9,6 +9,7 @@ namespace mopt {
 
 constexpr int kBlockThreads = 256;  // 4 wavefronts of 64
 constexpr int kNumParams = 6;       // (t, w) of SE(3)
+constexpr int kMaxParams = 8;       // small parametric models (scalarModelKernel)
 
 // ---- HBM layout ----------------------------------------------------------------------------
 // Correspondences live in HBM as *tiled structure-of-arrays*: a tile holds kBlockThreads * V
@@ -73,6 +74,22 @@ struct AffineBasis {
   double cov[9];
 };
 
+// Small parametric models over per-element scalar data (planes data[p * stride + i]).
+enum ScalarModelKind : int { kScalarExpCurve = 1, kScalarRational = 2, kScalarPowell = 3 };
+
+template <typename S>
+struct ScalarSweepArgs {
+  const S *data;
+  long long count;
+  long long stride;
+  int loss_kind;
+  S loss_param;
+  S x[kMaxParams];
+  S h[kMaxParams];  // forward-difference steps (linearization.h:85-87)
+  S cov[16];        // row-major m x m
+  double *partials;
+};
+
 // Where a sweep kernel is launched.
 struct LaunchSite {
   hipStream_t stream = nullptr;
@@ -117,6 +134,12 @@ hipError_t launchFinalizeMoments(const double *partials, int grid, const AffineB
                                  double *result, const HostPublish &pub, hipStream_t stream);
 hipError_t launchFinalizeCost(const double *partials, int grid, double *result,
                               const HostPublish &pub, hipStream_t stream);
+// Small parametric models: one launch computes the workgroup partial rows of the linearization
+// (or of the cost when cost_only); finish with launchFinalizeDense(n) / launchFinalizeCost.
+template <typename S>
+hipError_t launchScalarModel(const ScalarSweepArgs<S> &args, int model, bool cost_only,
+                             int jac_mode, int cov_mode, int grid, hipStream_t stream);
+
 // device result (count doubles) -> mapped host memory + flag (after a collective)
 hipError_t launchPublish(const double *d_values, int count, const HostPublish &pub,
                          hipStream_t stream);

@@ -158,25 +158,25 @@ __device__ __forceinline__ void blockReduceStore(double (&acc)[NACC], double *ou
   }
 }
 
-// acc += w J^T S J (upper triangle, or all 36 entries when S is not symmetric), w J^T S r, r^T r.
-// J is m x 6 (row index = output), cov row-major m x m.
-template <typename S, int M, int COV, int NACC>
-__device__ __forceinline__ void accumulateDense(const S (&J)[M][6], const S (&r)[M], S w, S rr,
+// acc += w J^T S J (upper triangle, or all n*n entries when S is not symmetric), w J^T S r, r^T r.
+// J is m x n (row index = output), cov row-major m x m.  FULL selects the n*n form.
+template <typename S, int M, int N, int COV, int NACC>
+__device__ __forceinline__ void accumulateDense(const S (&J)[M][N], const S (&r)[M], S w, S rr,
                                                 const S *cov, double (&acc)[NACC]) {
-  S SJ[M][6];
+  S SJ[M][N];
   S Sr[M];
   if (COV == kCovIdentity) {
 #pragma unroll
     for (int a = 0; a < M; ++a) {
 #pragma unroll
-      for (int j = 0; j < 6; ++j) SJ[a][j] = J[a][j];
+      for (int j = 0; j < N; ++j) SJ[a][j] = J[a][j];
       Sr[a] = r[a];
     }
   } else {
 #pragma unroll
     for (int a = 0; a < M; ++a) {
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
+      for (int j = 0; j < N; ++j) {
         S v = 0;
 #pragma unroll
         for (int c = 0; c < M; ++c) v += cov[a * M + c] * J[c][j];
@@ -188,34 +188,35 @@ __device__ __forceinline__ void accumulateDense(const S (&J)[M][6], const S (&r)
       Sr[a] = v;
     }
   }
-  S wJ[M][6];
+  S wJ[M][N];
 #pragma unroll
   for (int a = 0; a < M; ++a)
 #pragma unroll
-    for (int i = 0; i < 6; ++i) wJ[a][i] = w * J[a][i];
+    for (int i = 0; i < N; ++i) wJ[a][i] = w * J[a][i];
 
-  constexpr bool kFull = (NACC == kAccFull);
-  constexpr int kNH = kFull ? 36 : 21;
+  constexpr bool kFull = (NACC == N * N + N + 1);
+  constexpr int kNH = kFull ? N * N : N * (N + 1) / 2;
+  static_assert(NACC == kNH + N + 1, "accumulator count does not match the matrix form");
 #pragma unroll
-  for (int j = 0; j < 6; ++j) {
+  for (int j = 0; j < N; ++j) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < N; ++i) {
       if (!kFull && i > j) continue;
       S v = 0;
 #pragma unroll
       for (int a = 0; a < M; ++a) v += wJ[a][i] * SJ[a][j];
-      const int k = kFull ? (j * 6 + i) : (j * (j + 1) / 2 + i);
+      const int k = kFull ? (j * N + i) : (j * (j + 1) / 2 + i);
       acc[k] += double(v);
     }
   }
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
+  for (int i = 0; i < N; ++i) {
     S v = 0;
 #pragma unroll
     for (int a = 0; a < M; ++a) v += wJ[a][i] * Sr[a];
     acc[kNH + i] += double(v);
   }
-  acc[kNH + 6] += double(rr);
+  acc[kNH + N] += double(rr);
 }
 
 // ---- point-to-point, literal evaluation ------------------------------------------------------
@@ -255,7 +256,7 @@ __device__ __forceinline__ void p2pPointLiteral(
   }
   const S rr = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
   const S w = lossWeight<S>(A.loss_kind, A.loss_param, rr);
-  accumulateDense<S, 3, COV>(J, r, valid ? w : S(0), valid ? rr : S(0), A.cov, acc);
+  accumulateDense<S, 3, 6, COV>(J, r, valid ? w : S(0), valid ? rr : S(0), A.cov, acc);
 }
 
 template <typename S, int JAC, int COV>
@@ -401,8 +402,105 @@ __global__ __launch_bounds__(kBlockThreads) void reprojKernel(const ReprojSweepA
         }
         const double w = lossWeight<double>(A.loss_kind, A.loss_param, rr);
         // padded elements are all-zero points: o[2] = 0 gives inf/NaN, so mask by selection
-        if (valid) accumulateDense<double, 2, COV>(J, r, w, rr, A.cov, acc);
+        if (valid) accumulateDense<double, 2, 6, COV>(J, r, w, rr, A.cov, acc);
       }
+    }
+  }
+  blockReduceStore<NACC>(acc, A.partials + size_t(blockIdx.x) * NACC);
+}
+
+// ---- small parametric models over per-element scalar data ------------------------------------
+// The other models the reference's tests run through the same cost classes (n != 6):
+//   ExpCurve   y - exp(x0 t + x1)            tst/curve_fitting.cpp:81-98, multiple_objectives.cpp:81-98
+//   Rational   y - x0 t / (x1 + t)           tst/test_models.h:7-20; Jacobian tst/differentiation.cpp:26-38
+//   Powell     Powell's singular function    tst/powell.cpp:21-60 (4 outputs, one element)
+// Same skeleton: per-element residual, analytic or forward-difference Jacobian
+// (linearization.h:101-117 / :143-154), loss weight, dense accumulation, workgroup partial row.
+template <typename S>
+struct ExpCurve {
+  static constexpr int N = 2, M = 1, D = 2;
+  static constexpr bool kHasJacobian = false;
+  __device__ static void residual(const S *x, const S *d, S (&r)[M]) {
+    r[0] = d[1] - exp(x[0] * d[0] + x[1]);
+  }
+  __device__ static void jacobian(const S *, const S *, S (&)[M][N]) {}
+};
+
+template <typename S>
+struct Rational {
+  static constexpr int N = 2, M = 1, D = 2;
+  static constexpr bool kHasJacobian = true;
+  __device__ static void residual(const S *x, const S *d, S (&r)[M]) {
+    r[0] = d[1] - (x[0] * d[0]) / (x[1] + d[0]);
+  }
+  __device__ static void jacobian(const S *x, const S *d, S (&J)[M][N]) {
+    const S denominator = x[1] + d[0];
+    J[0][0] = -d[0] / denominator;
+    J[0][1] = (x[0] * d[0]) / (denominator * denominator);
+  }
+};
+
+template <typename S>
+struct Powell {
+  static constexpr int N = 4, M = 4, D = 0;
+  static constexpr bool kHasJacobian = true;
+  __device__ static void residual(const S *x, const S *, S (&r)[M]) {
+    r[0] = x[0] + 10 * x[1];
+    r[1] = sqrt(S(5)) * (x[2] - x[3]);
+    r[2] = (x[1] - 2 * x[2]) * (x[1] - 2 * x[2]);
+    r[3] = sqrt(S(10)) * (x[0] - x[3]) * (x[0] - x[3]);
+  }
+  // exactly the entries the reference's test model writes (tst/powell.cpp:31-57), including its
+  // (x1 + 2 x2) in rows 2 — the test's own Jacobian, not the textbook one
+  __device__ static void jacobian(const S *x, const S *, S (&J)[M][N]) {
+    const S s5 = sqrt(S(5)), s10 = sqrt(S(10));
+    J[0][0] = 1;  J[1][0] = 0;   J[2][0] = 0;                              J[3][0] = s10 * 2 * (x[0] - x[3]);
+    J[0][1] = 10; J[1][1] = 0;   J[2][1] = 2 * (x[1] + 2 * x[2]);          J[3][1] = 0;
+    J[0][2] = 0;  J[1][2] = s5;  J[2][2] = 2 * (x[1] + 2 * x[2]) * (-2);   J[3][2] = 0;
+    J[0][3] = 0;  J[1][3] = -s5; J[2][3] = 0;                              J[3][3] = s10 * 2 * (x[0] - x[3]) * (-1);
+  }
+};
+
+template <typename S, template <typename> class ModelT, int JAC, int COV, bool COST_ONLY>
+__global__ __launch_bounds__(kBlockThreads) void scalarModelKernel(const ScalarSweepArgs<S> A) {
+  using Model = ModelT<S>;
+  constexpr int N = Model::N, M = Model::M, D = Model::D;
+  constexpr int NACC =
+      COST_ONLY ? 1 : ((COV == kCovGeneral) ? N * N + N + 1 : N * (N + 1) / 2 + N + 1);
+  double acc[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+  for (long long i = (long long)blockIdx.x * kBlockThreads + threadIdx.x; i < A.count;
+       i += (long long)gridDim.x * kBlockThreads) {
+    S d[D > 0 ? D : 1];
+#pragma unroll
+    for (int p = 0; p < D; ++p) d[p] = A.data[p * A.stride + i];
+    S r[M];
+    Model::residual(A.x, d, r);
+    S rr = 0;
+#pragma unroll
+    for (int a = 0; a < M; ++a) rr += r[a] * r[a];
+    if constexpr (COST_ONLY) {
+      acc[0] += double(rr);
+    } else {
+      S J[M][N];
+      if (JAC == kJacNumeric || !Model::kHasJacobian) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          S xp[N];
+#pragma unroll
+          for (int k = 0; k < N; ++k) xp[k] = A.x[k];
+          xp[j] += A.h[j];  // linearization.h:89
+          S rp[M];
+          Model::residual(xp, d, rp);
+#pragma unroll
+          for (int a = 0; a < M; ++a) J[a][j] = (rp[a] - r[a]) / A.h[j];  // :105
+        }
+      } else {
+        Model::jacobian(A.x, d, J);
+      }
+      const S w = lossWeight<S>(A.loss_kind, A.loss_param, rr);
+      accumulateDense<S, M, N, COV>(J, r, w, rr, A.cov, acc);
     }
   }
   blockReduceStore<NACC>(acc, A.partials + size_t(blockIdx.x) * NACC);
@@ -449,6 +547,7 @@ __global__ void relayoutReprojKernel(const double *__restrict__ pts, const int *
 // independent and in flight together — the kernel costs about one memory round trip, not one
 // per row.  Column totals are then formed in a fixed order (bitwise reproducible).
 constexpr int kFinalThreads = 1024;
+constexpr int kMaxAccumulators = 128;  // n <= 8: n*n + n + 1 <= 73
 
 // Write-through store at system scope (sc0 sc1): straight to mapped host memory, nothing left
 // dirty in L2, so publishing needs no L2 write-back (a system-scope release fence costs two).
@@ -472,7 +571,8 @@ __device__ __forceinline__ void publishToHost(const HostPublish &pub, int count,
 }
 
 __device__ __forceinline__ void columnTotals(const double *partials, int grid, int nacc,
-                                             double (&scratch)[kFinalThreads], double (&total)[64]) {
+                                             double (&scratch)[kFinalThreads],
+                                             double (&total)[kMaxAccumulators]) {
   const int per_col = kFinalThreads / nacc;  // threads per column
   const int stride = per_col * nacc;
   const int total_elems = grid * nacc;
@@ -500,32 +600,35 @@ __device__ __forceinline__ void columnTotals(const double *partials, int grid, i
   __syncthreads();
 }
 
+// rows of [upper triangle or full H | b | sum_sq] over n parameters -> H (n x n column-major) | b |
+// sum_sq.  nacc tells the form: n(n+1)/2 + n + 1 (symmetric) or n*n + n + 1 (full).
 __global__ __launch_bounds__(kFinalThreads) void finalizeDenseKernel(const double *partials,
-                                                                      int grid, int nacc,
+                                                                      int grid, int nacc, int n,
                                                                       double *result,
                                                                       const HostPublish pub) {
   __shared__ double scratch[kFinalThreads];
-  __shared__ double total[64];
+  __shared__ double total[kMaxAccumulators];
   columnTotals(partials, grid, nacc, scratch, total);
   const int k = threadIdx.x;
+  const int count = n * n + n + 1;
   double v = 0.0;
-  if (k < kResultDoubles) {
-    const bool full = (nacc == kAccFull);
-    const int nh = full ? 36 : 21;
-    if (k < 36) {
-      const int i = k % 6, j = k / 6;  // column-major H(i, j)
+  if (k < count) {
+    const bool full = (nacc == count);
+    const int nh = full ? n * n : n * (n + 1) / 2;
+    if (k < n * n) {
+      const int i = k % n, j = k / n;  // column-major H(i, j)
       if (full) {
-        v = total[j * 6 + i];
+        v = total[j * n + i];
       } else {
         const int lo = i < j ? i : j, hi = i < j ? j : i;
         v = total[hi * (hi + 1) / 2 + lo];
       }
     } else {
-      v = total[nh + (k - 36)];  // b (6) then sum_sq
+      v = total[nh + (k - n * n)];  // b (n) then sum_sq
     }
     result[k] = v;
   }
-  publishToHost(pub, kResultDoubles, v);
+  publishToHost(pub, count, v);
 }
 
 // Moments -> H, b.  With p_0 = 1:  W(a,b) = sum w p_a p_b,  V(a,c) = sum w p_a r_c  and
@@ -537,7 +640,7 @@ __global__ __launch_bounds__(kFinalThreads) void finalizeMomentsKernel(const dou
                                                                         double *result,
                                                                         const HostPublish pub) {
   __shared__ double scratch[kFinalThreads];
-  __shared__ double total[64];
+  __shared__ double total[kMaxAccumulators];
   __shared__ double terms[36 * 16 + 6 * 4];
   columnTotals(partials, grid, kAccMoments, scratch, total);
   const int t = threadIdx.x;
@@ -722,9 +825,10 @@ hipError_t launchReprojCost(const ReprojSweepArgs &args, int grid, const LaunchS
 
 hipError_t launchFinalizeDense(const double *partials, int grid, int nacc, int n, double *result,
                                const HostPublish &pub, hipStream_t stream) {
-  if (n != kNumParams || (nacc != kAccSym && nacc != kAccFull)) return hipErrorInvalidValue;
+  if (n < 1 || n > kMaxParams || (nacc != n * (n + 1) / 2 + n + 1 && nacc != n * n + n + 1))
+    return hipErrorInvalidValue;
   hipLaunchKernelGGL(finalizeDenseKernel, dim3(1), dim3(kFinalThreads), 0, stream, partials, grid,
-                     nacc, result, pub);
+                     nacc, n, result, pub);
   return hipGetLastError();
 }
 
@@ -742,10 +846,61 @@ hipError_t launchFinalizeCost(const double *partials, int grid, double *result,
   return hipGetLastError();
 }
 
+namespace {
+template <typename S, template <typename> class ModelT>
+hipError_t launchScalarFor(const ScalarSweepArgs<S> &args, bool cost_only, int jac_mode,
+                           int cov_mode, int grid, hipStream_t stream) {
+  const dim3 g(grid), b(kBlockThreads);
+  if (cost_only) {
+    hipLaunchKernelGGL((scalarModelKernel<S, ModelT, kJacNumeric, kCovIdentity, true>), g, b, 0,
+                       stream, args);
+    return hipGetLastError();
+  }
+  const bool numeric = (jac_mode == kJacNumeric);
+#define MOPT_LAUNCH_SCALAR(JAC, COV) \
+  hipLaunchKernelGGL((scalarModelKernel<S, ModelT, JAC, COV, false>), g, b, 0, stream, args)
+  switch (cov_mode) {
+    case kCovIdentity:
+      if (numeric) MOPT_LAUNCH_SCALAR(kJacNumeric, kCovIdentity);
+      else MOPT_LAUNCH_SCALAR(kJacAnalytic, kCovIdentity);
+      break;
+    case kCovSymmetric:
+      if (numeric) MOPT_LAUNCH_SCALAR(kJacNumeric, kCovSymmetric);
+      else MOPT_LAUNCH_SCALAR(kJacAnalytic, kCovSymmetric);
+      break;
+    default:
+      if (numeric) MOPT_LAUNCH_SCALAR(kJacNumeric, kCovGeneral);
+      else MOPT_LAUNCH_SCALAR(kJacAnalytic, kCovGeneral);
+      break;
+  }
+#undef MOPT_LAUNCH_SCALAR
+  return hipGetLastError();
+}
+}  // namespace
+
+template <typename S>
+hipError_t launchScalarModel(const ScalarSweepArgs<S> &args, int model, bool cost_only,
+                             int jac_mode, int cov_mode, int grid, hipStream_t stream) {
+  switch (model) {
+    case kScalarExpCurve:
+      return launchScalarFor<S, ExpCurve>(args, cost_only, jac_mode, cov_mode, grid, stream);
+    case kScalarRational:
+      return launchScalarFor<S, Rational>(args, cost_only, jac_mode, cov_mode, grid, stream);
+    case kScalarPowell:
+      return launchScalarFor<S, Powell>(args, cost_only, jac_mode, cov_mode, grid, stream);
+    default:
+      return hipErrorInvalidValue;
+  }
+}
+template hipError_t launchScalarModel<float>(const ScalarSweepArgs<float> &, int, bool, int, int,
+                                             int, hipStream_t);
+template hipError_t launchScalarModel<double>(const ScalarSweepArgs<double> &, int, bool, int, int,
+                                              int, hipStream_t);
+
 hipError_t launchPublish(const double *d_values, int count, const HostPublish &pub,
                          hipStream_t stream) {
-  if (count < 0 || count > 64) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(publishKernel, dim3(1), dim3(64), 0, stream, d_values, count, pub);
+  if (count < 0 || count > kMaxAccumulators) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(publishKernel, dim3(1), dim3(kMaxAccumulators), 0, stream, d_values, count, pub);
   return hipGetLastError();
 }
 

@@ -270,6 +270,47 @@ int oracle_camera_minimize(const double *points_xyzw, const int32_t *pixels_uv,
   }
 }
 
+// The reference tests' small parametric models (model_kind: 1 exp curve, 2 rational, 3 Powell),
+// scalar_bytes 4 or 8 (exp curve / Powell: 8 only), numeric = 0 analytic cost class, 1 numeric.
+// t, y: `count` scalars each.  H: n*n column-major, b: n.
+int oracle_scalar_linearize(int scalar_bytes, int model_kind, int numeric, const void *t,
+                            const void *y, int count, const void *x, const void *cov,
+                            int loss_kind, double loss_param, void *H, void *b, void *cost) {
+  try {
+    const int cc = numeric ? kNumericDyn : kAnalyticDyn;
+    if (model_kind == 2 && scalar_bytes == 4) {
+      auto model = std::make_shared<oracle::RationalModel<float>>((const float *)t, (const float *)y);
+      auto c = makeCost<float>(cc, model, 2, 1, count, (const float *)cov, loss_kind, loss_param);
+      *(float *)cost = c->linearize((const float *)x, (float *)H, (float *)b);
+      return 0;
+    }
+    if (scalar_bytes != 8) return -1;
+    std::unique_ptr<moptimizer::CostFunctionBase<double>> c;
+    std::vector<double> interleaved;
+    if (model_kind == 1) {
+      interleaved.resize(2 * size_t(count));
+      for (int i = 0; i < count; ++i) {
+        interleaved[2 * i] = ((const double *)t)[i];
+        interleaved[2 * i + 1] = ((const double *)y)[i];
+      }
+      c = makeCost<double>(cc, std::make_shared<oracle::CurveFittingModel>(interleaved.data()), 2, 1,
+                           count, (const double *)cov, loss_kind, loss_param);
+    } else if (model_kind == 2) {
+      c = makeCost<double>(cc, std::make_shared<oracle::RationalModel<double>>((const double *)t, (const double *)y),
+                           2, 1, count, (const double *)cov, loss_kind, loss_param);
+    } else if (model_kind == 3) {
+      c = makeCost<double>(cc, std::make_shared<oracle::PowellModel>(), 4, 4, count,
+                           (const double *)cov, loss_kind, loss_param);
+    } else {
+      return -1;
+    }
+    *(double *)cost = c->linearize((const double *)x, (double *)H, (double *)b);
+    return 0;
+  } catch (...) {
+    return -2;
+  }
+}
+
 // The transforms the restatement derives from x: column-major 4x4 for x and, when n_plus = 6,
 // for each forward-difference point x + h_j e_j (linearization.h:78-92), plus the steps h.
 int oracle_se3_from_x(const double *x, double *T16, double *T16_plus /* 6*16 or NULL */,

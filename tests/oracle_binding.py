@@ -145,6 +145,27 @@ class Oracle:
         assert rc == 0, rc
         return x, status.value, iters.value
 
+    def scalar_linearize(self, kind, t, y, x, numeric=True, cov=None, loss_kind=0, loss_param=0.0,
+                         dtype=np.float64):
+        n, m = {1: (2, 1), 2: (2, 1), 3: (4, 4)}[kind]
+        count = 1 if kind == 3 else len(t)
+        t = None if t is None else np.ascontiguousarray(t, dtype=dtype)
+        y = None if y is None else np.ascontiguousarray(y, dtype=dtype)
+        x = np.ascontiguousarray(x, dtype=dtype)
+        cov = None if cov is None else np.asfortranarray(np.asarray(cov, dtype=dtype))
+        H = np.zeros((n, n), dtype=dtype, order="F")
+        b = np.zeros(n, dtype=dtype)
+        s = np.zeros(1, dtype=dtype)
+        self.lib.oracle_scalar_linearize.argtypes = [
+            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p,
+            ctypes.c_void_p, ctypes.c_void_p]
+        rc = self.lib.oracle_scalar_linearize(np.dtype(dtype).itemsize, kind, 1 if numeric else 0,
+                                              _p(t), _p(y), count, _p(x), _p(cov), loss_kind,
+                                              loss_param, _p(H), _p(b), _p(s))
+        assert rc == 0, rc
+        return H, b, s[0]
+
     def se3_from_x(self, x, with_steps=False):
         x = np.ascontiguousarray(x, dtype=np.float64)
         T = np.zeros(16)

@@ -22,3 +22,14 @@ def test_cpp_dropin_program(hip_lib, facade, tmp_path):
     print(out.stdout[-4000:])
     assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-2000:]
     assert "SUMMARY failures=0" in out.stdout
+
+
+def test_cpp_dropin_reference_model_tests(hip_lib):
+    """The reference's curve-fitting / Powell / simple-model / loss / covariance / multi-objective /
+    differentiation tests with the HIP cost classes (tests/cpp/dropin_models.cpp)."""
+    exe = os.path.join(ds.ROOT, "tests", "cpp", "_build", "dropin_models")
+    assert os.path.exists(exe), "build it with `make cpptests`"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    print(out.stdout[-6000:])
+    assert out.returncode == 0, out.stdout[-6000:] + out.stderr[-2000:]
+    assert "failures=0" in out.stdout

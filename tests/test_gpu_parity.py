@@ -426,3 +426,42 @@ def test_p2p_float32_all_modes_against_float_oracle(hip_lib, oracle, jac_mode):
                                 loss_param=100.0, dtype=np.float32)
     tol = 2e-3 if jac_mode == 2 else 2e-5
     check(cost.linearize(x, jac_mode), tuple(np.asarray(v, dtype=np.float64) for v in want), tol=tol)
+
+
+def test_small_parametric_models_match_oracle(hip_lib, oracle):
+    """Exp-curve, rational and Powell device models (n = 2, 2, 4) against the restated CPU cost
+    classes: forward-difference and analytic Jacobians, loss and covariance, fp64 and fp32."""
+    rng = np.random.default_rng(4)
+    t = np.linspace(0.0, 4.95, 5000)
+    y = np.exp(0.3 * t + 0.1) + rng.normal(0, 0.2, t.shape)
+    c = hip_lib.ScalarModelCost(hip_lib.capi.MODEL_EXP_CURVE, t, y)
+    for x in (np.zeros(2), np.array([0.29, 0.13]), np.array([1.2, 2.0])):
+        for cov in (None, np.array([[0.5]])):
+            for lk, lp in ((0, 0.0), (1, 100.0)):
+                c.set_covariance(cov)
+                c.set_loss(lk, lp)
+                want = oracle.scalar_linearize(1, t, y, x, numeric=True, cov=cov, loss_kind=lk, loss_param=lp)
+                check(c.linearize(x, 2), want, tol=fd_tolerance(x))
+    with pytest.raises(hip_lib.MoptError):
+        c.linearize(np.zeros(2), 0)   # no Jacobian in this model (BaseModel::f_df throws)
+
+    tr = np.abs(rng.normal(1.0, 1.0, 3000)) + 0.05
+    yr = 0.36 * tr / (0.56 + tr) + rng.normal(0, 0.01, tr.shape)
+    for dtype, tol in ((np.float64, None), (np.float32, 5e-3)):
+        c = hip_lib.ScalarModelCost(hip_lib.capi.MODEL_RATIONAL, tr, yr, dtype=dtype)
+        x = np.array([0.9, 0.2], dtype=dtype)
+        for numeric in (True, False):
+            want = oracle.scalar_linearize(2, tr, yr, x, numeric=numeric, dtype=dtype)
+            got = c.linearize(x, 2 if numeric else 0)
+            want = tuple(np.asarray(v, dtype=np.float64) for v in want)
+            check(got, want, tol=tol if tol else (fd_tolerance(x) if numeric else REL))
+
+    c = hip_lib.ScalarModelCost(hip_lib.capi.MODEL_POWELL)
+    x = np.array([3.0, -1.0, 0.0, 4.0])
+    cov = np.eye(4) * 0.01
+    for numeric in (True, False):
+        for cv in (None, cov):
+            c.set_covariance(cv)
+            want = oracle.scalar_linearize(3, None, None, x, numeric=numeric, cov=cv)
+            check(c.linearize(x, 2 if numeric else 0), want, tol=fd_tolerance(x) if numeric else REL)
+    assert abs(c.compute_cost(x) - want[2]) <= REL * want[2]
