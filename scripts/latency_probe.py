@@ -15,6 +15,7 @@ for n in (1000, 1_000_000, 10_000_000):
     src, tgt = make_shard_on_gpu(torch, n, 0, torch.float64)
     torch.cuda.synchronize()
     cost = mo.Point2PointCost(src.data_ptr(), tgt.data_ptr(), device_ptrs=True, count=n)
+    cost.set_speculation(False)
     for prof in (False, True):
         cost.set_profiling(prof)
         for what in ("linearize", "cost"):

@@ -34,6 +34,7 @@ def main():
         torch.cuda.synchronize()
         cost = mo.Point2PointCost(src.data_ptr(), tgt.data_ptr(), dtype=ndt, device_ptrs=True,
                                   count=n)
+        cost.set_speculation(False)  # time real sweeps, not answers from the kept result
         del src, tgt
         for bpc in args.bpc:
             os.environ["MOPT_BLOCKS_PER_CU"] = str(bpc)
