@@ -182,9 +182,11 @@ MOPT_API int mopt_cost_comm_init_rank(mopt_cost *cost, const void *id, int rank,
 
 /* ---- measurement -------------------------------------------------------------------------- */
 
-/* With profiling on, every sweep kernel launch is bracketed by HIP events on its stream.
- * mopt_cost_profile synchronises and reports the accumulated time of the dominant (sweep)
- * kernels and how many were launched since profiling was last switched on. */
+/* With profiling on, sweep kernel launches are bracketed by HIP events recorded on their stream:
+ * every launch when `enabled` is 1, every N-th launch when it is N > 1 (recording a pair costs the
+ * caller ~5 us, so sampling keeps a timed loop close to its un-instrumented speed).
+ * mopt_cost_profile synchronises and reports the accumulated time of the bracketed dominant (sweep)
+ * kernels and how many of them there were since profiling was last switched on. */
 MOPT_API int mopt_cost_set_profiling(mopt_cost *cost, int enabled);
 MOPT_API int mopt_cost_profile(mopt_cost *cost, double *sweep_ms_total, int64_t *sweep_launches);
 

@@ -220,7 +220,8 @@ class _CostBase:
         check(load().mopt_cost_synchronize(self._h))
 
     def set_profiling(self, enabled):
-        check(load().mopt_cost_set_profiling(self._h, 1 if enabled else 0))
+        """False/0 off; True/1 every sweep launch; N > 1 every N-th launch."""
+        check(load().mopt_cost_set_profiling(self._h, int(enabled)))
 
     def profile(self):
         ms = ctypes.c_double(0)

@@ -110,7 +110,8 @@ struct mopt_cost {
   long long stat_sweeps = 0;
   long long stat_cache_hits = 0;
 
-  bool profiling = false;
+  int profiling = 0;  // 0 off, N > 0: bracket every N-th sweep launch with events
+  long long profiling_tick = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
   std::vector<hipEvent_t> free_events;
   double sweep_ms_total = 0.0;
@@ -163,7 +164,7 @@ struct SweepTimer {
     static const int force = envInt("MOPT_STREAMING_LOADS", 0);  // 1 = never, 2 = always (tuning)
     const size_t bytes = size_t(cost->count) * 6 * size_t(cost->scalar_bytes);
     site.streaming = force == 2 || (force != 1 && bytes > (size_t(32) << 20));
-    if (!cost->profiling) return;
+    if (cost->profiling <= 0 || (cost->profiling_tick++ % cost->profiling) != 0) return;
     if (cost->pending_events.size() >= 4096 && resolvePendingEvents(cost) != MOPT_OK) return;
     hipEvent_t ev[2] = {nullptr, nullptr};
     for (auto &e : ev) {
@@ -961,7 +962,8 @@ int mopt_cost_set_profiling(mopt_cost *c, int enabled) {
   MOPT_HIP_TRY(hipSetDevice(c->device));
   const int rc = resolvePendingEvents(c);
   if (rc != MOPT_OK) return rc;
-  c->profiling = enabled != 0;
+  c->profiling = enabled > 0 ? enabled : 0;
+  c->profiling_tick = 0;
   c->sweep_ms_total = 0.0;
   c->sweep_launches = 0;
   return MOPT_OK;
