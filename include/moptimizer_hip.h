@@ -31,6 +31,8 @@
  *   - cov: m*m column-major (m = 3 point2point, m = 2 reprojection); NULL = identity.
  *   - device result layout of the async forms: double[n*n + n + 1] = H (column-major) | b | sum_sq,
  *     always fp64 whatever the cost's scalar.
+ *   - a mopt_cost (or mopt_group) is used by one thread at a time and runs one sweep at a time
+ *     (it owns one set of partial-sum buffers); different costs may be used concurrently.
  *   - every function returns MOPT_OK (0) or an error code; mopt_last_error() gives the text for
  *     the calling thread.  No call falls back to a CPU implementation: without a usable HIP
  *     device the create functions fail with MOPT_ERR_NO_DEVICE / MOPT_ERR_HIP.
@@ -105,6 +107,13 @@ MOPT_API const char *mopt_version(void);
 MOPT_API int mopt_point2point_create(mopt_cost **out, int device, int scalar_bytes,
                                      const void *src_xyz, const void *tgt_xyz, int64_t count,
                                      unsigned flags);
+
+/* Replace the correspondences of an existing point2point cost (same scalar type; any count) without
+ * rebuilding it — the service a model's `update(x)` needs when it re-matches correspondences every
+ * outer iteration (model.h:24-26, cost_function.h:42-44; the hook is empty in the reference's own
+ * models).  Re-lays the new arrays into the resident tiles, growing them if needed. */
+MOPT_API int mopt_point2point_set_data(mopt_cost *cost, const void *src_xyz, const void *tgt_xyz,
+                                       int64_t count, unsigned flags);
 
 /* Reprojection (camera-calibration) cost, fp64, numeric Jacobian only.  points_xyzw: packed
  * 4-vectors (32 B); pixels_uv: packed int32 pairs (8 B).  camera_3x4 / frame_4x4: row-major

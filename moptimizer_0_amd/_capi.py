@@ -47,6 +47,8 @@ def load():
         "mopt_device_count": [ctypes.POINTER(ctypes.c_int)],
         "mopt_point2point_create": [c_void_pp, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                     ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint],
+        "mopt_point2point_set_data": [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_int64, ctypes.c_uint],
         "mopt_reprojection_create": [c_void_pp, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_uint],
@@ -270,6 +272,17 @@ class Point2PointCost(_CostBase):
             check(load().mopt_point2point_create(ctypes.byref(self._h), device, self.scalar_bytes,
                                                  _ptr(src), _ptr(tgt), n, INPUT_HOST))
         self.count = n
+
+
+    def set_data(self, src, tgt):
+        """Replace the correspondences (host arrays) in place."""
+        dt = _dtype_of(self.scalar_bytes)
+        src = np.ascontiguousarray(src, dtype=dt).reshape(-1, 3)
+        tgt = np.ascontiguousarray(tgt, dtype=dt).reshape(-1, 3)
+        assert src.shape == tgt.shape
+        check(load().mopt_point2point_set_data(self._h, _ptr(src), _ptr(tgt), src.shape[0],
+                                               INPUT_HOST))
+        self.count = src.shape[0]
 
 
 class ReprojectionCost(_CostBase):

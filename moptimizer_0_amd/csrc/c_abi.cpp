@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -71,6 +72,7 @@ struct mopt_cost {
   int max_grid = 0;
 
   void *d_tiles = nullptr;
+  long long capacity_tiles = 0;  // tiles allocated in d_tiles
   double *d_partials = nullptr;
   double *d_result = nullptr;  // kResultDoubles
   // Mapped, fine-grained host memory the finalize kernel publishes into: 43 results + flag word.
@@ -489,6 +491,7 @@ int costAsyncImpl(mopt_cost *c, const void *x, double *d_sum, hipStream_t s,
 // into an error instead of an endless wait.
 int waitPublished(mopt_cost *c, unsigned long long sequence) {
   unsigned long long spins = 0;
+  const auto started = std::chrono::steady_clock::now();
   while (__atomic_load_n(c->h_flag, __ATOMIC_ACQUIRE) != sequence) {
     if ((++spins & 0x3fff) == 0) {
       const hipError_t q = hipStreamQuery(c->stream);
@@ -498,6 +501,9 @@ int waitPublished(mopt_cost *c, unsigned long long sequence) {
       }
       if (q != hipErrorNotReady)
         return fail(MOPT_ERR_HIP, std::string("sweep failed: ") + hipGetErrorString(q));
+      // a wedged device must not wedge the caller: give up after a generous bound
+      if (std::chrono::steady_clock::now() - started > std::chrono::seconds(60))
+        return fail(MOPT_ERR_HIP, "timed out waiting for the sweep result (60 s)");
     }
     __builtin_ia32_pause();
   }
@@ -665,14 +671,44 @@ int mopt_point2point_create(mopt_cost **out, int device, int scalar_bytes, const
   int rc = commonCreate(c.get(), device);
   if (rc != MOPT_OK) return rc;
 
-  const size_t tile_bytes = size_t(tile_points) * 6 * scalar_bytes;
-  if (c->num_tiles > 0) {
-    MOPT_HIP_TRY(hipMalloc(&c->d_tiles, tile_bytes * c->num_tiles));
+  rc = mopt_point2point_set_data(c.get(), src_xyz, tgt_xyz, count, flags);
+  if (rc != MOPT_OK) return rc;
+  c->state_version = 0;
+  *out = c.release();
+  return MOPT_OK;
+}
+
+int mopt_point2point_set_data(mopt_cost *c, const void *src_xyz, const void *tgt_xyz,
+                              int64_t count, unsigned flags) {
+  if (!c || c->model != kModelPoint2Point)
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "not a point2point cost");
+  if (count < 0 || (count > 0 && (!src_xyz || !tgt_xyz)))
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "bad point arrays / count");
+  MOPT_HIP_TRY(hipSetDevice(c->device));
+  const int tile_points = c->scalar_bytes == 8 ? mopt::TileShape<double>::kPoints
+                                               : mopt::TileShape<float>::kPoints;
+  const long long tiles = (count + tile_points - 1) / tile_points;
+  if (tiles > std::numeric_limits<int>::max())
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "count too large");
+  const size_t tile_bytes = size_t(tile_points) * 6 * c->scalar_bytes;
+  MOPT_HIP_TRY(hipStreamSynchronize(c->stream));
+  if (tiles > c->capacity_tiles) {
+    if (c->d_tiles) MOPT_HIP_TRY(hipFree(c->d_tiles));
+    c->d_tiles = nullptr;
+    c->capacity_tiles = 0;
+    MOPT_HIP_TRY(hipMalloc(&c->d_tiles, tile_bytes * size_t(tiles)));
+    c->capacity_tiles = tiles;
+  }
+  c->count = count;
+  c->num_tiles = int(tiles);
+  c->cache.valid = false;
+  c->state_version += 1;
+  if (tiles > 0) {
     Staging st;
-    const size_t bytes = size_t(count) * 3 * scalar_bytes;
-    rc = stageInputs(src_xyz, bytes, tgt_xyz, bytes, flags, c->stream, st);
+    const size_t bytes = size_t(count) * 3 * c->scalar_bytes;
+    const int rc = stageInputs(src_xyz, bytes, tgt_xyz, bytes, flags, c->stream, st);
     if (rc != MOPT_OK) return rc;
-    if (scalar_bytes == 8)
+    if (c->scalar_bytes == 8)
       MOPT_HIP_TRY(mopt::launchRelayoutP2P<double>(
           static_cast<const double *>(st.a), static_cast<const double *>(st.b), count,
           static_cast<double *>(c->d_tiles), c->num_tiles, c->stream));
@@ -682,7 +718,6 @@ int mopt_point2point_create(mopt_cost **out, int device, int scalar_bytes, const
           static_cast<float *>(c->d_tiles), c->num_tiles, c->stream));
     MOPT_HIP_TRY(hipStreamSynchronize(c->stream));
   }
-  *out = c.release();
   return MOPT_OK;
 }
 

@@ -465,3 +465,23 @@ def test_small_parametric_models_match_oracle(hip_lib, oracle):
             want = oracle.scalar_linearize(3, None, None, x, numeric=numeric, cov=cv)
             check(c.linearize(x, 2 if numeric else 0), want, tol=fd_tolerance(x) if numeric else REL)
     assert abs(c.compute_cost(x) - want[2]) <= REL * want[2]
+
+
+def test_set_data_replaces_correspondences(hip_lib, oracle):
+    """mopt_point2point_set_data: new correspondences (smaller, equal and larger count) in an
+    existing cost; the kept linearization must not leak across the change."""
+    x = ds.X_GENERIC
+    src, tgt = ds.synthetic_pair(5000, seed=31, noise=0.02)
+    cost = hip_lib.Point2PointCost(src, tgt)
+    check(cost.linearize(x, 0), oracle_ref(oracle, src, tgt, x, 0))
+    for n, seed in ((1200, 32), (5000, 33), (20_000, 34), (0, 35)):
+        s2, t2 = ds.synthetic_pair(max(n, 1), seed=seed, noise=0.02)
+        s2, t2 = s2[:n], t2[:n]
+        cost.set_data(s2, t2)
+        H, b, s = cost.linearize(x, 0)
+        if n == 0:
+            assert not H.any() and s == 0.0
+        else:
+            check((H, b, s), oracle_ref(oracle, s2, t2, x, 0))
+            want = oracle.p2p_cost(s2, t2, x)
+            assert abs(cost.compute_cost(x) - want) <= REL * want
