@@ -68,6 +68,8 @@ class DeviceModel : public IBaseModel<Scalar> {
   virtual mopt_cost *createDeviceCost(int device, int num_residuals) const = 0;
   virtual int numOutputs() const = 0;
   virtual int numParameters() const { return 6; }
+  // The cost hands its device handle to the model so that model->update(x) can act on it.
+  virtual void attach(mopt_cost *) {}
 };
 
 // The Point2Point model of tst/point2point.cpp:24-84: residual R(x) p + t(x) - q over
@@ -96,6 +98,43 @@ class Point2PointDeviceModel : public DeviceModel<Scalar> {
   const Scalar *src_;
   const Scalar *tgt_;
   std::size_t count_;
+};
+
+// Point-to-point ICP with correspondence search: update(x) — which the optimizer calls through
+// cost->update(x) at the top of every outer iteration (levenberg_marquadt_dyn.cpp:54) — re-matches
+// every source point to its nearest target under the current pose, on the GPU.
+template <typename Scalar>
+class IcpDeviceModel : public DeviceModel<Scalar> {
+ public:
+  using Ptr = std::shared_ptr<IcpDeviceModel>;
+  IcpDeviceModel(const Scalar *src_xyz, std::size_t num_src, const Scalar *tgt_xyz,
+                 std::size_t num_tgt, double max_distance)
+      : src_(src_xyz), tgt_(tgt_xyz), num_src_(num_src), num_tgt_(num_tgt),
+        max_distance_(max_distance) {}
+  typename IBaseModel<Scalar>::Ptr clone() const override {
+    return std::make_shared<IcpDeviceModel>(*this);
+  }
+  mopt_cost *createDeviceCost(int device, int num_residuals) const override {
+    if (num_residuals < 0 || std::size_t(num_residuals) > num_src_)
+      throw Exception("IcpDeviceModel: num_residuals exceeds the source cloud size");
+    mopt_cost *h = nullptr;
+    throwOnError(mopt_icp_create(&h, device, int(sizeof(Scalar)), src_, num_residuals, tgt_,
+                                 std::int64_t(num_tgt_), max_distance_),
+                 "mopt_icp_create");
+    return h;
+  }
+  int numOutputs() const override { return 3; }
+  void attach(mopt_cost *handle) override { handle_ = handle; }
+  void update(const Scalar *x) override {
+    if (handle_) throwOnError(mopt_icp_update(handle_, x, nullptr), "mopt_icp_update");
+  }
+
+ private:
+  const Scalar *src_;
+  const Scalar *tgt_;
+  std::size_t num_src_, num_tgt_;
+  double max_distance_;
+  mopt_cost *handle_ = nullptr;
 };
 
 // The CameraModel of tst/camera_calibration.cpp:12-57 (fp64, no Jacobian).
@@ -203,7 +242,7 @@ class CostFunctionHip : public CostFunctionBase<Scalar> {
   CostFunctionHip(ModelPtr model, int num_parameters, int num_outputs, int num_residuals,
                   int device = 0)
       : Base(model, num_residuals), num_parameters_(num_parameters), num_outputs_(num_outputs) {
-    auto *dm = dynamic_cast<const DeviceModel<Scalar> *>(model.get());
+    auto *dm = dynamic_cast<DeviceModel<Scalar> *>(model.get());
     if (!dm)
       throw Exception(
           "CostFunctionHip needs a device model (Point2PointDeviceModel / "
@@ -211,6 +250,7 @@ class CostFunctionHip : public CostFunctionBase<Scalar> {
     if (num_parameters != dm->numParameters() || num_outputs != dm->numOutputs())
       throw Exception("CostFunctionHip: (num_parameters, num_outputs) do not match the device model");
     handle_ = dm->createDeviceCost(device, num_residuals);
+    dm->attach(handle_);
     this->covariance_->resize(num_outputs_, num_outputs_);
     this->covariance_->setIdentity();
   }

@@ -115,6 +115,23 @@ MOPT_API int mopt_point2point_create(mopt_cost **out, int device, int scalar_byt
 MOPT_API int mopt_point2point_set_data(mopt_cost *cost, const void *src_xyz, const void *tgt_xyz,
                                        int64_t count, unsigned flags);
 
+/* ---- ICP with correspondence search on the GPU (the model's update(x) step) ------------------
+ * The reference calls cost->update(x) -> model->update(x) at the top of every outer LM iteration
+ * (src/levenberg_marquadt_dyn.cpp:54, include/moptimizer/cost_function.h:42-44) "i.e registration
+ * correspondences" (model.h:24-26), but ships no model that implements it.  Semantics here: for each
+ * source point p, the target nearest to R(x) p + t(x) in Euclidean distance, if within max_distance;
+ * sources without one are skipped by the sweeps exactly as an index whose f() returns false
+ * (linearization.h:102,144).  mopt_icp_create builds a point2point cost over `num_src` sources
+ * whose targets are (re)chosen from the `num_tgt`-point target cloud by every mopt_icp_update; all
+ * cost calls (linearize / compute / covariance / loss) apply unchanged.  Host arrays, packed xyz. */
+MOPT_API int mopt_icp_create(mopt_cost **out, int device, int scalar_bytes, const void *src_xyz,
+                             int64_t num_src, const void *tgt_xyz, int64_t num_tgt,
+                             double max_distance);
+MOPT_API int mopt_icp_update(mopt_cost *cost, const void *x, int64_t *num_matched /* may be NULL */);
+/* current target of every source as packed xyz (NaN triple where unmatched); host buffer of
+ * num_src * 3 scalars.  Works for any point2point cost. */
+MOPT_API int mopt_icp_get_matches(mopt_cost *cost, void *tgt_out_xyz);
+
 /* Reprojection (camera-calibration) cost, fp64, numeric Jacobian only.  points_xyzw: packed
  * 4-vectors (32 B); pixels_uv: packed int32 pairs (8 B).  camera_3x4 / frame_4x4: row-major
  * constants (tst/camera_calibration.cpp:22-30); NULL selects the reference's values. */

@@ -15,6 +15,7 @@ from ._capi import (  # noqa: F401
     KERNEL_MOMENTS,
     LOSS_GEMAN_MCCLURE,
     LOSS_NONE,
+    IcpCost,
     MoptError,
     Point2PointCost,
     Point2PointGroup,

@@ -49,6 +49,10 @@ def load():
                                     ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint],
         "mopt_point2point_set_data": [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_int64, ctypes.c_uint],
+        "mopt_icp_create": [c_void_pp, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64,
+                            ctypes.c_void_p, ctypes.c_int64, ctypes.c_double],
+        "mopt_icp_update": [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)],
+        "mopt_icp_get_matches": [ctypes.c_void_p, ctypes.c_void_p],
         "mopt_reprojection_create": [c_void_pp, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_uint],
@@ -283,6 +287,32 @@ class Point2PointCost(_CostBase):
         check(load().mopt_point2point_set_data(self._h, _ptr(src), _ptr(tgt), src.shape[0],
                                                INPUT_HOST))
         self.count = src.shape[0]
+
+
+class IcpCost(Point2PointCost):
+    """Point-to-point cost whose correspondences are re-searched on the GPU: update(x) is the
+    model's update step (nearest target of the warped source within max_distance)."""
+
+    def __init__(self, src, tgt, max_distance, device=0, dtype=np.float64):
+        _CostBase.__init__(self)
+        self.scalar_bytes = np.dtype(dtype).itemsize
+        self.n_out = 3
+        src = np.ascontiguousarray(src, dtype=dtype).reshape(-1, 3)
+        tgt = np.ascontiguousarray(tgt, dtype=dtype).reshape(-1, 3)
+        check(load().mopt_icp_create(ctypes.byref(self._h), device, self.scalar_bytes, _ptr(src),
+                                     src.shape[0], _ptr(tgt), tgt.shape[0], float(max_distance)))
+        self.count = src.shape[0]
+
+    def update(self, x, count_matches=True):
+        x = np.ascontiguousarray(x, dtype=_dtype_of(self.scalar_bytes))
+        n = ctypes.c_int64(-1)
+        check(load().mopt_icp_update(self._h, _ptr(x), ctypes.byref(n) if count_matches else None))
+        return n.value
+
+    def matches(self):
+        out = np.zeros((self.count, 3), dtype=_dtype_of(self.scalar_bytes))
+        check(load().mopt_icp_get_matches(self._h, _ptr(out)))
+        return out
 
 
 class ReprojectionCost(_CostBase):

@@ -58,6 +58,18 @@ int envInt(const char *name, int fallback) {
 
 }  // namespace
 
+// Uniform grid over the target cloud of an ICP cost (built once on the host, resident in HBM).
+struct IcpMatcher {
+  void *d_sorted = nullptr;      // [num_targets][4] scalars grouped by cell
+  int *d_cell_start = nullptr;   // [cells + 1]
+  unsigned int *d_matched = nullptr;
+  double origin[3] = {0, 0, 0};
+  double cell = 1.0;
+  int dims[3] = {1, 1, 1};
+  double max_dist = 0.0;
+  long long num_targets = 0;
+};
+
 struct mopt_cost {
   int device = 0;
   int scalar_bytes = 8;
@@ -94,6 +106,8 @@ struct mopt_cost {
 
   double camera[12];
   double frame[16];
+
+  std::unique_ptr<IcpMatcher> matcher;  // point2point costs created by mopt_icp_create
 
   // LM calls computeCost(xi) and, when the step is accepted, linearize(xi) right after
   // (levenberg_marquadt_dyn.cpp:86,112 then :55): with speculation on, computeCost runs the
@@ -593,6 +607,11 @@ void destroyCost(mopt_cost *c) {
   }
   for (auto e : c->free_events) (void)hipEventDestroy(e);
   if (c->comm) ncclCommDestroy(c->comm);
+  if (c->matcher) {
+    if (c->matcher->d_sorted) (void)hipFree(c->matcher->d_sorted);
+    if (c->matcher->d_cell_start) (void)hipFree(c->matcher->d_cell_start);
+    if (c->matcher->d_matched) (void)hipFree(c->matcher->d_matched);
+  }
   if (c->d_tiles) (void)hipFree(c->d_tiles);
   if (c->d_partials) (void)hipFree(c->d_partials);
   if (c->d_result) (void)hipFree(c->d_result);
@@ -718,6 +737,160 @@ int mopt_point2point_set_data(mopt_cost *c, const void *src_xyz, const void *tgt
           static_cast<float *>(c->d_tiles), c->num_tiles, c->stream));
     MOPT_HIP_TRY(hipStreamSynchronize(c->stream));
   }
+  return MOPT_OK;
+}
+
+}  // extern "C"
+
+namespace {
+// Counting sort of the targets into grid cells (host, once per target cloud).
+template <typename S>
+int buildIcpGrid(mopt_cost *c, const S *tgt, long long m, double max_distance) {
+  auto mt = std::make_unique<IcpMatcher>();
+  mt->max_dist = max_distance;
+  mt->num_targets = m;
+  double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  for (long long i = 0; i < m; ++i)
+    for (int a = 0; a < 3; ++a) {
+      const double v = double(tgt[3 * i + a]);
+      if (i == 0 || v < lo[a]) lo[a] = v;
+      if (i == 0 || v > hi[a]) hi[a] = v;
+    }
+  // cell edge a hair above the search radius, so the 27 cells around a query hold every target
+  // within it; enlarged when the box would need more than ~4 M cells
+  double cell = max_distance * 1.001;
+  for (;;) {
+    double cells = 1.0;
+    for (int a = 0; a < 3; ++a) cells *= std::floor((hi[a] - lo[a]) / cell) + 1.0;
+    if (cells <= double(1 << 22)) break;
+    cell *= 1.26;
+  }
+  mt->cell = cell;
+  long long ncells = 1;
+  for (int a = 0; a < 3; ++a) {
+    mt->origin[a] = lo[a];
+    mt->dims[a] = int(std::floor((hi[a] - lo[a]) / cell)) + 1;
+    ncells *= mt->dims[a];
+  }
+  std::vector<int> start(size_t(ncells) + 1, 0);
+  std::vector<int> cell_of(static_cast<size_t>(m));
+  for (long long i = 0; i < m; ++i) {
+    long long id = 0, stride = 1;
+    for (int a = 0; a < 3; ++a) {
+      int g = int(std::floor((double(tgt[3 * i + a]) - lo[a]) / cell));
+      g = g < 0 ? 0 : (g >= mt->dims[a] ? mt->dims[a] - 1 : g);
+      id += g * stride;
+      stride *= mt->dims[a];
+    }
+    cell_of[size_t(i)] = int(id);
+    start[size_t(id) + 1] += 1;
+  }
+  for (size_t k = 0; k < size_t(ncells); ++k) start[k + 1] += start[k];
+  std::vector<int> cursor(start.begin(), start.end() - 1);
+  std::vector<S> sorted(size_t(m) * 4, S(0));
+  for (long long i = 0; i < m; ++i) {  // stable: original order inside a cell
+    const size_t dst = size_t(cursor[size_t(cell_of[size_t(i)])]++);
+    for (int a = 0; a < 3; ++a) sorted[dst * 4 + a] = tgt[3 * i + a];
+  }
+  if (m > 0) {
+    MOPT_HIP_TRY(hipMalloc(&mt->d_sorted, sorted.size() * sizeof(S)));
+    MOPT_HIP_TRY(hipMemcpy(mt->d_sorted, sorted.data(), sorted.size() * sizeof(S),
+                           hipMemcpyHostToDevice));
+  }
+  MOPT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&mt->d_cell_start), start.size() * sizeof(int)));
+  MOPT_HIP_TRY(hipMemcpy(mt->d_cell_start, start.data(), start.size() * sizeof(int),
+                         hipMemcpyHostToDevice));
+  MOPT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&mt->d_matched), 64));
+  c->matcher = std::move(mt);
+  return MOPT_OK;
+}
+
+template <typename S>
+int icpUpdate(mopt_cost *c, const S *x, int64_t *num_matched) {
+  const IcpMatcher &mt = *c->matcher;
+  mopt::IcpMatchArgs<S> a;
+  a.tiles = static_cast<S *>(c->d_tiles);
+  a.count = c->count;
+  a.num_tiles = c->num_tiles;
+  a.sorted = static_cast<const S *>(mt.d_sorted);
+  a.cell_start = mt.d_cell_start;
+  for (int k = 0; k < 3; ++k) {
+    a.origin[k] = S(mt.origin[k]);
+    a.dims[k] = mt.dims[k];
+  }
+  a.inv_cell = S(1.0 / mt.cell);
+  a.max_dist2 = S(mt.max_dist * mt.max_dist);
+  const auto T = moptimizer::so3::rigidFrom6DOF<S>(x);
+  std::memcpy(a.T, T.m, sizeof T.m);
+  a.matched = num_matched ? mt.d_matched : nullptr;
+  if (num_matched) MOPT_HIP_TRY(hipMemsetAsync(mt.d_matched, 0, sizeof(unsigned int), c->stream));
+  MOPT_HIP_TRY(mopt::launchIcpMatch<S>(a, c->stream));
+  c->cache.valid = false;
+  c->state_version += 1;
+  if (num_matched) {
+    unsigned int n = 0;
+    MOPT_HIP_TRY(hipMemcpyAsync(&n, mt.d_matched, sizeof n, hipMemcpyDeviceToHost, c->stream));
+    MOPT_HIP_TRY(hipStreamSynchronize(c->stream));
+    *num_matched = int64_t(n);
+  }
+  return MOPT_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int mopt_icp_create(mopt_cost **out, int device, int scalar_bytes, const void *src_xyz,
+                    int64_t num_src, const void *tgt_xyz, int64_t num_tgt, double max_distance) {
+  if (!out) return fail(MOPT_ERR_INVALID_ARGUMENT, "out is NULL");
+  *out = nullptr;
+  if (num_src < 0 || num_tgt < 0 || (num_src > 0 && !src_xyz) || (num_tgt > 0 && !tgt_xyz) ||
+      num_tgt > std::numeric_limits<int>::max())
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "bad clouds");
+  if (!(max_distance > 0.0)) return fail(MOPT_ERR_INVALID_ARGUMENT, "max_distance must be > 0");
+  mopt_cost *raw = nullptr;
+  // the source goes into the resident tiles; the target planes are filled by the first search
+  int rc = mopt_point2point_create(&raw, device, scalar_bytes, src_xyz, src_xyz, num_src,
+                                   MOPT_INPUT_HOST);
+  if (rc != MOPT_OK) return rc;
+  std::unique_ptr<mopt_cost, void (*)(mopt_cost *)> c(raw, destroyCost);
+  rc = scalar_bytes == 8
+           ? buildIcpGrid<double>(c.get(), static_cast<const double *>(tgt_xyz), num_tgt, max_distance)
+           : buildIcpGrid<float>(c.get(), static_cast<const float *>(tgt_xyz), num_tgt, max_distance);
+  if (rc != MOPT_OK) return rc;
+  const double zero8[6] = {0, 0, 0, 0, 0, 0};
+  const float zero4[6] = {0, 0, 0, 0, 0, 0};
+  rc = mopt_icp_update(c.get(), scalar_bytes == 8 ? static_cast<const void *>(zero8)
+                                                   : static_cast<const void *>(zero4), nullptr);
+  if (rc != MOPT_OK) return rc;
+  *out = c.release();
+  return MOPT_OK;
+}
+
+int mopt_icp_update(mopt_cost *c, const void *x, int64_t *num_matched) {
+  if (!c || !x) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (!c->matcher) return fail(MOPT_ERR_INVALID_ARGUMENT, "not a cost made by mopt_icp_create");
+  MOPT_HIP_TRY(hipSetDevice(c->device));
+  return c->scalar_bytes == 8 ? icpUpdate<double>(c, static_cast<const double *>(x), num_matched)
+                              : icpUpdate<float>(c, static_cast<const float *>(x), num_matched);
+}
+
+int mopt_icp_get_matches(mopt_cost *c, void *tgt_out_xyz) {
+  if (!c || !tgt_out_xyz) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (c->model != kModelPoint2Point) return fail(MOPT_ERR_INVALID_ARGUMENT, "not a point2point cost");
+  MOPT_HIP_TRY(hipSetDevice(c->device));
+  if (c->count == 0) return MOPT_OK;
+  const size_t bytes = size_t(c->count) * 3 * c->scalar_bytes;
+  void *d_tmp = nullptr;
+  MOPT_HIP_TRY(hipMalloc(&d_tmp, bytes));
+  hipError_t e = c->scalar_bytes == 8
+                     ? mopt::launchGatherTargets<double>(static_cast<const double *>(c->d_tiles),
+                                                         c->count, static_cast<double *>(d_tmp), c->stream)
+                     : mopt::launchGatherTargets<float>(static_cast<const float *>(c->d_tiles),
+                                                        c->count, static_cast<float *>(d_tmp), c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(tgt_out_xyz, d_tmp, bytes, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d_tmp);
+  if (e != hipSuccess) return fail(MOPT_ERR_HIP, std::string("gather: ") + hipGetErrorString(e));
   return MOPT_OK;
 }
 

@@ -90,6 +90,24 @@ struct ScalarSweepArgs {
   double *partials;
 };
 
+// Correspondence search (the model's update(x) step for ICP): targets binned into a uniform grid
+// (cell edge >= the maximum correspondence distance, so the 27 cells around a query hold every
+// candidate), stored cell by cell as padded 4-vectors with a prefix table of cell starts.
+template <typename S>
+struct IcpMatchArgs {
+  S *tiles;               // point2point tile layout: source planes read, target planes written
+  long long count;
+  int num_tiles;
+  const S *sorted;        // [num_targets][4]  (x, y, z, unused), grouped by cell
+  const int *cell_start;  // [cells + 1]
+  S origin[3];
+  S inv_cell;
+  int dims[3];
+  S max_dist2;
+  S T[12];                // row-major [R | t] applied to the source before the search
+  unsigned int *matched;  // optional counter of matched sources
+};
+
 // Where a sweep kernel is launched.
 struct LaunchSite {
   hipStream_t stream = nullptr;
@@ -139,6 +157,14 @@ hipError_t launchFinalizeCost(const double *partials, int grid, double *result,
 template <typename S>
 hipError_t launchScalarModel(const ScalarSweepArgs<S> &args, int model, bool cost_only,
                              int jac_mode, int cov_mode, int grid, hipStream_t stream);
+
+// For every source point i: nearest target of T p_i within max_dist -> target planes of slot i
+// (NaN marker when there is none).
+template <typename S>
+hipError_t launchIcpMatch(const IcpMatchArgs<S> &args, hipStream_t stream);
+// target planes of the tile layout -> packed xyz (NaN where unmatched); for inspection / tests
+template <typename S>
+hipError_t launchGatherTargets(const S *tiles, long long count, S *out_xyz, hipStream_t stream);
 
 // device result (count doubles) -> mapped host memory + flag (after a collective)
 hipError_t launchPublish(const double *d_values, int count, const HostPublish &pub,

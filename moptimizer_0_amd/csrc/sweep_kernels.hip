@@ -67,6 +67,15 @@ __device__ __forceinline__ void p2pResidual(const S (&T)[12], const S (&p)[3], c
   }
 }
 
+// A slot of the tile layout holds a correspondence when its index is inside the data set and
+// its target is not the NaN marker — the device form of the model's `f` returning false for an
+// index (model.h:32, linearization.h:102,144): padding, and source points the correspondence
+// search (icpMatchKernel) left unmatched.
+template <typename S>
+__device__ __forceinline__ bool isCorrespondence(long long index, long long count, S target_x) {
+  return index < count && target_x == target_x;
+}
+
 // Walks this workgroup's tiles (blockIdx.x, + gridDim.x, ...) with two register sets used in
 // ping-pong: the six 16-byte loads of the NEXT tile are issued into the idle set before the
 // arithmetic of the current one starts, and nothing is ever copied between the sets.
@@ -272,8 +281,9 @@ __global__ __launch_bounds__(kBlockThreads) void p2pLinearizeLiteralKernel(
 #pragma unroll
     for (int e = 0; e < V; ++e) {
       const S p[3] = {cur[0].v[e], cur[1].v[e], cur[2].v[e]};
-      const S q[3] = {cur[3].v[e], cur[4].v[e], cur[5].v[e]};
-      p2pPointLiteral<S, JAC, COV>(A, p, q, first + e < A.count, acc);
+      const bool ok = isCorrespondence(first + e, A.count, cur[3].v[e]);
+      const S q[3] = {ok ? cur[3].v[e] : S(0), ok ? cur[4].v[e] : S(0), ok ? cur[5].v[e] : S(0)};
+      p2pPointLiteral<S, JAC, COV>(A, p, q, ok, acc);
     }
   });
   blockReduceStore<NACC>(acc, A.partials + size_t(blockIdx.x) * NACC);
@@ -296,10 +306,11 @@ __global__ __launch_bounds__(kBlockThreads) void p2pMomentsKernel(const P2PSweep
 #pragma unroll
     for (int e = 0; e < V; ++e) {
       const S p[3] = {cur[0].v[e], cur[1].v[e], cur[2].v[e]};
-      const S q[3] = {cur[3].v[e], cur[4].v[e], cur[5].v[e]};
+      const bool valid = isCorrespondence(first + e, A.count, cur[3].v[e]);
+      const S q[3] = {valid ? cur[3].v[e] : S(0), valid ? cur[4].v[e] : S(0),
+                      valid ? cur[5].v[e] : S(0)};
       S r[3];
       p2pResidual<S>(A.T[0], p, q, r);
-      const bool valid = first + e < A.count;
       S rr = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
       S w = lossWeight<S>(A.loss_kind, A.loss_param, rr);
       w = valid ? w : S(0);
@@ -338,11 +349,13 @@ __global__ __launch_bounds__(kBlockThreads) void p2pCostKernel(const P2PSweepArg
 #pragma unroll
     for (int e = 0; e < V; ++e) {
       const S p[3] = {cur[0].v[e], cur[1].v[e], cur[2].v[e]};
-      const S q[3] = {cur[3].v[e], cur[4].v[e], cur[5].v[e]};
+      const bool valid = isCorrespondence(first + e, A.count, cur[3].v[e]);
+      const S q[3] = {valid ? cur[3].v[e] : S(0), valid ? cur[4].v[e] : S(0),
+                      valid ? cur[5].v[e] : S(0)};
       S r[3];
       p2pResidual<S>(A.T[0], p, q, r);
       const S rr = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
-      acc[0] += (first + e < A.count) ? double(rr) : 0.0;
+      acc[0] += valid ? double(rr) : 0.0;
     }
   });
   blockReduceStore<1>(acc, A.partials + blockIdx.x);
@@ -504,6 +517,86 @@ __global__ __launch_bounds__(kBlockThreads) void scalarModelKernel(const ScalarS
     }
   }
   blockReduceStore<NACC>(acc, A.partials + size_t(blockIdx.x) * NACC);
+}
+
+// ---- correspondence search (ICP update step) ---------------------------------------------------
+// One thread per source point: warp it with the current pose, visit the 27 grid cells around it,
+// keep the nearest target within the maximum distance, and write that target into the target
+// planes of the point's slot (or the NaN marker).  The reference leaves this step to the user
+// model's update(x) (model.h:24-26; "setup can be i.e nearest neighboor search", docs/Cost.puml:14-17)
+// and ships no implementation, so semantics are defined here: exact nearest neighbour in the
+// Euclidean metric, ties resolved to the first candidate in (cell z, y, x; original index) order.
+template <typename S>
+__global__ __launch_bounds__(kBlockThreads) void icpMatchKernel(const IcpMatchArgs<S> A) {
+  constexpr int TP = TileShape<S>::kPoints;
+  const long long i = (long long)blockIdx.x * kBlockThreads + threadIdx.x;
+  if (i >= (long long)A.num_tiles * TP) return;
+  S *slot = A.tiles + (i / TP) * TileShape<S>::kP2PScalars + (i % TP);
+  bool found = false;
+  S best[3] = {S(0), S(0), S(0)};
+  if (i < A.count) {
+    const S p[3] = {slot[0 * TP], slot[1 * TP], slot[2 * TP]};
+    S w[3], g[3];
+    bool inside = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      w[a] = ((A.T[a * 4 + 0] * p[0] + A.T[a * 4 + 1] * p[1]) + A.T[a * 4 + 2] * p[2]) + A.T[a * 4 + 3];
+      g[a] = floor((w[a] - A.origin[a]) * A.inv_cell);
+      inside = inside && g[a] >= S(-1) && g[a] <= S(A.dims[a]);
+    }
+    if (inside) {
+      const int c[3] = {int(g[0]), int(g[1]), int(g[2])};
+      S best_d = A.max_dist2;
+      for (int dz = -1; dz <= 1; ++dz) {
+        const int z = c[2] + dz;
+        if (z < 0 || z >= A.dims[2]) continue;
+        for (int dy = -1; dy <= 1; ++dy) {
+          const int y = c[1] + dy;
+          if (y < 0 || y >= A.dims[1]) continue;
+          // the three x-neighbours are consecutive cells: one contiguous candidate range
+          const int x0 = c[0] - 1 < 0 ? 0 : c[0] - 1;
+          const int x1 = c[0] + 1 >= A.dims[0] ? A.dims[0] - 1 : c[0] + 1;
+          if (x0 > x1) continue;
+          const long long row = ((long long)z * A.dims[1] + y) * A.dims[0];
+          const int begin = A.cell_start[row + x0], end = A.cell_start[row + x1 + 1];
+          for (int k = begin; k < end; ++k) {
+            const Pack<S> *cand = reinterpret_cast<const Pack<S> *>(A.sorted + size_t(k) * 4);
+            S q[4];
+            if (sizeof(S) == 8) {
+              const Pack<S> lo = cand[0], hi = cand[1];
+              q[0] = lo.v[0]; q[1] = lo.v[1]; q[2] = hi.v[0];
+            } else {
+              const Pack<S> all = cand[0];
+              q[0] = all.v[0]; q[1] = all.v[1]; q[2] = all.v[2];
+            }
+            const S d0 = w[0] - q[0], d1 = w[1] - q[1], d2 = w[2] - q[2];
+            const S dist = d0 * d0 + d1 * d1 + d2 * d2;
+            if (dist <= A.max_dist2 && (!found || dist < best_d)) {
+              found = true;
+              best_d = dist;
+              best[0] = q[0]; best[1] = q[1]; best[2] = q[2];
+            }
+          }
+        }
+      }
+    }
+  }
+  const S nan = S(__builtin_nan(""));
+  slot[3 * TP] = found ? best[0] : nan;
+  slot[4 * TP] = found ? best[1] : nan;
+  slot[5 * TP] = found ? best[2] : nan;
+  if (found && A.matched) atomicAdd(A.matched, 1u);
+}
+
+template <typename S>
+__global__ void gatherTargetsKernel(const S *__restrict__ tiles, long long count,
+                                    S *__restrict__ out_xyz) {
+  constexpr int TP = TileShape<S>::kPoints;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const S *slot = tiles + (i / TP) * TileShape<S>::kP2PScalars + (i % TP);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) out_xyz[3 * i + k] = slot[(3 + k) * TP];
 }
 
 // ---- layout conversion (once per data set) -----------------------------------------------------
@@ -896,6 +989,28 @@ template hipError_t launchScalarModel<float>(const ScalarSweepArgs<float> &, int
                                              int, hipStream_t);
 template hipError_t launchScalarModel<double>(const ScalarSweepArgs<double> &, int, bool, int, int,
                                               int, hipStream_t);
+
+template <typename S>
+hipError_t launchIcpMatch(const IcpMatchArgs<S> &args, hipStream_t stream) {
+  const long long padded = (long long)args.num_tiles * TileShape<S>::kPoints;
+  if (padded == 0) return hipSuccess;
+  const unsigned blocks = unsigned((padded + kBlockThreads - 1) / kBlockThreads);
+  hipLaunchKernelGGL((icpMatchKernel<S>), dim3(blocks), dim3(kBlockThreads), 0, stream, args);
+  return hipGetLastError();
+}
+template hipError_t launchIcpMatch<float>(const IcpMatchArgs<float> &, hipStream_t);
+template hipError_t launchIcpMatch<double>(const IcpMatchArgs<double> &, hipStream_t);
+
+template <typename S>
+hipError_t launchGatherTargets(const S *tiles, long long count, S *out_xyz, hipStream_t stream) {
+  if (count == 0) return hipSuccess;
+  const unsigned blocks = unsigned((count + 255) / 256);
+  hipLaunchKernelGGL((gatherTargetsKernel<S>), dim3(blocks), dim3(256), 0, stream, tiles, count,
+                     out_xyz);
+  return hipGetLastError();
+}
+template hipError_t launchGatherTargets<float>(const float *, long long, float *, hipStream_t);
+template hipError_t launchGatherTargets<double>(const double *, long long, double *, hipStream_t);
 
 hipError_t launchPublish(const double *d_values, int count, const HostPublish &pub,
                          hipStream_t stream) {

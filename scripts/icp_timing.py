@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Correspondence-search (update step) timing: N sources against N targets in a box whose density
+gives ~`per_cell` targets per grid cell."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import moptimizer_0_amd as mo
+
+for n, per_cell in ((1_000_000, 1.0), (1_000_000, 4.0), (4_000_000, 1.0)):
+    rng = np.random.default_rng(1)
+    side = 100.0
+    tgt = rng.random((n, 3)) * side
+    src = tgt[rng.permutation(n)] + rng.normal(0, 0.01, (n, 3))
+    max_dist = side * (per_cell / n) ** (1.0 / 3.0)
+    t0 = time.perf_counter()
+    cost = mo.IcpCost(src, tgt, max_dist)
+    build = time.perf_counter() - t0
+    x = np.array([0.01, -0.01, 0.02, 0.001, -0.002, 0.001])
+    cost.update(x)
+    ts = []
+    for _ in range(10):
+        t0 = time.perf_counter(); m = cost.update(x); ts.append(time.perf_counter() - t0)
+    dt = float(np.median(ts))
+    print("n=%d targets/cell~%.0f max_dist=%.3f: create (host grid build + upload) %.0f ms; "
+          "update %.3f ms = %.2e sources/s, %d matched" % (n, per_cell, max_dist, build * 1e3, dt * 1e3, n / dt, m), flush=True)
+    cost.close()

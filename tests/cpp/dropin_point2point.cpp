@@ -20,6 +20,7 @@
 #include "test_models.hpp"   // oracle (test infrastructure)
 #include "moptimizer_amd/cost_function_hip.hpp"
 #include "moptimizer_amd/levenberg_marquadt.hpp"
+#include "moptimizer_amd/so3.hpp"
 
 using Scalar = double;
 namespace mh = moptimizer::hip;
@@ -184,6 +185,29 @@ int main(int argc, char **argv) {
       const Scalar sc = nu_s.linearize(x0, Ha, ba), sd = nu_d.linearize(x0, Hb, bb);
       expectTrue(sc == sd && relErr(Ha, Hb, 36) == 0.0, "static == dynamic numeric (HIP)", sc, sd);
       expectTrue(std::fabs(sa - sc) <= 1e-7 * sa, "sum analytic == sum numeric (1e-7 rel)", sa, sc);
+    }
+
+    // ---- ICP: correspondences unknown, re-searched by model->update(x) inside the LM loop ----
+    {
+      // target = the cloud moved by a small pose, in reversed order (index alignment destroyed)
+      const double xt[6] = {0.15, -0.10, 0.05, 0.02, -0.01, 0.03};
+      double Tt[16];
+      moptimizer::so3::convert6DOFParameterToMatrix<double>(xt, Tt);
+      std::vector<Scalar> moved(src.size());
+      for (int i = 0; i < n; ++i)
+        for (int r = 0; r < 3; ++r)
+          moved[3 * (n - 1 - i) + r] = Tt[0 * 4 + r] * src[3 * i] + Tt[1 * 4 + r] * src[3 * i + 1] +
+                                       Tt[2 * 4 + r] * src[3 * i + 2] + Tt[3 * 4 + r];
+      auto icp = std::make_shared<mh::IcpDeviceModel<Scalar>>(src.data(), n, moved.data(), n, 1.0);
+      mh::CostFunctionAnalyticalHip<Scalar> cost(icp, 6, 3, n);
+      moptimizer::LevenbergMarquadtDynamic<Scalar> lm(6);
+      lm.setMaximumIterations(60);
+      lm.addCost(&cost);
+      double x[6] = {0, 0, 0, 0, 0, 0};
+      lm.minimize(x);   // every outer iteration: cost.update(x) -> GPU nearest-neighbour search
+      double e = 0;
+      for (int i = 0; i < 6; ++i) e = std::max(e, std::fabs(x[i] - xt[i]));
+      expectTrue(e < 1e-5, "ICP with GPU correspondence search recovers the pose", e, 1e-5);
     }
 
     // ---- a host model is refused, not silently run on the CPU ----------------------------

@@ -485,3 +485,76 @@ def test_set_data_replaces_correspondences(hip_lib, oracle):
             check((H, b, s), oracle_ref(oracle, s2, t2, x, 0))
             want = oracle.p2p_cost(s2, t2, x)
             assert abs(cost.compute_cost(x) - want) <= REL * want
+
+
+def _brute_force_matches(src, tgt, x, max_dist):
+    T = np.eye(4)
+    th = np.linalg.norm(x[3:])
+    if th > 0:
+        a = x[3:] / th
+        K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        T[:3, :3] = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+    T[:3, 3] = x[:3]
+    w = src @ T[:3, :3].T + T[:3, 3]
+    d2 = ((w[:, None, :] - tgt[None, :, :]) ** 2).sum(-1)
+    j = d2.argmin(1)
+    out = tgt[j].copy()
+    out[d2[np.arange(len(src)), j] > max_dist ** 2] = np.nan
+    return out
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_icp_matcher_equals_brute_force(hip_lib, dtype):
+    """Correspondence search: grid search on the GPU vs the O(N M) definition (nearest target of
+    the warped source within max_distance, NaN marker otherwise)."""
+    rng = np.random.default_rng(12)
+    tgt = (rng.random((4000, 3)) * np.array([10.0, 6.0, 3.0])).astype(dtype)
+    src = (rng.random((3000, 3)) * np.array([12.0, 7.0, 4.0]) - 1.0).astype(dtype)   # some outside
+    for max_dist in (0.15, 0.5, 2.5):
+        cost = hip_lib.IcpCost(src, tgt, max_dist, dtype=dtype)
+        for x in (np.zeros(6), np.array([0.3, -0.2, 0.1, 0.05, -0.02, 0.04])):
+            n = cost.update(x.astype(dtype))
+            got = cost.matches()
+            want = _brute_force_matches(src.astype(np.float64), tgt.astype(np.float64), x, max_dist)
+            miss_g, miss_w = np.isnan(got[:, 0]), np.isnan(want[:, 0])
+            if dtype == np.float64:
+                assert np.array_equal(miss_g, miss_w)
+                assert np.array_equal(got[~miss_g], want[~miss_w])
+            else:   # float distances can flip a near-tie or a point at the radius
+                assert (miss_g != miss_w).mean() < 2e-3
+                both = ~miss_g & ~miss_w
+                assert (np.abs(got[both] - want[both]).max(1) > 0).mean() < 2e-3
+            assert n == int((~miss_g).sum())
+
+
+def test_icp_solve_with_gpu_correspondence_search(hip_lib, oracle):
+    """Real ICP: unknown correspondences, re-matched at the top of every outer LM iteration
+    (cost->update(x), levenberg_marquadt_dyn.cpp:54).  Target = moved source + noise, shuffled,
+    plus clutter; start near the solution; the solve must land on the pose, and the linearization
+    over the matched pairs must equal the CPU path on the same pairs."""
+    rng = np.random.default_rng(5)
+    n = 20_000
+    src = rng.random((n, 3)) * np.array([10.0, 10.0, 3.0])
+    x_true = np.array([0.12, -0.08, 0.05, 0.02, -0.015, 0.03])
+    R = oracle.se3_from_x(x_true)
+    moved = src @ R[:3, :3].T + R[:3, 3] + rng.normal(0, 0.002, src.shape)
+    clutter = rng.random((2000, 3)) * np.array([10.0, 10.0, 3.0]) + np.array([0, 0, 6.0])
+    tgt = np.concatenate([moved, clutter])[rng.permutation(n + 2000)]
+    cost = hip_lib.IcpCost(src, tgt, max_distance=0.5)
+
+    # linearization over the current matches == CPU path over the same pairs
+    x0 = np.zeros(6)
+    matched = cost.update(x0)
+    pairs = cost.matches()
+    ok = ~np.isnan(pairs[:, 0])
+    assert matched == ok.sum() and matched > 0.9 * n
+    check(cost.linearize(x0, 0), oracle_ref(oracle, src[ok], pairs[ok], x0, 0))
+    want = oracle.p2p_cost(src[ok], pairs[ok], x0)
+    assert abs(cost.compute_cost(x0) - want) <= REL * want
+
+    x = x0.copy()
+    for outer in range(12):
+        cost.update(x)
+        x, status, iters = _lm_minimize([((lambda v: cost.linearize(v, 0)), cost.compute_cost)], x,
+                                        max_iter=3)
+    assert np.abs(x - x_true).max() < 2e-4, x
