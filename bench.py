@@ -84,6 +84,7 @@ def prewarm_runtime(mo, device=0, calls=450):
     from tests import datasets as ds
     src, tgt = ds.synthetic_pair(1000, seed=3)
     dummy = mo.Point2PointCost(src, tgt, device=device)
+    dummy.set_speculation(False)  # every call must really launch
     x = ds.X_GENERIC
     for _ in range(calls):
         dummy.linearize(x, mo.JAC_ANALYTIC)
