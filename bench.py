@@ -189,10 +189,20 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    # MOPT_BENCH_BACKEND=gloo is a rehearsal mode for a box with fewer GPUs than ranks: ranks share
+    # devices and the 43 sums are combined through gloo instead of RCCL (RCCL refuses two ranks on
+    # one GPU).  Everything else — shards, barriers, timing, the JSON line — is the real code path.
+    backend = os.environ.get("MOPT_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+            if not os.environ.get("MOPT_BENCH_TRY_RCCL"):  # (set: rehearse the failure path too)
+                args.collective = "torch"
 
     if args.total_n:
         lo, hi = args.total_n * rank // world, args.total_n * (rank + 1) // world
@@ -236,7 +246,8 @@ def main():
                 print("rank %d: library communicator unavailable (%s)" % (rank, e), file=sys.stderr)
             # every rank must take the same path: fall back to the torch.distributed collective
             # (still RCCL) if any rank failed
-            agreed = torch.tensor([ok], device="cuda", dtype=torch.int32)
+            agreed = torch.tensor([ok], dtype=torch.int32,
+                                  device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
             if int(agreed.item()) == 0:
                 collective = "torch"
@@ -271,7 +282,8 @@ def main():
     cost.set_profiling(False)
 
     if world > 1:
-        tmax = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        tmax = torch.tensor([elapsed], dtype=torch.float64,
+                            device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -309,7 +321,7 @@ def main():
                 "correspondences_per_gpu": args.n,
                 "total_correspondences": total,
                 "parallelism": "shard%d" % world,
-                "collective": collective,
+                "collective": collective if backend == "nccl" else "torch/" + backend + " (rehearsal)",
                 "kernel_variant": args.variant,
             },
             "roofline": {

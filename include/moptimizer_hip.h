@@ -183,8 +183,10 @@ MOPT_API int mopt_cost_stats(const mopt_cost *cost, int64_t *sweeps, int64_t *ca
 
 /* ---- asynchronous sweeps (shard partials stay in HBM) -------------------------------------- */
 
-/* Enqueue on `hip_stream` (a hipStream_t; NULL = the cost's own stream) and return at once.
- * d_result: device double[n*n + n + 1].  d_sum_sq: device double[1]. */
+/* Enqueue on `hip_stream` and return at once.  hip_stream is a hipStream_t passed as a pointer;
+ * NULL is HIP's null (legacy default) stream, as everywhere in HIP — mopt_cost_stream gives the
+ * cost's own stream when that is wanted.  d_result: device double[n*n + n + 1].  d_sum_sq: device
+ * double[1].  The caller orders later work after the sweep by stream order or a synchronisation. */
 MOPT_API int mopt_cost_linearize_async(mopt_cost *cost, int jacobian_mode, const void *x,
                                        double *d_result, void *hip_stream);
 MOPT_API int mopt_cost_compute_async(mopt_cost *cost, const void *x, double *d_sum_sq,

@@ -205,16 +205,25 @@ class _CostBase:
         return s[0]
 
     # -- asynchronous forms: results stay in HBM --------------------------------------------
+    def own_stream(self):
+        s = ctypes.c_void_p()
+        check(load().mopt_cost_stream(self._h, ctypes.byref(s)))
+        return s.value or 0
+
     def linearize_async(self, x, jac_mode, d_result_ptr, stream_ptr=None):
+        """stream_ptr: a hipStream_t value (0 = HIP's null stream, torch's default); None = the
+        cost's own stream."""
         x = np.ascontiguousarray(x, dtype=_dtype_of(self.scalar_bytes))
+        stream = self.own_stream() if stream_ptr is None else stream_ptr
         check(load().mopt_cost_linearize_async(self._h, int(jac_mode), _ptr(x),
                                                ctypes.c_void_p(d_result_ptr),
-                                               ctypes.c_void_p(stream_ptr or 0)))
+                                               ctypes.c_void_p(stream)))
 
     def compute_cost_async(self, x, d_sum_ptr, stream_ptr=None):
         x = np.ascontiguousarray(x, dtype=_dtype_of(self.scalar_bytes))
+        stream = self.own_stream() if stream_ptr is None else stream_ptr
         check(load().mopt_cost_compute_async(self._h, _ptr(x), ctypes.c_void_p(d_sum_ptr),
-                                             ctypes.c_void_p(stream_ptr or 0)))
+                                             ctypes.c_void_p(stream)))
 
     def comm_init_rank(self, unique_id, rank, num_ranks):
         """Attach this cost (one shard) to the multi-process RCCL group: afterwards the blocking

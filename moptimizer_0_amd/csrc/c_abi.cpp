@@ -1048,15 +1048,15 @@ int mopt_cost_linearize_async(mopt_cost *c, int jacobian_mode, const void *x, do
                               void *hip_stream) {
   if (!c || !x || !d_result) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
   MOPT_HIP_TRY(hipSetDevice(c->device));
-  hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
-  return linearizeAsyncImpl(c, jacobian_mode, x, d_result, s);
+  // hip_stream is the hipStream_t itself; NULL is HIP's null (legacy default) stream, which is
+  // also what torch's default stream is
+  return linearizeAsyncImpl(c, jacobian_mode, x, d_result, static_cast<hipStream_t>(hip_stream));
 }
 
 int mopt_cost_compute_async(mopt_cost *c, const void *x, double *d_sum_sq, void *hip_stream) {
   if (!c || !x || !d_sum_sq) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
   MOPT_HIP_TRY(hipSetDevice(c->device));
-  hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
-  return costAsyncImpl(c, x, d_sum_sq, s);
+  return costAsyncImpl(c, x, d_sum_sq, static_cast<hipStream_t>(hip_stream));
 }
 
 namespace {

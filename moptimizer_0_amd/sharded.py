@@ -34,11 +34,21 @@ class ShardedSweep:
         self.result = torch.zeros(RESULT_DOUBLES, dtype=torch.float64, device=self.device)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
 
+    def _all_reduce(self, t):
+        # gloo cannot reduce device tensors: rehearsal runs (several ranks sharing one GPU, gloo
+        # backend) take the sums through the host; with RCCL ("nccl") the tensor stays in HBM.
+        if t.is_cuda and dist.get_backend(self.group) == "gloo":
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
     def linearize_device(self, x, jac_mode):
         """Asynchronous: returns the device tensor holding the all-reduced sums."""
         self.local_linearize(x, jac_mode, self.result)
         if self.world > 1:
-            dist.all_reduce(self.result, op=dist.ReduceOp.SUM, group=self.group)
+            self._all_reduce(self.result)
         return self.result
 
     def linearize(self, x, jac_mode):
@@ -48,7 +58,7 @@ class ShardedSweep:
     def compute_cost(self, x):
         self.local_cost(x, self.result)
         if self.world > 1:
-            dist.all_reduce(self.result[42:43], op=dist.ReduceOp.SUM, group=self.group)
+            self._all_reduce(self.result[42:43])
         return float(self.result[42].item())
 
 
