@@ -540,7 +540,7 @@ int blockingSweep(mopt_cost *c, bool cost_only, int jac_mode, const void *x) {
   mopt::HostPublish pub = nextPublish(c, offset);
   c->stat_sweeps += 1;
   int rc;
-  if (c->comm && c->comm_size > 1) {
+  if (c->comm) {  // also for a 1-rank communicator: same code path as N ranks
     rc = cost_only ? costAsyncImpl(c, x, c->d_result + offset, c->stream)
                    : linearizeAsyncImpl(c, jac_mode, x, c->d_result, c->stream);
     if (rc != MOPT_OK) return rc;

@@ -245,13 +245,26 @@ def test_full_size_properties(hip_lib):
 
 
 def test_single_rank_communicator(hip_lib, oracle, cloud_1k):
-    """mopt_cost_comm_init_rank with one rank: the collective path degenerates to the plain sweep."""
-    src, tgt = cloud_1k
+    """mopt_cost_comm_init_rank with one rank runs the very sequence N ranks run — sweep, finalize,
+    ncclAllReduce on the cost's stream, publish kernel, host flag — so RCCL linkage, stream order
+    and the publish-after-collective are exercised on a single GPU."""
+    src, tgt = ds.synthetic_pair(200_000, seed=43, noise=0.01)
+    plain = hip_lib.Point2PointCost(src, tgt)
     cost = hip_lib.Point2PointCost(src, tgt)
     cost.comm_init_rank(hip_lib.capi.comm_unique_id(), 0, 1)
-    check(cost.linearize(ds.X_GENERIC, 0), oracle_ref(oracle, src, tgt, ds.X_GENERIC, 0))
-    want = oracle.p2p_cost(src, tgt, ds.X_GENERIC)
-    assert abs(cost.compute_cost(ds.X_GENERIC) - want) <= REL * want
+    cost.set_speculation(False)
+    plain.set_speculation(False)
+    for k in range(30):
+        x = ds.X_GENERIC + 1e-3 * k
+        mode = (0, 2, 1)[k % 3]
+        H, b, s = cost.linearize(x, mode)
+        Hp, bp, sp = plain.linearize(x, mode)
+        assert np.array_equal(H, Hp) and np.array_equal(b, bp) and s == sp
+        assert cost.compute_cost(x) == plain.compute_cost(x)
+    src1, tgt1 = cloud_1k
+    small = hip_lib.Point2PointCost(src1, tgt1)
+    small.comm_init_rank(hip_lib.capi.comm_unique_id(), 0, 1)
+    check(small.linearize(ds.X_GENERIC, 0), oracle_ref(oracle, src1, tgt1, ds.X_GENERIC, 0))
 
 
 def test_repeated_blocking_calls_are_reproducible(hip_lib, cloud_1k):
