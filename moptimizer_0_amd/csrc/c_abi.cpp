@@ -68,6 +68,9 @@ struct IcpMatcher {
   int dims[3] = {1, 1, 1};
   double max_dist = 0.0;
   long long num_targets = 0;
+  // Sources are stored in grid-cell order (of their un-warped position) so that neighbouring
+  // lanes visit neighbouring cells; slot k of the tiles holds the caller's source order[k].
+  std::vector<long long> order;
 };
 
 struct mopt_cost {
@@ -745,7 +748,8 @@ int mopt_point2point_set_data(mopt_cost *c, const void *src_xyz, const void *tgt
 namespace {
 // Counting sort of the targets into grid cells (host, once per target cloud).
 template <typename S>
-int buildIcpGrid(mopt_cost *c, const S *tgt, long long m, double max_distance) {
+int buildIcpGrid(const S *tgt, long long m, double max_distance,
+                 std::unique_ptr<IcpMatcher> &out_matcher) {
   auto mt = std::make_unique<IcpMatcher>();
   mt->max_dist = max_distance;
   mt->num_targets = m;
@@ -801,8 +805,37 @@ int buildIcpGrid(mopt_cost *c, const S *tgt, long long m, double max_distance) {
   MOPT_HIP_TRY(hipMemcpy(mt->d_cell_start, start.data(), start.size() * sizeof(int),
                          hipMemcpyHostToDevice));
   MOPT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&mt->d_matched), 64));
-  c->matcher = std::move(mt);
+  out_matcher = std::move(mt);
   return MOPT_OK;
+}
+
+// Order of the sources by the grid cell of their position (stable), and the reordered copy.
+template <typename S>
+void sortSourcesByCell(const IcpMatcher &mt, const S *src, long long n, std::vector<long long> &order,
+                       std::vector<S> &sorted_src) {
+  long long ncells = 1;
+  for (int a = 0; a < 3; ++a) ncells *= mt.dims[a];
+  std::vector<long long> start(size_t(ncells) + 1, 0);
+  std::vector<long long> cell_of(static_cast<size_t>(n));
+  for (long long i = 0; i < n; ++i) {
+    long long id = 0, stride = 1;
+    for (int a = 0; a < 3; ++a) {
+      double g = std::floor((double(src[3 * i + a]) - mt.origin[a]) / mt.cell);
+      g = g < 0 ? 0 : (g >= mt.dims[a] ? mt.dims[a] - 1 : g);
+      id += (long long)g * stride;
+      stride *= mt.dims[a];
+    }
+    cell_of[size_t(i)] = id;
+    start[size_t(id) + 1] += 1;
+  }
+  for (size_t k = 0; k < size_t(ncells); ++k) start[k + 1] += start[k];
+  order.assign(static_cast<size_t>(n), 0);
+  sorted_src.assign(static_cast<size_t>(n) * 3, S(0));
+  for (long long i = 0; i < n; ++i) {
+    const size_t dst = size_t(start[size_t(cell_of[size_t(i)])]++);
+    order[dst] = i;
+    for (int a = 0; a < 3; ++a) sorted_src[dst * 3 + a] = src[3 * i + a];
+  }
 }
 
 template <typename S>
@@ -847,16 +880,43 @@ int mopt_icp_create(mopt_cost **out, int device, int scalar_bytes, const void *s
       num_tgt > std::numeric_limits<int>::max())
     return fail(MOPT_ERR_INVALID_ARGUMENT, "bad clouds");
   if (!(max_distance > 0.0)) return fail(MOPT_ERR_INVALID_ARGUMENT, "max_distance must be > 0");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(MOPT_ERR_NO_DEVICE, "no HIP device is visible to this process");
+  if (device < 0 || device >= ndev) return fail(MOPT_ERR_INVALID_ARGUMENT, "device index out of range");
+  MOPT_HIP_TRY(hipSetDevice(device));
+  std::unique_ptr<IcpMatcher> matcher;
+  int rc = scalar_bytes == 8
+               ? buildIcpGrid<double>(static_cast<const double *>(tgt_xyz), num_tgt, max_distance, matcher)
+               : buildIcpGrid<float>(static_cast<const float *>(tgt_xyz), num_tgt, max_distance, matcher);
+  auto freeMatcher = [&]() {
+    if (!matcher) return;
+    if (matcher->d_sorted) (void)hipFree(matcher->d_sorted);
+    if (matcher->d_cell_start) (void)hipFree(matcher->d_cell_start);
+    if (matcher->d_matched) (void)hipFree(matcher->d_matched);
+  };
+  if (rc != MOPT_OK) {
+    freeMatcher();
+    return rc;
+  }
+  // the sources go into the resident tiles in cell order; the target planes are filled by the
+  // first search
   mopt_cost *raw = nullptr;
-  // the source goes into the resident tiles; the target planes are filled by the first search
-  int rc = mopt_point2point_create(&raw, device, scalar_bytes, src_xyz, src_xyz, num_src,
-                                   MOPT_INPUT_HOST);
-  if (rc != MOPT_OK) return rc;
+  if (scalar_bytes == 8) {
+    std::vector<double> sorted;
+    sortSourcesByCell<double>(*matcher, static_cast<const double *>(src_xyz), num_src, matcher->order, sorted);
+    rc = mopt_point2point_create(&raw, device, 8, sorted.data(), sorted.data(), num_src, MOPT_INPUT_HOST);
+  } else {
+    std::vector<float> sorted;
+    sortSourcesByCell<float>(*matcher, static_cast<const float *>(src_xyz), num_src, matcher->order, sorted);
+    rc = mopt_point2point_create(&raw, device, 4, sorted.data(), sorted.data(), num_src, MOPT_INPUT_HOST);
+  }
+  if (rc != MOPT_OK) {
+    freeMatcher();
+    return rc;
+  }
   std::unique_ptr<mopt_cost, void (*)(mopt_cost *)> c(raw, destroyCost);
-  rc = scalar_bytes == 8
-           ? buildIcpGrid<double>(c.get(), static_cast<const double *>(tgt_xyz), num_tgt, max_distance)
-           : buildIcpGrid<float>(c.get(), static_cast<const float *>(tgt_xyz), num_tgt, max_distance);
-  if (rc != MOPT_OK) return rc;
+  c->matcher = std::move(matcher);
   const double zero8[6] = {0, 0, 0, 0, 0, 0};
   const float zero4[6] = {0, 0, 0, 0, 0, 0};
   rc = mopt_icp_update(c.get(), scalar_bytes == 8 ? static_cast<const void *>(zero8)
@@ -887,10 +947,19 @@ int mopt_icp_get_matches(mopt_cost *c, void *tgt_out_xyz) {
                                                          c->count, static_cast<double *>(d_tmp), c->stream)
                      : mopt::launchGatherTargets<float>(static_cast<const float *>(c->d_tiles),
                                                         c->count, static_cast<float *>(d_tmp), c->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(tgt_out_xyz, d_tmp, bytes, hipMemcpyDeviceToHost, c->stream);
+  const bool permuted = c->matcher && !c->matcher->order.empty();
+  std::vector<unsigned char> staged(permuted ? bytes : 0);
+  void *host_dst = permuted ? static_cast<void *>(staged.data()) : tgt_out_xyz;
+  if (e == hipSuccess) e = hipMemcpyAsync(host_dst, d_tmp, bytes, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   (void)hipFree(d_tmp);
   if (e != hipSuccess) return fail(MOPT_ERR_HIP, std::string("gather: ") + hipGetErrorString(e));
+  if (permuted) {  // slot k holds the caller's source order[k]
+    const size_t triple = size_t(3) * c->scalar_bytes;
+    for (long long k = 0; k < c->count; ++k)
+      std::memcpy(static_cast<unsigned char *>(tgt_out_xyz) + size_t(c->matcher->order[size_t(k)]) * triple,
+                  staged.data() + size_t(k) * triple, triple);
+  }
   return MOPT_OK;
 }
 
