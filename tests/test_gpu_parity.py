@@ -592,3 +592,19 @@ def test_async_sweeps_on_torch_stream(hip_lib, oracle, cloud_1k):
     with torch.cuda.stream(side):
         H, b, s = sweep.linearize(ds.X_GENERIC, 0)
     assert np.array_equal(H, cost.linearize(ds.X_GENERIC, 0)[0])
+
+
+@pytest.mark.parametrize("jac_mode", [0, 2])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_baseline_configs_2_and_3_full_size_against_oracle(hip_lib, oracle, jac_mode, variant):
+    """BASELINE.json configs 2 (analytic) and 3 (finite-difference) at their full size, 1 M
+    correspondences, directly against the CPU restatement on the same inputs — default kernels and
+    the literal per-point evaluation."""
+    src, tgt = ds.synthetic_pair(1_000_000, seed=42, noise=0.01)
+    cost = hip_lib.Point2PointCost(src, tgt)
+    cost.set_kernel_variant(variant)
+    for x in (ds.X_ZERO, ds.X_GENERIC):
+        check(cost.linearize(x, jac_mode), oracle_ref(oracle, src, tgt, x, jac_mode))
+    want = oracle.p2p_cost(src, tgt, ds.X_GENERIC)
+    cost.set_speculation(False)
+    assert abs(cost.compute_cost(ds.X_GENERIC) - want) <= REL * want
