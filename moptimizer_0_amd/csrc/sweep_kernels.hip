@@ -20,6 +20,8 @@
 //     H (column-major) | b | sum_sq; no atomics anywhere.
 #include "sweep.hpp"
 
+#include <type_traits>
+
 namespace mopt {
 namespace {
 
@@ -302,7 +304,23 @@ __global__ __launch_bounds__(kBlockThreads) void p2pMomentsKernel(const P2PSweep
 #pragma unroll
   for (int k = 0; k < kAccMoments; ++k) acc[k] = 0.0;
 
+  // fp64: the moment updates contract into one v_fma_f64 each, straight into the accumulators.
+  // fp32: the four correspondences a lane holds per tile are first summed in fp32 (fp32 FMAs),
+  // then promoted once — 23 conversions + fp64 adds per tile instead of 92, which otherwise makes
+  // the fp32 sweep VALU-bound.
+  using Local = typename std::conditional<sizeof(S) == 8, double, S>::type;
   sweepTiles<S, STREAMING>(A.tiles, A.num_tiles, [&](const Pack<S>(&cur)[6], long long first) {
+    Local loc[kAccMoments];
+    if constexpr (sizeof(S) == 4) {
+#pragma unroll
+      for (int k = 0; k < kAccMoments; ++k) loc[k] = Local(0);
+    }
+    auto add = [&](int k, S v) {
+      if constexpr (sizeof(S) == 8)
+        acc[k] += double(v);
+      else
+        loc[k] += v;
+    };
 #pragma unroll
     for (int e = 0; e < V; ++e) {
       const S p[3] = {cur[0].v[e], cur[1].v[e], cur[2].v[e]};
@@ -317,24 +335,28 @@ __global__ __launch_bounds__(kBlockThreads) void p2pMomentsKernel(const P2PSweep
       rr = valid ? rr : S(0);
       const S wp[3] = {w * p[0], w * p[1], w * p[2]};
       const S wr[3] = {w * r[0], w * r[1], w * r[2]};
-      acc[0] += double(w);
-      acc[1] += double(wp[0]);
-      acc[2] += double(wp[1]);
-      acc[3] += double(wp[2]);
-      acc[4] += double(wp[0] * p[0]);
-      acc[5] += double(wp[0] * p[1]);
-      acc[6] += double(wp[0] * p[2]);
-      acc[7] += double(wp[1] * p[1]);
-      acc[8] += double(wp[1] * p[2]);
-      acc[9] += double(wp[2] * p[2]);
-      acc[10] += double(wr[0]);
-      acc[11] += double(wr[1]);
-      acc[12] += double(wr[2]);
+      add(0, w);
+      add(1, wp[0]);
+      add(2, wp[1]);
+      add(3, wp[2]);
+      add(4, wp[0] * p[0]);
+      add(5, wp[0] * p[1]);
+      add(6, wp[0] * p[2]);
+      add(7, wp[1] * p[1]);
+      add(8, wp[1] * p[2]);
+      add(9, wp[2] * p[2]);
+      add(10, wr[0]);
+      add(11, wr[1]);
+      add(12, wr[2]);
 #pragma unroll
       for (int k = 0; k < 3; ++k)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) acc[13 + 3 * k + c] += double(p[k] * wr[c]);
-      acc[22] += double(rr);
+        for (int c = 0; c < 3; ++c) add(13 + 3 * k + c, p[k] * wr[c]);
+      add(22, rr);
+    }
+    if constexpr (sizeof(S) == 4) {
+#pragma unroll
+      for (int k = 0; k < kAccMoments; ++k) acc[k] += double(loc[k]);
     }
   });
   blockReduceStore<kAccMoments>(acc, A.partials + size_t(blockIdx.x) * kAccMoments);
