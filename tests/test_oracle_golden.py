@@ -126,3 +126,34 @@ def test_product_so3_agrees_with_oracle_so3(oracle):
         x = np.zeros(6)
         lib.product_se3(x.ctypes.data_as(ctypes.c_void_p), T.ctypes.data_as(ctypes.c_void_p))
         assert np.array_equal(T.reshape(4, 4, order="F"), np.eye(4))
+
+
+def test_text_cloud_loader_round_trip(facade, tmp_path):
+    """include/moptimizer_amd/cloud_io.hpp reads the reference's `x y z r g b` text format
+    (tst/point2point.cpp:125-138): written with 8 decimals like tst/data/fachada.txt, the façade
+    comes back bit for bit."""
+    import ctypes
+    src, _ = facade
+    txt = os.path.join(tmp_path, "cloud.txt")
+    with open(txt, "w") as f:
+        for x, y, z in src[:2000]:
+            f.write("%.8f %.8f %.8f 255 218 0\n" % (x, y, z))
+        f.write("not a number\n7 8 9 1 2 3\n")   # parsing stops here, as the reference's loop does
+    code = r'''
+    #include "moptimizer_amd/cloud_io.hpp"
+    extern "C" long load_cloud(const char* path, double* out, long cap) {
+      auto v = moptimizer::io::loadXyzRgbText<double>(path);
+      for (long i = 0; i < (long)v.size() && i < cap; ++i) out[i] = v[i];
+      return (long)v.size(); }
+    '''
+    cpp = os.path.join(tmp_path, "l.cpp")
+    so = os.path.join(tmp_path, "l.so")
+    open(cpp, "w").write(code)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I",
+                           os.path.join(ds.ROOT, "include"), cpp, "-o", so])
+    lib = ctypes.CDLL(so)
+    lib.load_cloud.restype = ctypes.c_long
+    out = np.zeros(3 * 4000)
+    n = lib.load_cloud(txt.encode(), out.ctypes.data_as(ctypes.c_void_p), ctypes.c_long(out.size))
+    assert n == 3 * 2000
+    assert np.array_equal(out[:n].reshape(-1, 3), src[:2000])
