@@ -223,7 +223,9 @@ MOPT_API int mopt_cost_profile(mopt_cost *cost, double *sweep_ms_total, int64_t 
 /* Shard `count` correspondences contiguously over `num_devices` GPUs of this node, one
  * mopt_cost per device, and combine the n*n + n + 1 partial sums of every sweep with one
  * ncclAllReduce(sum, fp64) over xGMI.  The blocking calls below have the semantics of
- * mopt_cost_linearize / mopt_cost_compute on the whole data set. */
+ * mopt_cost_linearize / mopt_cost_compute on the whole data set.  (A device list that names a GPU
+ * more than once — several shards on one GPU, to rehearse the sharding on a smaller machine —
+ * cannot form an RCCL communicator; its shard sums are added on the host in shard order.) */
 MOPT_API int mopt_group_point2point_create(mopt_group **out, const int *devices, int num_devices,
                                            int scalar_bytes, const void *src_xyz,
                                            const void *tgt_xyz, int64_t count);

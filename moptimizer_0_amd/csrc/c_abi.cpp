@@ -1263,6 +1263,9 @@ struct mopt_group {
   std::vector<mopt_cost *> shards;
   std::vector<ncclComm_t> comms;
   int scalar_bytes = 8;
+  // RCCL needs distinct devices.  A device list with repeats (several shards on one GPU: a
+  // rehearsal of the sharding on a smaller machine) combines the shard sums on the host instead.
+  bool host_combine = false;
 };
 
 namespace {
@@ -1302,7 +1305,10 @@ int mopt_group_point2point_create(mopt_group **out, const int *devices, int num_
     if (rc != MOPT_OK) return rc;
     g->shards.push_back(shard);
   }
-  if (num_devices > 1) {
+  for (int a = 0; a < num_devices; ++a)
+    for (int b = a + 1; b < num_devices; ++b)
+      if (devices[a] == devices[b]) g->host_combine = true;
+  if (num_devices > 1 && !g->host_combine) {
     g->comms.assign(num_devices, nullptr);
     MOPT_NCCL_TRY(ncclCommInitAll(g->comms.data(), num_devices, devices));
   }
@@ -1341,6 +1347,22 @@ int mopt_group_set_loss(mopt_group *g, int loss_kind, double parameter) {
 
 static int groupReduceAndFetch(mopt_group *g, int offset, int n_doubles) {
   const int G = int(g->shards.size());
+  if (g->host_combine) {
+    for (int k = 0; k < G; ++k) {
+      mopt_cost *c = g->shards[k];
+      MOPT_HIP_TRY(hipSetDevice(c->device));
+      MOPT_HIP_TRY(hipMemcpyAsync(c->h_result + offset, c->d_result + offset,
+                                  n_doubles * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    }
+    for (int k = 0; k < G; ++k) {
+      MOPT_HIP_TRY(hipSetDevice(g->shards[k]->device));
+      MOPT_HIP_TRY(hipStreamSynchronize(g->shards[k]->stream));
+    }
+    double *total = g->shards[0]->h_result + offset;
+    for (int k = 1; k < G; ++k)  // shard order: deterministic
+      for (int q = 0; q < n_doubles; ++q) total[q] += g->shards[k]->h_result[offset + q];
+    return MOPT_OK;
+  }
   if (G > 1) {
     // one all-reduce per sweep over xGMI; every rank ends with the full sums
     MOPT_NCCL_TRY(ncclGroupStart());

@@ -608,3 +608,24 @@ def test_baseline_configs_2_and_3_full_size_against_oracle(hip_lib, oracle, jac_
     want = oracle.p2p_cost(src, tgt, ds.X_GENERIC)
     cost.set_speculation(False)
     assert abs(cost.compute_cost(ds.X_GENERIC) - want) <= REL * want
+
+
+def test_group_shards_on_one_gpu(hip_lib, oracle):
+    """mopt_group_* with a repeated device: three contiguous shards of a ragged count on GPU 0.
+    Same result as one cost over everything (shard invariance) and as the oracle."""
+    src, tgt = ds.synthetic_pair(100_003, seed=51, noise=0.02)
+    grp = hip_lib.Point2PointGroup(src, tgt, devices=[0, 0, 0])
+    one = hip_lib.Point2PointCost(src, tgt)
+    cov = np.diag([0.5, 2.0, 3.0])
+    grp.set_covariance(cov)
+    grp.set_loss(1, 100.0)
+    one.set_covariance(cov)
+    one.set_loss(1, 100.0)
+    for jac_mode in (0, 2):
+        H, b, s = grp.linearize(ds.X_GENERIC, jac_mode)
+        H1, b1, s1 = one.linearize(ds.X_GENERIC, jac_mode)
+        assert rel_err(H, H1) < 1e-12 and rel_err(b, b1) < 1e-12 and abs(s - s1) < 1e-12 * s1
+        check((H, b, s), oracle_ref(oracle, src, tgt, ds.X_GENERIC, jac_mode, cov=cov, loss_kind=1,
+                                    loss_param=100.0))
+    want = oracle.p2p_cost(src, tgt, ds.X_GENERIC)
+    assert abs(grp.compute_cost(ds.X_GENERIC) - want) <= REL * want
