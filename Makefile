@@ -15,7 +15,8 @@ OBJDIR      = build/obj
 LIBDIR      = moptimizer_0_amd/lib
 LIB         = $(LIBDIR)/libmoptimizer_hip.so
 
-PUBLIC_HEADERS = include/moptimizer_hip.h include/moptimizer_amd/so3.hpp $(CSRC)/sweep.hpp
+PUBLIC_HEADERS = include/moptimizer_hip.h include/moptimizer_amd/so3.hpp $(CSRC)/sweep.hpp \
+                 $(CSRC)/jit_model.hpp
 
 all: $(LIB)
 
@@ -28,8 +29,11 @@ $(OBJDIR)/sweep_kernels.o: $(CSRC)/sweep_kernels.hip $(PUBLIC_HEADERS) | $(OBJDI
 $(OBJDIR)/c_abi.o: $(CSRC)/c_abi.cpp $(PUBLIC_HEADERS) | $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) $(INCLUDES) -x hip -c $< -o $@
 
-$(LIB): $(OBJDIR)/sweep_kernels.o $(OBJDIR)/c_abi.o | $(LIBDIR)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -L$(ROCM)/lib -lrccl \
+$(OBJDIR)/jit_model.o: $(CSRC)/jit_model.cpp $(PUBLIC_HEADERS) | $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) $(INCLUDES) -x hip -c $< -o $@
+
+$(LIB): $(OBJDIR)/sweep_kernels.o $(OBJDIR)/c_abi.o $(OBJDIR)/jit_model.o | $(LIBDIR)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -L$(ROCM)/lib -lrccl -lhiprtc \
 	    -Wl,-rpath,$(ROCM)/lib -Wl,--no-undefined
 
 oracle:

@@ -16,6 +16,7 @@
 // MOPTIMIZER_AMD_USE_REFERENCE_HEADERS.
 #pragma once
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <memory>
@@ -229,6 +230,45 @@ class PowellDeviceModel : public DeviceModel<double> {
   }
   int numOutputs() const override { return 4; }
   int numParameters() const override { return 4; }
+};
+
+/// A model written by the user: the device counterpart of deriving from BaseModel /
+/// BaseModelJacobian (model.h:29-47).  `residual_body` / `jacobian_body` are the statements of
+///   void f   (const Scalar *x, const Scalar *d, Scalar *r)      // r: num_outputs values
+///   void f_df(const Scalar *x, const Scalar *d, Scalar *J)      // J: num_outputs x n, row-major
+/// in HIP C++ (`S` names the scalar type); d holds the element's value from each data plane.
+/// Compiled for the GPU when the cost function is constructed; a model without a Jacobian body
+/// behaves as BaseModel does (f_df throws).
+template <typename Scalar>
+class JitDeviceModel : public DeviceModel<Scalar> {
+ public:
+  using Ptr = std::shared_ptr<JitDeviceModel>;
+  JitDeviceModel(int num_parameters, int num_outputs, std::string residual_body,
+                 std::string jacobian_body, std::vector<const Scalar *> planes)
+      : n_(num_parameters), m_(num_outputs), residual_(std::move(residual_body)),
+        jacobian_(std::move(jacobian_body)), planes_(std::move(planes)) {}
+  typename IBaseModel<Scalar>::Ptr clone() const override {
+    return std::make_shared<JitDeviceModel>(*this);
+  }
+  mopt_cost *createDeviceCost(int device, int num_residuals) const override {
+    // the planes are separate user arrays: gather them into one staging block
+    std::vector<Scalar> staged(planes_.size() * std::size_t(num_residuals));
+    for (std::size_t p = 0; p < planes_.size(); ++p)
+      std::copy(planes_[p], planes_[p] + num_residuals, staged.begin() + p * num_residuals);
+    mopt_cost *h = nullptr;
+    throwOnError(mopt_jit_model_create(&h, device, int(sizeof(Scalar)), n_, m_, int(planes_.size()),
+                                       residual_.c_str(), jacobian_.empty() ? nullptr : jacobian_.c_str(),
+                                       staged.data(), num_residuals, num_residuals, MOPT_INPUT_HOST),
+                 "mopt_jit_model_create");
+    return h;
+  }
+  int numOutputs() const override { return m_; }
+  int numParameters() const override { return n_; }
+
+ private:
+  int n_, m_;
+  std::string residual_, jacobian_;
+  std::vector<const Scalar *> planes_;
 };
 
 // ---- cost functions ---------------------------------------------------------------------------

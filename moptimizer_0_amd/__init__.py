@@ -16,6 +16,7 @@ from ._capi import (  # noqa: F401
     LOSS_GEMAN_MCCLURE,
     LOSS_NONE,
     IcpCost,
+    JitModelCost,
     MoptError,
     Point2PointCost,
     Point2PointGroup,

@@ -59,6 +59,9 @@ def load():
         "mopt_scalar_model_create": [c_void_pp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                      ctypes.c_int64],
+        "mopt_jit_model_create": [c_void_pp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                  ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p,
+                                  ctypes.c_int64, ctypes.c_int64, ctypes.c_uint],
         "mopt_cost_destroy": [ctypes.c_void_p],
         "mopt_cost_set_covariance": [ctypes.c_void_p, ctypes.c_void_p],
         "mopt_cost_set_loss": [ctypes.c_void_p, ctypes.c_int, ctypes.c_double],
@@ -365,6 +368,28 @@ class ScalarModelCost(_CostBase):
             check(load().mopt_scalar_model_create(ctypes.byref(self._h), device, self.scalar_bytes,
                                                   kind, _ptr(t), _ptr(y), 1, t.shape[0]))
             self.count = t.shape[0]
+
+
+class JitModelCost(_CostBase):
+    """A user-defined model given as HIP source for its residual (and optionally Jacobian) body."""
+
+    def __init__(self, n_params, n_outputs, residual_body, jacobian_body=None, planes=None,
+                 device=0, dtype=np.float64):
+        super().__init__()
+        self.scalar_bytes = np.dtype(dtype).itemsize
+        self.n_params, self.n_out = int(n_params), int(n_outputs)
+        if planes is None:
+            data, n_planes, count = None, 0, 1
+        else:
+            data = np.ascontiguousarray(planes, dtype=dtype)
+            assert data.ndim == 2
+            n_planes, count = data.shape
+        jac = None if not jacobian_body else jacobian_body.encode()
+        check(load().mopt_jit_model_create(ctypes.byref(self._h), device, self.scalar_bytes,
+                                           self.n_params, self.n_out, n_planes,
+                                           residual_body.encode(), jac,
+                                           None if data is None else _ptr(data), count, count, 0))
+        self.count = count
 
 
 class Point2PointGroup:

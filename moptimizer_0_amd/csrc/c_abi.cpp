@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "moptimizer_amd/so3.hpp"
+#include "jit_model.hpp"
 #include "sweep.hpp"
 
 namespace {
@@ -45,7 +46,7 @@ int fail(int code, const std::string &msg) {
       return fail(MOPT_ERR_RCCL, std::string(#expr) + ": " + ncclGetErrorString(r_));      \
   } while (0)
 
-enum ModelKind { kModelPoint2Point = 1, kModelReprojection = 2, kModelScalar = 3 };
+enum ModelKind { kModelPoint2Point = 1, kModelReprojection = 2, kModelScalar = 3, kModelJit = 4 };
 constexpr int kMaxParamBytes = mopt::kMaxParams * 8;
 constexpr int kResultSlots = 96;  // >= n*n + n + 1 for n <= 8 (73)
 
@@ -111,6 +112,7 @@ struct mopt_cost {
   double frame[16];
 
   std::unique_ptr<IcpMatcher> matcher;  // point2point costs created by mopt_icp_create
+  mopt::JitKernel jit;                  // kModelJit: the run-time compiled sweep
 
   // LM calls computeCost(xi) and, when the step is accepted, linearize(xi) right after
   // (levenberg_marquadt_dyn.cpp:86,112 then :55): with speculation on, computeCost runs the
@@ -472,10 +474,60 @@ int scalarSweepAsync(mopt_cost *c, bool cost_only, int jac_mode, const S *x, dou
   return MOPT_OK;
 }
 
+// User-defined (hipRTC) model: same sweep shape as the built-in scalar models, full-form rows.
+template <typename S>
+int jitSweepAsync(mopt_cost *c, bool cost_only, int jac_mode, const S *x, double *d_out,
+                  hipStream_t s, const mopt::HostPublish &pub) {
+  if (!cost_only) {
+    if (jac_mode == MOPT_JAC_ANALYTIC_TST_LAYOUT)
+      return fail(MOPT_ERR_UNSUPPORTED, "the as-written point2point layout applies to point2point only");
+    if (jac_mode == MOPT_JAC_ANALYTIC && !c->jit.has_jacobian)
+      return fail(MOPT_ERR_UNSUPPORTED,
+                  "Non implemented non-jacobian model function `f_df` being used.");
+  }
+  mopt::ScalarSweepArgs<S> filled;
+  fillScalarArgs<S>(c, x, filled);
+  mopt::JitArgs<S> args;
+  args.data = filled.data;
+  args.count = filled.count;
+  args.stride = filled.stride;
+  args.loss_kind = filled.loss_kind;
+  args.numeric = jac_mode == MOPT_JAC_NUMERIC ? 1 : 0;
+  args.cost_only = cost_only ? 1 : 0;
+  args.pad_ = 0;
+  args.loss_param = filled.loss_param;
+  for (int k = 0; k < 8; ++k) {
+    args.x[k] = filled.x[k];
+    args.h[k] = filled.h[k];
+  }
+  for (int k = 0; k < 16; ++k) args.cov[k] = filled.cov[k];
+  args.partials = c->d_partials;
+  long long blocks = (c->count + mopt::kBlockThreads - 1) / mopt::kBlockThreads;
+  if (blocks > c->num_cus * 4) blocks = c->num_cus * 4;
+  if (blocks < 1) blocks = 1;
+  const int grid = int(blocks);
+  const int n = c->n_params;
+  SweepTimer timer(c, s);
+  MOPT_HIP_TRY(mopt::jitLaunch(c->jit, &args, sizeof args, grid, s));
+  timer.stop();
+  if (cost_only) {
+    MOPT_HIP_TRY(mopt::launchFinalizeCost(c->d_partials, grid, d_out, pub, s));
+  } else {
+    MOPT_HIP_TRY(mopt::launchFinalizeDense(c->d_partials, grid, n * n + n + 1, n, d_out, pub, s));
+  }
+  return MOPT_OK;
+}
+
 int linearizeAsyncImpl(mopt_cost *c, int jac_mode, const void *x, double *d_result, hipStream_t s,
                        const mopt::HostPublish &pub = mopt::HostPublish()) {
   if (jac_mode < MOPT_JAC_ANALYTIC || jac_mode > MOPT_JAC_NUMERIC)
     return fail(MOPT_ERR_INVALID_ARGUMENT, "unknown jacobian_mode");
+  if (c->model == kModelJit)
+    return c->scalar_bytes == 8
+               ? jitSweepAsync<double>(c, false, jac_mode, static_cast<const double *>(x), d_result,
+                                       s, pub)
+               : jitSweepAsync<float>(c, false, jac_mode, static_cast<const float *>(x), d_result, s,
+                                      pub);
   if (c->model == kModelScalar)
     return c->scalar_bytes == 8
                ? scalarSweepAsync<double>(c, false, jac_mode, static_cast<const double *>(x),
@@ -491,6 +543,10 @@ int linearizeAsyncImpl(mopt_cost *c, int jac_mode, const void *x, double *d_resu
 
 int costAsyncImpl(mopt_cost *c, const void *x, double *d_sum, hipStream_t s,
                   const mopt::HostPublish &pub = mopt::HostPublish()) {
+  if (c->model == kModelJit)
+    return c->scalar_bytes == 8
+               ? jitSweepAsync<double>(c, true, 0, static_cast<const double *>(x), d_sum, s, pub)
+               : jitSweepAsync<float>(c, true, 0, static_cast<const float *>(x), d_sum, s, pub);
   if (c->model == kModelScalar)
     return c->scalar_bytes == 8
                ? scalarSweepAsync<double>(c, true, 0, static_cast<const double *>(x), d_sum, s, pub)
@@ -615,6 +671,7 @@ void destroyCost(mopt_cost *c) {
     if (c->matcher->d_cell_start) (void)hipFree(c->matcher->d_cell_start);
     if (c->matcher->d_matched) (void)hipFree(c->matcher->d_matched);
   }
+  mopt::jitRelease(c->jit);
   if (c->d_tiles) (void)hipFree(c->d_tiles);
   if (c->d_partials) (void)hipFree(c->d_partials);
   if (c->d_result) (void)hipFree(c->d_result);
@@ -1037,6 +1094,44 @@ int mopt_scalar_model_create(mopt_cost **out, int device, int scalar_bytes, int 
                     src[p] + size_t(i) * size_t(stride_scalars) * scalar_bytes, scalar_bytes);
     MOPT_HIP_TRY(hipMalloc(&c->d_tiles, staged.size()));
     MOPT_HIP_TRY(hipMemcpy(c->d_tiles, staged.data(), staged.size(), hipMemcpyHostToDevice));
+  }
+  mopt_cost_set_covariance(c.get(), nullptr);
+  c->state_version = 0;
+  *out = c.release();
+  return MOPT_OK;
+}
+
+int mopt_jit_model_create(mopt_cost **out, int device, int scalar_bytes, int n_params,
+                          int n_outputs, int n_planes, const char *residual_body,
+                          const char *jacobian_body, const void *data, int64_t plane_stride,
+                          int64_t count, unsigned flags) {
+  if (!out) return fail(MOPT_ERR_INVALID_ARGUMENT, "out is NULL");
+  *out = nullptr;
+  if (scalar_bytes != 4 && scalar_bytes != 8)
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "scalar_bytes must be 4 or 8");
+  if (count < 1 || (n_planes > 0 && (!data || plane_stride < count)))
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "bad data planes / count");
+  std::unique_ptr<mopt_cost, void (*)(mopt_cost *)> c(new (std::nothrow) mopt_cost, destroyCost);
+  if (!c) return fail(MOPT_ERR_HIP, "out of host memory");
+  c->scalar_bytes = scalar_bytes;
+  c->model = kModelJit;
+  c->n_params = n_params;
+  c->n_out = n_outputs;
+  c->count = count;
+  c->num_tiles = 1;
+  c->data_stride = count;
+  int rc = commonCreate(c.get(), device);
+  if (rc != MOPT_OK) return rc;
+  if (!mopt::jitCompile(scalar_bytes, n_params, n_outputs, n_planes, residual_body, jacobian_body,
+                        c->jit))
+    return fail(MOPT_ERR_INVALID_ARGUMENT, mopt::jitLastError());
+  if (n_planes > 0) {
+    const size_t row = size_t(count) * scalar_bytes;
+    MOPT_HIP_TRY(hipMalloc(&c->d_tiles, row * n_planes));
+    MOPT_HIP_TRY(hipMemcpy2D(c->d_tiles, row, data, size_t(plane_stride) * scalar_bytes, row,
+                             size_t(n_planes),
+                             (flags & MOPT_INPUT_DEVICE) ? hipMemcpyDeviceToDevice
+                                                         : hipMemcpyHostToDevice));
   }
   mopt_cost_set_covariance(c.get(), nullptr);
   c->state_version = 0;

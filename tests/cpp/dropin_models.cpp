@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <memory>
+#include <vector>
 
 #include "moptimizer_amd/cost_function_hip.hpp"
 #include "moptimizer_amd/levenberg_marquadt.hpp"
@@ -178,9 +179,58 @@ static void covarianceScaling() {
   }
 }
 
+// tst/curve_fitting.cpp:81-147 once more, with the model written by the user (source text) rather
+// than picked from the built-in ones: same LM program, same known answers; plus the user's
+// Jacobian against forward differences as tst/differentiation.cpp does for its models.
+static void userDefinedModel() {
+  std::vector<double> t(kNumObservations), y(kNumObservations);
+  for (int i = 0; i < kNumObservations; ++i) {
+    t[i] = kCurveData[2 * i];
+    y[i] = kCurveData[2 * i + 1];
+  }
+  auto model = std::make_shared<mh::JitDeviceModel<double>>(
+      2, 1, "r[0] = d[1] - exp(x[0] * d[0] + x[1]);",
+      "const S e = exp(x[0] * d[0] + x[1]); J[0] = -d[0] * e; J[1] = -e;",
+      std::vector<const double *>{t.data(), y.data()});
+  for (int analytic = 0; analytic < 2; ++analytic) {
+    LevenbergMarquadtDynamic<double> optimizer(2);
+    std::unique_ptr<moptimizer::CostFunctionBase<double>> cost;
+    if (analytic)
+      cost.reset(new mh::CostFunctionAnalytical<double, 2, 1>(model, kNumObservations));
+    else
+      cost.reset(new mh::CostFunctionNumerical<double, 2, 1>(model, kNumObservations));
+    optimizer.addCost(cost.get());
+    double x0[2] = {0.0, 0.0};
+    optimizer.minimize(x0);
+    expectNear(analytic ? "UserModel(jit) analytic x[0]" : "UserModel(jit) numeric x[0]", x0[0], 0.291861, 5e-5);
+    expectNear(analytic ? "UserModel(jit) analytic x[1]" : "UserModel(jit) numeric x[1]", x0[1], 0.131439, 5e-5);
+  }
+  mh::CostFunctionAnalytical<double, 2, 1> cost_ana(model, kNumObservations);
+  mh::CostFunctionNumerical<double, 2, 1> cost_num(model, kNumObservations);
+  double H[4], Hn[4], b[2], x0[2] = {0.29, 0.13};
+  cost_ana.linearize(x0, H, b);
+  cost_num.linearize(x0, Hn, b);
+  for (int i = 0; i < 4; ++i) {
+    char label[96];
+    std::snprintf(label, sizeof label, "UserModel(jit) analytic vs numeric H(%d)", i);
+    expectNear(label, H[i], Hn[i], 1e-4 * std::fabs(Hn[i]));
+  }
+  bool threw = false;
+  try {
+    mh::CostFunctionNumerical<double, 2, 1> bad(
+        std::make_shared<mh::JitDeviceModel<double>>(2, 1, "r[0] = undefined_symbol;", "",
+                                                     std::vector<const double *>{t.data(), y.data()}),
+        kNumObservations);
+  } catch (const moptimizer::Exception &) {
+    threw = true;
+  }
+  expectNear("UserModel(jit) source error surfaces as moptimizer::Exception", threw ? 1 : 0, 1, 0);
+}
+
 int main() {
   try {
     curveFitting();
+    userDefinedModel();
     powell();
     simpleModelFloat();
     multipleObjectives();

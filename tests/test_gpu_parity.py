@@ -480,6 +480,131 @@ def test_small_parametric_models_match_oracle(hip_lib, oracle):
     assert abs(c.compute_cost(x) - want[2]) <= REL * want[2]
 
 
+def numpy_linearize(residual, planes, x, numeric_jac=None, cov=None, loss=None):
+    """linearization.h:65-158 in numpy for an arbitrary residual(x, planes) -> (count, m):
+    forward differences with the reference's step unless `numeric_jac` (count, m, n) is given."""
+    x = np.asarray(x, dtype=np.float64)
+    r = residual(x, planes)
+    count, m = r.shape
+    n = x.shape[0]
+    if numeric_jac is None:
+        J = np.empty((count, m, n))
+        for j in range(n):
+            h = np.sqrt(np.finfo(np.float64).eps) * abs(x[j]) or np.sqrt(np.finfo(np.float64).eps)
+            xp = x.copy()
+            xp[j] += h
+            J[:, :, j] = (residual(xp, planes) - r) / h
+    else:
+        J = numeric_jac
+    S = np.eye(m) if cov is None else np.asarray(cov, dtype=np.float64)
+    rr = np.einsum("ia,ia->i", r, r)
+    w = np.ones(count) if loss is None else (loss * loss) / (rr + loss) ** 2
+    H = np.einsum("i,iak,ab,ibl->kl", w, J, S, J)
+    b = np.einsum("i,iak,ab,ib->k", w, J, S, r)
+    return H, b, rr.sum()
+
+
+def test_jit_models_match_builtin_models_and_numpy(hip_lib, oracle):
+    """User-defined models compiled at run time: (1) the exp-curve and rational models written as
+    source agree with the oracle like the built-in device models do; (2) a model the library has
+    never seen (n = 3, m = 2, three data planes) agrees with a numpy statement of the
+    reference's linearization, with loss, a non-symmetric covariance and a supplied Jacobian;
+    (3) the largest shape (n = 8, m = 4); (4) a body that does not compile is an error with
+    the compiler's message."""
+    rng = np.random.default_rng(14)
+    t = np.linspace(0.0, 4.95, 5000)
+    y = np.exp(0.3 * t + 0.1) + rng.normal(0, 0.2, t.shape)
+    c = hip_lib.JitModelCost(2, 1, "r[0] = d[1] - exp(x[0] * d[0] + x[1]);", planes=np.stack([t, y]))
+    for x in (np.zeros(2), np.array([0.29, 0.13])):
+        for lk, lp in ((0, 0.0), (1, 100.0)):
+            c.set_loss(lk, lp)
+            want = oracle.scalar_linearize(1, t, y, x, numeric=True, loss_kind=lk, loss_param=lp)
+            check(c.linearize(x, 2), want, tol=fd_tolerance(x))
+            assert abs(c.compute_cost(x) - want[2]) <= REL * want[2]
+    with pytest.raises(hip_lib.MoptError):
+        c.linearize(np.zeros(2), 0)
+
+    tr = np.abs(rng.normal(1.0, 1.0, 3000)) + 0.05
+    yr = 0.36 * tr / (0.56 + tr) + rng.normal(0, 0.01, tr.shape)
+    for dtype, tol in ((np.float64, None), (np.float32, 5e-3)):
+        c = hip_lib.JitModelCost(
+            2, 1, "r[0] = d[1] - x[0] * d[0] / (x[1] + d[0]);",
+            "const S q = x[1] + d[0]; J[0] = -d[0] / q; J[1] = x[0] * d[0] / (q * q);",
+            planes=np.stack([tr, yr]), dtype=dtype)
+        x = np.array([0.9, 0.2], dtype=dtype)
+        for numeric in (True, False):
+            want = oracle.scalar_linearize(2, tr, yr, x, numeric=numeric, dtype=dtype)
+            want = tuple(np.asarray(v, dtype=np.float64) for v in want)
+            check(c.linearize(x, 2 if numeric else 0), want,
+                  tol=tol if tol else (fd_tolerance(x) if numeric else REL))
+
+    # a damped oscillation observed in two channels
+    count = 20_011
+    planes = np.stack([np.linspace(0.0, 6.0, count), rng.normal(0, 0.05, count),
+                       rng.normal(0, 0.05, count)])
+    x = np.array([1.3, 0.4, 2.1])
+
+    def residual(x, d):
+        e = np.exp(-x[1] * d[0])
+        return np.stack([d[1] - x[0] * e * np.cos(x[2] * d[0]),
+                         d[2] - x[0] * e * np.sin(x[2] * d[0])], axis=1)
+
+    def jacobian(x, d):
+        e = np.exp(-x[1] * d[0])
+        cs, sn = np.cos(x[2] * d[0]), np.sin(x[2] * d[0])
+        J = np.empty((d.shape[1], 2, 3))
+        J[:, 0, 0] = -e * cs
+        J[:, 0, 1] = x[0] * d[0] * e * cs
+        J[:, 0, 2] = x[0] * e * d[0] * sn
+        J[:, 1, 0] = -e * sn
+        J[:, 1, 1] = x[0] * d[0] * e * sn
+        J[:, 1, 2] = -x[0] * e * d[0] * cs
+        return J
+
+    c = hip_lib.JitModelCost(
+        3, 2,
+        """const S e = exp(-x[1] * d[0]);
+           r[0] = d[1] - x[0] * e * cos(x[2] * d[0]);
+           r[1] = d[2] - x[0] * e * sin(x[2] * d[0]);""",
+        """const S e = exp(-x[1] * d[0]), cs = cos(x[2] * d[0]), sn = sin(x[2] * d[0]);
+           J[0] = -e * cs; J[1] = x[0] * d[0] * e * cs; J[2] = x[0] * e * d[0] * sn;
+           J[3] = -e * sn; J[4] = x[0] * d[0] * e * sn; J[5] = -x[0] * e * d[0] * cs;""",
+        planes=planes)
+    cov = np.array([[2.0, 0.3], [-0.1, 0.5]])
+    for cv in (None, cov):
+        for loss in (None, 0.8):
+            c.set_covariance(cv)
+            c.set_loss(0 if loss is None else 1, loss or 0.0)
+            check(c.linearize(x, 2), numpy_linearize(residual, planes, x, cov=cv, loss=loss),
+                  tol=fd_tolerance(x))
+            check(c.linearize(x, 0),
+                  numpy_linearize(residual, planes, x, numeric_jac=jacobian(x, planes), cov=cv,
+                                  loss=loss), tol=1e-11)
+
+    # n = 8, m = 4: r_a = d_a - sum_k x_{2a'+k} basis, every parameter in some output
+    count = 3001
+    planes = rng.normal(0, 1.0, (5, count))
+    x8 = np.array([0.3, -1.2, 0.8, 0.05, 1.7, -0.6, 0.9, 2.2])
+
+    def residual8(x, d):
+        return np.stack([d[1] - (x[0] * d[0] + x[1]) * x[4],
+                         d[2] - (x[2] * d[0] * d[0] + x[3]) * x[5],
+                         d[3] - np.sin(x[6] * d[0]) * x[0],
+                         d[4] - x[7] * x[1] * d[0]], axis=1)
+
+    c = hip_lib.JitModelCost(
+        8, 4,
+        """r[0] = d[1] - (x[0] * d[0] + x[1]) * x[4];
+           r[1] = d[2] - (x[2] * d[0] * d[0] + x[3]) * x[5];
+           r[2] = d[3] - sin(x[6] * d[0]) * x[0];
+           r[3] = d[4] - x[7] * x[1] * d[0];""", planes=planes)
+    check(c.linearize(x8, 2), numpy_linearize(residual8, planes, x8), tol=fd_tolerance(x8))
+
+    with pytest.raises(hip_lib.MoptError) as err:
+        hip_lib.JitModelCost(2, 1, "r[0] = not_declared(x[0]);", planes=np.stack([t, y]))
+    assert "not_declared" in str(err.value)
+
+
 def test_set_data_replaces_correspondences(hip_lib, oracle):
     """mopt_point2point_set_data: new correspondences (smaller, equal and larger count) in an
     existing cost; the kept linearization must not leak across the change."""
