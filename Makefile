@@ -29,10 +29,13 @@ $(OBJDIR)/sweep_kernels.o: $(CSRC)/sweep_kernels.hip $(PUBLIC_HEADERS) | $(OBJDI
 $(OBJDIR)/c_abi.o: $(CSRC)/c_abi.cpp $(PUBLIC_HEADERS) | $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) $(INCLUDES) -x hip -c $< -o $@
 
+$(OBJDIR)/icp_grid.o: $(CSRC)/icp_grid.hip $(PUBLIC_HEADERS) | $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) $(INCLUDES) -c $< -o $@
+
 $(OBJDIR)/jit_model.o: $(CSRC)/jit_model.cpp $(PUBLIC_HEADERS) | $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) $(INCLUDES) -x hip -c $< -o $@
 
-$(LIB): $(OBJDIR)/sweep_kernels.o $(OBJDIR)/c_abi.o $(OBJDIR)/jit_model.o | $(LIBDIR)
+$(LIB): $(OBJDIR)/sweep_kernels.o $(OBJDIR)/c_abi.o $(OBJDIR)/jit_model.o $(OBJDIR)/icp_grid.o | $(LIBDIR)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -L$(ROCM)/lib -lrccl -lhiprtc \
 	    -Wl,-rpath,$(ROCM)/lib -Wl,--no-undefined
 

@@ -803,20 +803,35 @@ int mopt_point2point_set_data(mopt_cost *c, const void *src_xyz, const void *tgt
 }  // extern "C"
 
 namespace {
-// Counting sort of the targets into grid cells (host, once per target cloud).
+struct DeviceScratch {  // hipFree on scope exit
+  void *p = nullptr;
+  ~DeviceScratch() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+  template <typename T>
+  T *as() const { return static_cast<T *>(p); }
+};
+
+// Grid over the targets and cell-ordered copy of the sources, built on the device (icp_grid.hip);
+// the host only chooses the resolution.  On return `d_src_sorted` holds the n sources in cell
+// order (packed xyz) and matcher->order the original index of each.
 template <typename S>
-int buildIcpGrid(const S *tgt, long long m, double max_distance,
-                 std::unique_ptr<IcpMatcher> &out_matcher) {
+int buildIcpGrid(const S *src, long long n, const S *tgt, long long m, double max_distance,
+                 hipStream_t s, std::unique_ptr<IcpMatcher> &out_matcher,
+                 DeviceScratch &d_src_sorted) {
   auto mt = std::make_unique<IcpMatcher>();
   mt->max_dist = max_distance;
   mt->num_targets = m;
-  double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-  for (long long i = 0; i < m; ++i)
-    for (int a = 0; a < 3; ++a) {
-      const double v = double(tgt[3 * i + a]);
-      if (i == 0 || v < lo[a]) lo[a] = v;
-      if (i == 0 || v > hi[a]) hi[a] = v;
-    }
+  DeviceScratch d_tgt, d_src, d_perm_t, d_perm_s;
+  MOPT_HIP_TRY(d_tgt.alloc(size_t(m) * 3 * sizeof(S)));
+  MOPT_HIP_TRY(d_src.alloc(size_t(n) * 3 * sizeof(S)));
+  if (m > 0)
+    MOPT_HIP_TRY(hipMemcpyAsync(d_tgt.p, tgt, size_t(m) * 3 * sizeof(S), hipMemcpyHostToDevice, s));
+  if (n > 0)
+    MOPT_HIP_TRY(hipMemcpyAsync(d_src.p, src, size_t(n) * 3 * sizeof(S), hipMemcpyHostToDevice, s));
+  double lo[3], hi[3];
+  MOPT_HIP_TRY(mopt::icpBoundingBox<S>(d_tgt.as<S>(), m, lo, hi, s));
   // cell edge a hair above the search radius, so the 27 cells around a query hold every target
   // within it; enlarged when the box would need more than ~4 M cells
   double cell = max_distance * 1.001;
@@ -833,66 +848,32 @@ int buildIcpGrid(const S *tgt, long long m, double max_distance,
     mt->dims[a] = int(std::floor((hi[a] - lo[a]) / cell)) + 1;
     ncells *= mt->dims[a];
   }
-  std::vector<int> start(size_t(ncells) + 1, 0);
-  std::vector<int> cell_of(static_cast<size_t>(m));
-  for (long long i = 0; i < m; ++i) {
-    long long id = 0, stride = 1;
-    for (int a = 0; a < 3; ++a) {
-      int g = int(std::floor((double(tgt[3 * i + a]) - lo[a]) / cell));
-      g = g < 0 ? 0 : (g >= mt->dims[a] ? mt->dims[a] - 1 : g);
-      id += g * stride;
-      stride *= mt->dims[a];
-    }
-    cell_of[size_t(i)] = int(id);
-    start[size_t(id) + 1] += 1;
-  }
-  for (size_t k = 0; k < size_t(ncells); ++k) start[k + 1] += start[k];
-  std::vector<int> cursor(start.begin(), start.end() - 1);
-  std::vector<S> sorted(size_t(m) * 4, S(0));
-  for (long long i = 0; i < m; ++i) {  // stable: original order inside a cell
-    const size_t dst = size_t(cursor[size_t(cell_of[size_t(i)])]++);
-    for (int a = 0; a < 3; ++a) sorted[dst * 4 + a] = tgt[3 * i + a];
-  }
+  out_matcher = std::move(mt);  // from here on the caller frees the matcher's device arrays
+  IcpMatcher &g = *out_matcher;
+  MOPT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_cell_start), size_t(ncells + 1) * sizeof(int)));
+  MOPT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_matched), 64));
+  MOPT_HIP_TRY(d_perm_t.alloc(size_t(m) * sizeof(int)));
+  MOPT_HIP_TRY(mopt::icpSortByCell<S>(d_tgt.as<S>(), m, g.origin, g.cell, g.dims, d_perm_t.as<int>(),
+                                      g.d_cell_start, s));
   if (m > 0) {
-    MOPT_HIP_TRY(hipMalloc(&mt->d_sorted, sorted.size() * sizeof(S)));
-    MOPT_HIP_TRY(hipMemcpy(mt->d_sorted, sorted.data(), sorted.size() * sizeof(S),
-                           hipMemcpyHostToDevice));
+    MOPT_HIP_TRY(hipMalloc(&g.d_sorted, size_t(m) * 4 * sizeof(S)));
+    MOPT_HIP_TRY(mopt::icpGatherPoints<S>(d_tgt.as<S>(), d_perm_t.as<int>(), m,
+                                          static_cast<S *>(g.d_sorted), true, s));
   }
-  MOPT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&mt->d_cell_start), start.size() * sizeof(int)));
-  MOPT_HIP_TRY(hipMemcpy(mt->d_cell_start, start.data(), start.size() * sizeof(int),
-                         hipMemcpyHostToDevice));
-  MOPT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&mt->d_matched), 64));
-  out_matcher = std::move(mt);
+  // the sources in the cell order of their un-warped position
+  MOPT_HIP_TRY(d_perm_s.alloc(size_t(n) * sizeof(int)));
+  MOPT_HIP_TRY(mopt::icpSortByCell<S>(d_src.as<S>(), n, g.origin, g.cell, g.dims, d_perm_s.as<int>(),
+                                      nullptr, s));
+  MOPT_HIP_TRY(d_src_sorted.alloc(size_t(n) * 3 * sizeof(S)));
+  MOPT_HIP_TRY(mopt::icpGatherPoints<S>(d_src.as<S>(), d_perm_s.as<int>(), n, d_src_sorted.as<S>(),
+                                        false, s));
+  std::vector<int> perm(static_cast<size_t>(n));
+  if (n > 0)
+    MOPT_HIP_TRY(hipMemcpyAsync(perm.data(), d_perm_s.p, size_t(n) * sizeof(int),
+                                hipMemcpyDeviceToHost, s));
+  MOPT_HIP_TRY(hipStreamSynchronize(s));
+  g.order.assign(perm.begin(), perm.end());
   return MOPT_OK;
-}
-
-// Order of the sources by the grid cell of their position (stable), and the reordered copy.
-template <typename S>
-void sortSourcesByCell(const IcpMatcher &mt, const S *src, long long n, std::vector<long long> &order,
-                       std::vector<S> &sorted_src) {
-  long long ncells = 1;
-  for (int a = 0; a < 3; ++a) ncells *= mt.dims[a];
-  std::vector<long long> start(size_t(ncells) + 1, 0);
-  std::vector<long long> cell_of(static_cast<size_t>(n));
-  for (long long i = 0; i < n; ++i) {
-    long long id = 0, stride = 1;
-    for (int a = 0; a < 3; ++a) {
-      double g = std::floor((double(src[3 * i + a]) - mt.origin[a]) / mt.cell);
-      g = g < 0 ? 0 : (g >= mt.dims[a] ? mt.dims[a] - 1 : g);
-      id += (long long)g * stride;
-      stride *= mt.dims[a];
-    }
-    cell_of[size_t(i)] = id;
-    start[size_t(id) + 1] += 1;
-  }
-  for (size_t k = 0; k < size_t(ncells); ++k) start[k + 1] += start[k];
-  order.assign(static_cast<size_t>(n), 0);
-  sorted_src.assign(static_cast<size_t>(n) * 3, S(0));
-  for (long long i = 0; i < n; ++i) {
-    const size_t dst = size_t(start[size_t(cell_of[size_t(i)])]++);
-    order[dst] = i;
-    for (int a = 0; a < 3; ++a) sorted_src[dst * 3 + a] = src[3 * i + a];
-  }
 }
 
 template <typename S>
@@ -934,7 +915,7 @@ int mopt_icp_create(mopt_cost **out, int device, int scalar_bytes, const void *s
   if (!out) return fail(MOPT_ERR_INVALID_ARGUMENT, "out is NULL");
   *out = nullptr;
   if (num_src < 0 || num_tgt < 0 || (num_src > 0 && !src_xyz) || (num_tgt > 0 && !tgt_xyz) ||
-      num_tgt > std::numeric_limits<int>::max())
+      num_tgt > std::numeric_limits<int>::max() || num_src > std::numeric_limits<int>::max())
     return fail(MOPT_ERR_INVALID_ARGUMENT, "bad clouds");
   if (!(max_distance > 0.0)) return fail(MOPT_ERR_INVALID_ARGUMENT, "max_distance must be > 0");
   int ndev = 0;
@@ -943,31 +924,30 @@ int mopt_icp_create(mopt_cost **out, int device, int scalar_bytes, const void *s
   if (device < 0 || device >= ndev) return fail(MOPT_ERR_INVALID_ARGUMENT, "device index out of range");
   MOPT_HIP_TRY(hipSetDevice(device));
   std::unique_ptr<IcpMatcher> matcher;
-  int rc = scalar_bytes == 8
-               ? buildIcpGrid<double>(static_cast<const double *>(tgt_xyz), num_tgt, max_distance, matcher)
-               : buildIcpGrid<float>(static_cast<const float *>(tgt_xyz), num_tgt, max_distance, matcher);
   auto freeMatcher = [&]() {
     if (!matcher) return;
     if (matcher->d_sorted) (void)hipFree(matcher->d_sorted);
     if (matcher->d_cell_start) (void)hipFree(matcher->d_cell_start);
     if (matcher->d_matched) (void)hipFree(matcher->d_matched);
   };
-  if (rc != MOPT_OK) {
-    freeMatcher();
-    return rc;
-  }
+  hipStream_t build_stream = nullptr;
+  MOPT_HIP_TRY(hipStreamCreateWithFlags(&build_stream, hipStreamNonBlocking));
+  DeviceScratch d_src_sorted;
+  int rc = scalar_bytes == 8
+               ? buildIcpGrid<double>(static_cast<const double *>(src_xyz), num_src,
+                                      static_cast<const double *>(tgt_xyz), num_tgt, max_distance,
+                                      build_stream, matcher, d_src_sorted)
+               : buildIcpGrid<float>(static_cast<const float *>(src_xyz), num_src,
+                                     static_cast<const float *>(tgt_xyz), num_tgt, max_distance,
+                                     build_stream, matcher, d_src_sorted);
+  (void)hipStreamSynchronize(build_stream);
+  (void)hipStreamDestroy(build_stream);
   // the sources go into the resident tiles in cell order; the target planes are filled by the
   // first search
   mopt_cost *raw = nullptr;
-  if (scalar_bytes == 8) {
-    std::vector<double> sorted;
-    sortSourcesByCell<double>(*matcher, static_cast<const double *>(src_xyz), num_src, matcher->order, sorted);
-    rc = mopt_point2point_create(&raw, device, 8, sorted.data(), sorted.data(), num_src, MOPT_INPUT_HOST);
-  } else {
-    std::vector<float> sorted;
-    sortSourcesByCell<float>(*matcher, static_cast<const float *>(src_xyz), num_src, matcher->order, sorted);
-    rc = mopt_point2point_create(&raw, device, 4, sorted.data(), sorted.data(), num_src, MOPT_INPUT_HOST);
-  }
+  if (rc == MOPT_OK)
+    rc = mopt_point2point_create(&raw, device, scalar_bytes, d_src_sorted.p, d_src_sorted.p, num_src,
+                                 MOPT_INPUT_DEVICE);
   if (rc != MOPT_OK) {
     freeMatcher();
     return rc;

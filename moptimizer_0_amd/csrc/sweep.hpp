@@ -166,6 +166,22 @@ hipError_t launchIcpMatch(const IcpMatchArgs<S> &args, hipStream_t stream);
 template <typename S>
 hipError_t launchGatherTargets(const S *tiles, long long count, S *out_xyz, hipStream_t stream);
 
+// Grid construction for the search (icp_grid.hip).  All pointers are device memory.
+//   icpBoundingBox   min / max of m packed points (synchronises the stream)
+//   icpSortByCell    d_perm[k] = original index of the k-th point in (cell id, original index)
+//                    order; d_cell_start (optional) [cells + 1] offsets into that order
+//                    (synchronises the stream)
+//   icpGatherPoints  out[k] = xyz[d_perm[k]], packed (3) or padded to 4 scalars
+template <typename S>
+hipError_t icpBoundingBox(const S *d_xyz, long long m, double lo[3], double hi[3],
+                          hipStream_t stream);
+template <typename S>
+hipError_t icpSortByCell(const S *d_xyz, long long m, const double origin[3], double cell,
+                         const int dims[3], int *d_perm, int *d_cell_start, hipStream_t stream);
+template <typename S>
+hipError_t icpGatherPoints(const S *d_xyz, const int *d_perm, long long m, S *d_out, bool padded,
+                           hipStream_t stream);
+
 // device result (count doubles) -> mapped host memory + flag (after a collective)
 hipError_t launchPublish(const double *d_values, int count, const HostPublish &pub,
                          hipStream_t stream);

@@ -7,7 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import moptimizer_0_amd as mo
 
-for n, per_cell in ((1_000_000, 1.0), (1_000_000, 4.0), (4_000_000, 1.0)):
+mo.capi.device_count()
+for n, per_cell in ((1_000, 1.0), (1_000_000, 1.0), (1_000_000, 4.0), (4_000_000, 1.0)):
     rng = np.random.default_rng(1)
     side = 100.0
     tgt = rng.random((n, 3)) * side
@@ -22,6 +23,6 @@ for n, per_cell in ((1_000_000, 1.0), (1_000_000, 4.0), (4_000_000, 1.0)):
     for _ in range(10):
         t0 = time.perf_counter(); m = cost.update(x); ts.append(time.perf_counter() - t0)
     dt = float(np.median(ts))
-    print("n=%d targets/cell~%.0f max_dist=%.3f: create (host grid build + upload) %.0f ms; "
+    print("n=%d targets/cell~%.0f max_dist=%.3f: create (upload + GPU grid build + first search) %.0f ms; "
           "update %.3f ms = %.2e sources/s, %d matched" % (n, per_cell, max_dist, build * 1e3, dt * 1e3, n / dt, m), flush=True)
     cost.close()

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Throughput of the generic sweeps (built-in scalar models and run-time compiled user models) at
+data-set sizes far beyond the reference's tests: HIP-event time of the sweep kernel and the
+algorithmic GB/s (planes x sizeof(S) per element).
+Usage: python scripts/jit_timing.py [--n 10000000]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def timed(cost, x, mode, iters):
+    cost.set_speculation(False)
+    for _ in range(3):
+        cost.linearize(x, mode)
+    cost.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        cost.linearize(x, mode)
+    wall = (time.perf_counter() - t0) / iters
+    ms, cnt = cost.profile()
+    cost.set_profiling(False)
+    return ms / cnt * 1e3, wall * 1e6
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, nargs="+", default=[10_000_000, 1_000_000])
+    ap.add_argument("--iters", type=int, default=30)
+    args = ap.parse_args()
+    import moptimizer_0_amd as mo
+
+    rng = np.random.default_rng(3)
+    for n in args.n:
+        t = np.linspace(0.0, 4.95, n)
+        y = np.exp(0.3 * t + 0.1) + rng.normal(0, 0.2, n)
+        x = np.array([0.29, 0.13])
+        t0 = time.perf_counter()
+        jit = mo.JitModelCost(2, 1, "r[0] = d[1] - exp(x[0] * d[0] + x[1]);",
+                              "const S e = exp(x[0] * d[0] + x[1]); J[0] = -d[0] * e; J[1] = -e;",
+                              planes=np.stack([t, y]))
+        create_ms = (time.perf_counter() - t0) * 1e3
+        builtin = mo.ScalarModelCost(mo.capi.MODEL_EXP_CURVE, t, y)
+        for name, cost, mode in (("built-in exp curve, numeric", builtin, 2),
+                                 ("jit exp curve, numeric", jit, 2),
+                                 ("jit exp curve, analytic", jit, 0)):
+            k, wall = timed(cost, x, mode, args.iters)
+            print("n=%9d %-30s kernel %8.2f us  %7.1f GB/s  call %8.2f us" %
+                  (n, name, k, n * 16 / (k * 1e-6) / 1e9, wall), flush=True)
+        print("n=%9d jit create (compile + upload) %.1f ms" % (n, create_ms), flush=True)
+        planes = rng.normal(0, 1.0, (3, n))
+        planes[0] = np.linspace(0.0, 6.0, n)
+        osc = mo.JitModelCost(
+            3, 2,
+            "const S e = exp(-x[1] * d[0]); r[0] = d[1] - x[0] * e * cos(x[2] * d[0]);"
+            "r[1] = d[2] - x[0] * e * sin(x[2] * d[0]);", planes=planes)
+        k, wall = timed(osc, np.array([1.3, 0.4, 2.1]), 2, args.iters)
+        print("n=%9d %-30s kernel %8.2f us  %7.1f GB/s  call %8.2f us" %
+              (n, "jit oscillation n=3 m=2, numeric", k, n * 24 / (k * 1e-6) / 1e9, wall), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -735,6 +735,28 @@ def test_baseline_configs_2_and_3_full_size_against_oracle(hip_lib, oracle, jac_
     assert abs(cost.compute_cost(ds.X_GENERIC) - want) <= REL * want
 
 
+def test_parallel_cost_test_of_the_reference(hip_lib, oracle):
+    """tst/parallel.cpp:39-94 with the GPU cost sweep in place of parallelComputeCost: 1 000 000
+    points in [0,10]^3, target = source + (1,2,3), pure translation (x = 0 here since the offset is
+    in the data).  The reference asserts |parallel - serial| <= 1e-8 on a sum of ~1.4e7; the
+    GPU sum associates differently from the serial loop, so the bound used is 1e-12 relative
+    (the observed distance is printed by scripts/parity_table.py-style runs; it is ~1e-15)."""
+    rng = np.random.default_rng(70)
+    src = rng.uniform(0.0, 10.0, (1_000_000, 3))
+    tgt = src + np.array([1.0, 2.0, 3.0])
+    cost = hip_lib.Point2PointCost(src, tgt)
+    cost.set_speculation(False)
+    serial = oracle.p2p_cost(src, tgt, ds.X_ZERO)
+    got = cost.compute_cost(ds.X_ZERO)
+    assert abs(serial - 14.0e6) < 1e-3
+    assert abs(got - serial) <= 1e-12 * serial, (got, serial)
+    # the same number from the linearization sweep, and with the offset as the parameter instead
+    assert abs(cost.linearize(ds.X_ZERO, 0)[2] - serial) <= 1e-12 * serial
+    moved = hip_lib.Point2PointCost(src, src)
+    x = np.array([-1.0, -2.0, -3.0, 0.0, 0.0, 0.0])
+    assert abs(moved.compute_cost(x) - 14.0e6) <= 1e-12 * 14.0e6
+
+
 def test_group_shards_on_one_gpu(hip_lib, oracle):
     """mopt_group_* with a repeated device: three contiguous shards of a ragged count on GPU 0.
     Same result as one cost over everything (shard invariance) and as the oracle."""
