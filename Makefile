@@ -16,7 +16,7 @@ LIBDIR      = moptimizer_0_amd/lib
 LIB         = $(LIBDIR)/libmoptimizer_hip.so
 
 PUBLIC_HEADERS = include/moptimizer_hip.h include/moptimizer_amd/so3.hpp $(CSRC)/sweep.hpp \
-                 $(CSRC)/jit_model.hpp
+                 $(CSRC)/jit_model.hpp $(CSRC)/cost_state.hpp
 
 all: $(LIB)
 
@@ -26,16 +26,16 @@ $(OBJDIR) $(LIBDIR):
 $(OBJDIR)/sweep_kernels.o: $(CSRC)/sweep_kernels.hip $(PUBLIC_HEADERS) | $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) $(INCLUDES) -c $< -o $@
 
-$(OBJDIR)/c_abi.o: $(CSRC)/c_abi.cpp $(PUBLIC_HEADERS) | $(OBJDIR)
+$(OBJDIR)/%.o: $(CSRC)/%.cpp $(PUBLIC_HEADERS) | $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) $(INCLUDES) -x hip -c $< -o $@
 
 $(OBJDIR)/icp_grid.o: $(CSRC)/icp_grid.hip $(PUBLIC_HEADERS) | $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) $(INCLUDES) -c $< -o $@
 
-$(OBJDIR)/jit_model.o: $(CSRC)/jit_model.cpp $(PUBLIC_HEADERS) | $(OBJDIR)
-	$(HIPCC) $(HIPFLAGS) $(INCLUDES) -x hip -c $< -o $@
+OBJS = $(OBJDIR)/sweep_kernels.o $(OBJDIR)/icp_grid.o $(OBJDIR)/c_abi.o $(OBJDIR)/icp.o \
+       $(OBJDIR)/group.o $(OBJDIR)/jit_model.o
 
-$(LIB): $(OBJDIR)/sweep_kernels.o $(OBJDIR)/c_abi.o $(OBJDIR)/jit_model.o $(OBJDIR)/icp_grid.o | $(LIBDIR)
+$(LIB): $(OBJS) | $(LIBDIR)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -L$(ROCM)/lib -lrccl -lhiprtc \
 	    -Wl,-rpath,$(ROCM)/lib -Wl,--no-undefined
 

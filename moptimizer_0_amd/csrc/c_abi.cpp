@@ -2,147 +2,30 @@
 // the once-per-x host work (SE(3) transforms, forward-difference steps), kernel selection and
 // the RCCL-combined device group.  There is no CPU implementation behind any entry point: when
 // HIP cannot run the work the call returns an error code.
-#include "moptimizer_hip.h"
-
-#include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+#include "cost_state.hpp"
 
 #include <chrono>
 #include <cmath>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <limits>
-#include <memory>
 #include <new>
-#include <string>
-#include <utility>
-#include <vector>
 
 #include "moptimizer_amd/so3.hpp"
-#include "jit_model.hpp"
-#include "sweep.hpp"
+
+using namespace mopt_detail;
 
 namespace {
-
 thread_local std::string g_last_error;
+}  // namespace
 
-int fail(int code, const std::string &msg) {
+int mopt_detail::fail(int code, const std::string &msg) {
   g_last_error = msg;
   return code;
 }
 
-#define MOPT_HIP_TRY(expr)                                                                  \
-  do {                                                                                      \
-    hipError_t e_ = (expr);                                                                 \
-    if (e_ != hipSuccess)                                                                   \
-      return fail(MOPT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
-  } while (0)
-
-#define MOPT_NCCL_TRY(expr)                                                                 \
-  do {                                                                                      \
-    ncclResult_t r_ = (expr);                                                               \
-    if (r_ != ncclSuccess)                                                                  \
-      return fail(MOPT_ERR_RCCL, std::string(#expr) + ": " + ncclGetErrorString(r_));      \
-  } while (0)
-
-enum ModelKind { kModelPoint2Point = 1, kModelReprojection = 2, kModelScalar = 3, kModelJit = 4 };
-constexpr int kMaxParamBytes = mopt::kMaxParams * 8;
-constexpr int kResultSlots = 96;  // >= n*n + n + 1 for n <= 8 (73)
-
-int envInt(const char *name, int fallback) {
-  const char *v = std::getenv(name);
-  if (!v || !*v) return fallback;
-  const int parsed = std::atoi(v);
-  return parsed > 0 ? parsed : fallback;
-}
-
-}  // namespace
-
-// Uniform grid over the target cloud of an ICP cost (built once on the host, resident in HBM).
-struct IcpMatcher {
-  void *d_sorted = nullptr;      // [num_targets][4] scalars grouped by cell
-  int *d_cell_start = nullptr;   // [cells + 1]
-  unsigned int *d_matched = nullptr;
-  double origin[3] = {0, 0, 0};
-  double cell = 1.0;
-  int dims[3] = {1, 1, 1};
-  double max_dist = 0.0;
-  long long num_targets = 0;
-  // Sources are stored in grid-cell order (of their un-warped position) so that neighbouring
-  // lanes visit neighbouring cells; slot k of the tiles holds the caller's source order[k].
-  std::vector<long long> order;
-};
-
-struct mopt_cost {
-  int device = 0;
-  int scalar_bytes = 8;
-  int model = kModelPoint2Point;
-  int scalar_model = 0;  // mopt::ScalarModelKind when model == kModelScalar
-  int n_params = mopt::kNumParams;
-  int n_out = 3;
-  long long data_stride = 0;  // scalar models: elements per data plane
-  long long count = 0;
-  int num_tiles = 0;
-  int num_cus = 0;
-  int max_grid = 0;
-
-  void *d_tiles = nullptr;
-  long long capacity_tiles = 0;  // tiles allocated in d_tiles
-  double *d_partials = nullptr;
-  double *d_result = nullptr;  // kResultDoubles
-  // Mapped, fine-grained host memory the finalize kernel publishes into: 43 results + flag word.
-  double *h_result = nullptr;
-  unsigned long long *h_flag = nullptr;
-  double *h_result_dev = nullptr;  // the same memory as the device addresses it
-  unsigned long long *h_flag_dev = nullptr;
-  unsigned long long sequence = 0;
-  hipStream_t stream = nullptr;
-  ncclComm_t comm = nullptr;  // multi-process shard group (one rank per GPU), optional
-  int comm_size = 1;
-
-  double cov[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // row-major, stride 3 (m <= 3), as double
-  double cov_m[16] = {1};                        // row-major m x m compact (scalar models, m <= 4)
-  int cov_mode = mopt::kCovIdentity;
-  int loss_kind = MOPT_LOSS_NONE;
-  double loss_param = 0.0;
-  int variant = MOPT_KERNEL_AUTO;
-
-  double camera[12];
-  double frame[16];
-
-  std::unique_ptr<IcpMatcher> matcher;  // point2point costs created by mopt_icp_create
-  mopt::JitKernel jit;                  // kModelJit: the run-time compiled sweep
-
-  // LM calls computeCost(xi) and, when the step is accepted, linearize(xi) right after
-  // (levenberg_marquadt_dyn.cpp:86,112 then :55): with speculation on, computeCost runs the
-  // linearization sweep (same HBM traffic as the cost sweep) and keeps its H | b | sum_sq, so the
-  // following linearize at the same x costs no sweep at all.
-  bool speculate = true;
-  int last_jac_mode = -1;
-  unsigned long long state_version = 0;  // bumped when loss / covariance / variant change
-  struct {
-    bool valid = false;
-    int mode = -1;
-    unsigned long long version = 0;
-    unsigned char x[kMaxParamBytes] = {0};
-    double result[kResultSlots] = {0};
-  } cache;
-  long long stat_sweeps = 0;
-  long long stat_cache_hits = 0;
-
-  int profiling = 0;  // 0 off, N > 0: bracket every N-th sweep launch with events
-  long long profiling_tick = 0;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
-  std::vector<hipEvent_t> free_events;
-  double sweep_ms_total = 0.0;
-  long long sweep_launches = 0;
-};
-
 namespace {
 
-using mopt::kNumParams;
-using mopt::kResultDoubles;
 
 inline int resultCount(const mopt_cost *c) { return c->n_params * c->n_params + c->n_params + 1; }
 inline int costOffset(const mopt_cost *c) { return c->n_params * c->n_params + c->n_params; }
@@ -518,8 +401,11 @@ int jitSweepAsync(mopt_cost *c, bool cost_only, int jac_mode, const S *x, double
   return MOPT_OK;
 }
 
+}  // namespace
+
+namespace mopt_detail {
 int linearizeAsyncImpl(mopt_cost *c, int jac_mode, const void *x, double *d_result, hipStream_t s,
-                       const mopt::HostPublish &pub = mopt::HostPublish()) {
+                       const mopt::HostPublish &pub) {
   if (jac_mode < MOPT_JAC_ANALYTIC || jac_mode > MOPT_JAC_NUMERIC)
     return fail(MOPT_ERR_INVALID_ARGUMENT, "unknown jacobian_mode");
   if (c->model == kModelJit)
@@ -542,7 +428,7 @@ int linearizeAsyncImpl(mopt_cost *c, int jac_mode, const void *x, double *d_resu
 }
 
 int costAsyncImpl(mopt_cost *c, const void *x, double *d_sum, hipStream_t s,
-                  const mopt::HostPublish &pub = mopt::HostPublish()) {
+                  const mopt::HostPublish &pub) {
   if (c->model == kModelJit)
     return c->scalar_bytes == 8
                ? jitSweepAsync<double>(c, true, 0, static_cast<const double *>(x), d_sum, s, pub)
@@ -558,6 +444,9 @@ int costAsyncImpl(mopt_cost *c, const void *x, double *d_sum, hipStream_t s,
   return p2pCostAsync<float>(c, static_cast<const float *>(x), d_sum, s, pub);
 }
 
+}  // namespace mopt_detail
+
+namespace {
 // Blocking completion without a copy or a stream synchronisation: the last kernel of the call
 // stores the results into mapped host memory and then releases `sequence` into the flag word;
 // the host polls that word.  The stream is queried now and then so that a faulted kernel turns
@@ -614,6 +503,9 @@ int blockingSweep(mopt_cost *c, bool cost_only, int jac_mode, const void *x) {
   return waitPublished(c, pub.sequence);
 }
 
+}  // namespace
+
+namespace mopt_detail {
 void storeResult(const mopt_cost *c, const double *res, void *hessian, void *b, void *sum_sq) {
   const int n = c->n_params, nn = n * n;
   if (c->scalar_bytes == 8) {
@@ -680,6 +572,9 @@ void destroyCost(mopt_cost *c) {
   delete c;
 }
 
+}  // namespace mopt_detail
+
+namespace {
 // Copies (or adopts) two input arrays into device staging memory and returns device pointers.
 struct Staging {
   void *a = nullptr, *b = nullptr;
@@ -800,205 +695,6 @@ int mopt_point2point_set_data(mopt_cost *c, const void *src_xyz, const void *tgt
   return MOPT_OK;
 }
 
-}  // extern "C"
-
-namespace {
-struct DeviceScratch {  // hipFree on scope exit
-  void *p = nullptr;
-  ~DeviceScratch() {
-    if (p) (void)hipFree(p);
-  }
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
-  template <typename T>
-  T *as() const { return static_cast<T *>(p); }
-};
-
-// Grid over the targets and cell-ordered copy of the sources, built on the device (icp_grid.hip);
-// the host only chooses the resolution.  On return `d_src_sorted` holds the n sources in cell
-// order (packed xyz) and matcher->order the original index of each.
-template <typename S>
-int buildIcpGrid(const S *src, long long n, const S *tgt, long long m, double max_distance,
-                 hipStream_t s, std::unique_ptr<IcpMatcher> &out_matcher,
-                 DeviceScratch &d_src_sorted) {
-  auto mt = std::make_unique<IcpMatcher>();
-  mt->max_dist = max_distance;
-  mt->num_targets = m;
-  DeviceScratch d_tgt, d_src, d_perm_t, d_perm_s;
-  MOPT_HIP_TRY(d_tgt.alloc(size_t(m) * 3 * sizeof(S)));
-  MOPT_HIP_TRY(d_src.alloc(size_t(n) * 3 * sizeof(S)));
-  if (m > 0)
-    MOPT_HIP_TRY(hipMemcpyAsync(d_tgt.p, tgt, size_t(m) * 3 * sizeof(S), hipMemcpyHostToDevice, s));
-  if (n > 0)
-    MOPT_HIP_TRY(hipMemcpyAsync(d_src.p, src, size_t(n) * 3 * sizeof(S), hipMemcpyHostToDevice, s));
-  double lo[3], hi[3];
-  MOPT_HIP_TRY(mopt::icpBoundingBox<S>(d_tgt.as<S>(), m, lo, hi, s));
-  // cell edge a hair above the search radius, so the 27 cells around a query hold every target
-  // within it; enlarged when the box would need more than ~4 M cells
-  double cell = max_distance * 1.001;
-  for (;;) {
-    double cells = 1.0;
-    for (int a = 0; a < 3; ++a) cells *= std::floor((hi[a] - lo[a]) / cell) + 1.0;
-    if (cells <= double(1 << 22)) break;
-    cell *= 1.26;
-  }
-  mt->cell = cell;
-  long long ncells = 1;
-  for (int a = 0; a < 3; ++a) {
-    mt->origin[a] = lo[a];
-    mt->dims[a] = int(std::floor((hi[a] - lo[a]) / cell)) + 1;
-    ncells *= mt->dims[a];
-  }
-  out_matcher = std::move(mt);  // from here on the caller frees the matcher's device arrays
-  IcpMatcher &g = *out_matcher;
-  MOPT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_cell_start), size_t(ncells + 1) * sizeof(int)));
-  MOPT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_matched), 64));
-  MOPT_HIP_TRY(d_perm_t.alloc(size_t(m) * sizeof(int)));
-  MOPT_HIP_TRY(mopt::icpSortByCell<S>(d_tgt.as<S>(), m, g.origin, g.cell, g.dims, d_perm_t.as<int>(),
-                                      g.d_cell_start, s));
-  if (m > 0) {
-    MOPT_HIP_TRY(hipMalloc(&g.d_sorted, size_t(m) * 4 * sizeof(S)));
-    MOPT_HIP_TRY(mopt::icpGatherPoints<S>(d_tgt.as<S>(), d_perm_t.as<int>(), m,
-                                          static_cast<S *>(g.d_sorted), true, s));
-  }
-  // the sources in the cell order of their un-warped position
-  MOPT_HIP_TRY(d_perm_s.alloc(size_t(n) * sizeof(int)));
-  MOPT_HIP_TRY(mopt::icpSortByCell<S>(d_src.as<S>(), n, g.origin, g.cell, g.dims, d_perm_s.as<int>(),
-                                      nullptr, s));
-  MOPT_HIP_TRY(d_src_sorted.alloc(size_t(n) * 3 * sizeof(S)));
-  MOPT_HIP_TRY(mopt::icpGatherPoints<S>(d_src.as<S>(), d_perm_s.as<int>(), n, d_src_sorted.as<S>(),
-                                        false, s));
-  std::vector<int> perm(static_cast<size_t>(n));
-  if (n > 0)
-    MOPT_HIP_TRY(hipMemcpyAsync(perm.data(), d_perm_s.p, size_t(n) * sizeof(int),
-                                hipMemcpyDeviceToHost, s));
-  MOPT_HIP_TRY(hipStreamSynchronize(s));
-  g.order.assign(perm.begin(), perm.end());
-  return MOPT_OK;
-}
-
-template <typename S>
-int icpUpdate(mopt_cost *c, const S *x, int64_t *num_matched) {
-  const IcpMatcher &mt = *c->matcher;
-  mopt::IcpMatchArgs<S> a;
-  a.tiles = static_cast<S *>(c->d_tiles);
-  a.count = c->count;
-  a.num_tiles = c->num_tiles;
-  a.sorted = static_cast<const S *>(mt.d_sorted);
-  a.cell_start = mt.d_cell_start;
-  for (int k = 0; k < 3; ++k) {
-    a.origin[k] = S(mt.origin[k]);
-    a.dims[k] = mt.dims[k];
-  }
-  a.inv_cell = S(1.0 / mt.cell);
-  a.max_dist2 = S(mt.max_dist * mt.max_dist);
-  const auto T = moptimizer::so3::rigidFrom6DOF<S>(x);
-  std::memcpy(a.T, T.m, sizeof T.m);
-  a.matched = num_matched ? mt.d_matched : nullptr;
-  if (num_matched) MOPT_HIP_TRY(hipMemsetAsync(mt.d_matched, 0, sizeof(unsigned int), c->stream));
-  MOPT_HIP_TRY(mopt::launchIcpMatch<S>(a, c->stream));
-  c->cache.valid = false;
-  c->state_version += 1;
-  if (num_matched) {
-    unsigned int n = 0;
-    MOPT_HIP_TRY(hipMemcpyAsync(&n, mt.d_matched, sizeof n, hipMemcpyDeviceToHost, c->stream));
-    MOPT_HIP_TRY(hipStreamSynchronize(c->stream));
-    *num_matched = int64_t(n);
-  }
-  return MOPT_OK;
-}
-}  // namespace
-
-extern "C" {
-
-int mopt_icp_create(mopt_cost **out, int device, int scalar_bytes, const void *src_xyz,
-                    int64_t num_src, const void *tgt_xyz, int64_t num_tgt, double max_distance) {
-  if (!out) return fail(MOPT_ERR_INVALID_ARGUMENT, "out is NULL");
-  *out = nullptr;
-  if (num_src < 0 || num_tgt < 0 || (num_src > 0 && !src_xyz) || (num_tgt > 0 && !tgt_xyz) ||
-      num_tgt > std::numeric_limits<int>::max() || num_src > std::numeric_limits<int>::max())
-    return fail(MOPT_ERR_INVALID_ARGUMENT, "bad clouds");
-  if (!(max_distance > 0.0)) return fail(MOPT_ERR_INVALID_ARGUMENT, "max_distance must be > 0");
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-    return fail(MOPT_ERR_NO_DEVICE, "no HIP device is visible to this process");
-  if (device < 0 || device >= ndev) return fail(MOPT_ERR_INVALID_ARGUMENT, "device index out of range");
-  MOPT_HIP_TRY(hipSetDevice(device));
-  std::unique_ptr<IcpMatcher> matcher;
-  auto freeMatcher = [&]() {
-    if (!matcher) return;
-    if (matcher->d_sorted) (void)hipFree(matcher->d_sorted);
-    if (matcher->d_cell_start) (void)hipFree(matcher->d_cell_start);
-    if (matcher->d_matched) (void)hipFree(matcher->d_matched);
-  };
-  hipStream_t build_stream = nullptr;
-  MOPT_HIP_TRY(hipStreamCreateWithFlags(&build_stream, hipStreamNonBlocking));
-  DeviceScratch d_src_sorted;
-  int rc = scalar_bytes == 8
-               ? buildIcpGrid<double>(static_cast<const double *>(src_xyz), num_src,
-                                      static_cast<const double *>(tgt_xyz), num_tgt, max_distance,
-                                      build_stream, matcher, d_src_sorted)
-               : buildIcpGrid<float>(static_cast<const float *>(src_xyz), num_src,
-                                     static_cast<const float *>(tgt_xyz), num_tgt, max_distance,
-                                     build_stream, matcher, d_src_sorted);
-  (void)hipStreamSynchronize(build_stream);
-  (void)hipStreamDestroy(build_stream);
-  // the sources go into the resident tiles in cell order; the target planes are filled by the
-  // first search
-  mopt_cost *raw = nullptr;
-  if (rc == MOPT_OK)
-    rc = mopt_point2point_create(&raw, device, scalar_bytes, d_src_sorted.p, d_src_sorted.p, num_src,
-                                 MOPT_INPUT_DEVICE);
-  if (rc != MOPT_OK) {
-    freeMatcher();
-    return rc;
-  }
-  std::unique_ptr<mopt_cost, void (*)(mopt_cost *)> c(raw, destroyCost);
-  c->matcher = std::move(matcher);
-  const double zero8[6] = {0, 0, 0, 0, 0, 0};
-  const float zero4[6] = {0, 0, 0, 0, 0, 0};
-  rc = mopt_icp_update(c.get(), scalar_bytes == 8 ? static_cast<const void *>(zero8)
-                                                   : static_cast<const void *>(zero4), nullptr);
-  if (rc != MOPT_OK) return rc;
-  *out = c.release();
-  return MOPT_OK;
-}
-
-int mopt_icp_update(mopt_cost *c, const void *x, int64_t *num_matched) {
-  if (!c || !x) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
-  if (!c->matcher) return fail(MOPT_ERR_INVALID_ARGUMENT, "not a cost made by mopt_icp_create");
-  MOPT_HIP_TRY(hipSetDevice(c->device));
-  return c->scalar_bytes == 8 ? icpUpdate<double>(c, static_cast<const double *>(x), num_matched)
-                              : icpUpdate<float>(c, static_cast<const float *>(x), num_matched);
-}
-
-int mopt_icp_get_matches(mopt_cost *c, void *tgt_out_xyz) {
-  if (!c || !tgt_out_xyz) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
-  if (c->model != kModelPoint2Point) return fail(MOPT_ERR_INVALID_ARGUMENT, "not a point2point cost");
-  MOPT_HIP_TRY(hipSetDevice(c->device));
-  if (c->count == 0) return MOPT_OK;
-  const size_t bytes = size_t(c->count) * 3 * c->scalar_bytes;
-  void *d_tmp = nullptr;
-  MOPT_HIP_TRY(hipMalloc(&d_tmp, bytes));
-  hipError_t e = c->scalar_bytes == 8
-                     ? mopt::launchGatherTargets<double>(static_cast<const double *>(c->d_tiles),
-                                                         c->count, static_cast<double *>(d_tmp), c->stream)
-                     : mopt::launchGatherTargets<float>(static_cast<const float *>(c->d_tiles),
-                                                        c->count, static_cast<float *>(d_tmp), c->stream);
-  const bool permuted = c->matcher && !c->matcher->order.empty();
-  std::vector<unsigned char> staged(permuted ? bytes : 0);
-  void *host_dst = permuted ? static_cast<void *>(staged.data()) : tgt_out_xyz;
-  if (e == hipSuccess) e = hipMemcpyAsync(host_dst, d_tmp, bytes, hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  (void)hipFree(d_tmp);
-  if (e != hipSuccess) return fail(MOPT_ERR_HIP, std::string("gather: ") + hipGetErrorString(e));
-  if (permuted) {  // slot k holds the caller's source order[k]
-    const size_t triple = size_t(3) * c->scalar_bytes;
-    for (long long k = 0; k < c->count; ++k)
-      std::memcpy(static_cast<unsigned char *>(tgt_out_xyz) + size_t(c->matcher->order[size_t(k)]) * triple,
-                  staged.data() + size_t(k) * triple, triple);
-  }
-  return MOPT_OK;
-}
 
 int mopt_reprojection_create(mopt_cost **out, int device, const double *points_xyzw,
                              const int32_t *pixels_uv, int64_t count, const double *camera_3x4,
@@ -1328,165 +1024,6 @@ int mopt_cost_profile(mopt_cost *c, double *sweep_ms_total, int64_t *sweep_launc
   if (rc != MOPT_OK) return rc;
   if (sweep_ms_total) *sweep_ms_total = c->sweep_ms_total;
   if (sweep_launches) *sweep_launches = c->sweep_launches;
-  return MOPT_OK;
-}
-
-}  // extern "C"
-
-// ---- single-process multi-GPU group --------------------------------------------------------
-struct mopt_group {
-  std::vector<mopt_cost *> shards;
-  std::vector<ncclComm_t> comms;
-  int scalar_bytes = 8;
-  // RCCL needs distinct devices.  A device list with repeats (several shards on one GPU: a
-  // rehearsal of the sharding on a smaller machine) combines the shard sums on the host instead.
-  bool host_combine = false;
-};
-
-namespace {
-void destroyGroup(mopt_group *g) {
-  if (!g) return;
-  for (auto comm : g->comms)
-    if (comm) ncclCommDestroy(comm);
-  for (auto *c : g->shards) destroyCost(c);
-  delete g;
-}
-}  // namespace
-
-extern "C" {
-
-int mopt_group_point2point_create(mopt_group **out, const int *devices, int num_devices,
-                                  int scalar_bytes, const void *src_xyz, const void *tgt_xyz,
-                                  int64_t count) {
-  if (!out) return fail(MOPT_ERR_INVALID_ARGUMENT, "out is NULL");
-  *out = nullptr;
-  if (!devices || num_devices < 1) return fail(MOPT_ERR_INVALID_ARGUMENT, "no devices given");
-  if (scalar_bytes != 4 && scalar_bytes != 8)
-    return fail(MOPT_ERR_INVALID_ARGUMENT, "scalar_bytes must be 4 or 8");
-  std::unique_ptr<mopt_group, void (*)(mopt_group *)> g(new (std::nothrow) mopt_group,
-                                                        destroyGroup);
-  if (!g) return fail(MOPT_ERR_HIP, "out of host memory");
-  g->scalar_bytes = scalar_bytes;
-  const char *src = static_cast<const char *>(src_xyz);
-  const char *tgt = static_cast<const char *>(tgt_xyz);
-  for (int k = 0; k < num_devices; ++k) {
-    // contiguous index ranges [k N / G, (k + 1) N / G)
-    const int64_t lo = count * k / num_devices, hi = count * (k + 1) / num_devices;
-    mopt_cost *shard = nullptr;
-    const int rc = mopt_point2point_create(&shard, devices[k], scalar_bytes,
-                                           src + size_t(lo) * 3 * scalar_bytes,
-                                           tgt + size_t(lo) * 3 * scalar_bytes, hi - lo,
-                                           MOPT_INPUT_HOST);
-    if (rc != MOPT_OK) return rc;
-    g->shards.push_back(shard);
-  }
-  for (int a = 0; a < num_devices; ++a)
-    for (int b = a + 1; b < num_devices; ++b)
-      if (devices[a] == devices[b]) g->host_combine = true;
-  if (num_devices > 1 && !g->host_combine) {
-    g->comms.assign(num_devices, nullptr);
-    MOPT_NCCL_TRY(ncclCommInitAll(g->comms.data(), num_devices, devices));
-  }
-  *out = g.release();
-  return MOPT_OK;
-}
-
-int mopt_group_destroy(mopt_group *group) {
-  destroyGroup(group);
-  return MOPT_OK;
-}
-
-int mopt_group_size(const mopt_group *g, int *num_devices) {
-  if (!g || !num_devices) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
-  *num_devices = int(g->shards.size());
-  return MOPT_OK;
-}
-
-int mopt_group_set_covariance(mopt_group *g, const void *cov_colmajor) {
-  if (!g) return fail(MOPT_ERR_INVALID_ARGUMENT, "group is NULL");
-  for (auto *c : g->shards) {
-    const int rc = mopt_cost_set_covariance(c, cov_colmajor);
-    if (rc != MOPT_OK) return rc;
-  }
-  return MOPT_OK;
-}
-
-int mopt_group_set_loss(mopt_group *g, int loss_kind, double parameter) {
-  if (!g) return fail(MOPT_ERR_INVALID_ARGUMENT, "group is NULL");
-  for (auto *c : g->shards) {
-    const int rc = mopt_cost_set_loss(c, loss_kind, parameter);
-    if (rc != MOPT_OK) return rc;
-  }
-  return MOPT_OK;
-}
-
-static int groupReduceAndFetch(mopt_group *g, int offset, int n_doubles) {
-  const int G = int(g->shards.size());
-  if (g->host_combine) {
-    for (int k = 0; k < G; ++k) {
-      mopt_cost *c = g->shards[k];
-      MOPT_HIP_TRY(hipSetDevice(c->device));
-      MOPT_HIP_TRY(hipMemcpyAsync(c->h_result + offset, c->d_result + offset,
-                                  n_doubles * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    }
-    for (int k = 0; k < G; ++k) {
-      MOPT_HIP_TRY(hipSetDevice(g->shards[k]->device));
-      MOPT_HIP_TRY(hipStreamSynchronize(g->shards[k]->stream));
-    }
-    double *total = g->shards[0]->h_result + offset;
-    for (int k = 1; k < G; ++k)  // shard order: deterministic
-      for (int q = 0; q < n_doubles; ++q) total[q] += g->shards[k]->h_result[offset + q];
-    return MOPT_OK;
-  }
-  if (G > 1) {
-    // one all-reduce per sweep over xGMI; every rank ends with the full sums
-    MOPT_NCCL_TRY(ncclGroupStart());
-    for (int k = 0; k < G; ++k) {
-      mopt_cost *c = g->shards[k];
-      ncclResult_t r = ncclAllReduce(c->d_result + offset, c->d_result + offset, n_doubles,
-                                     ncclDouble, ncclSum, g->comms[k], c->stream);
-      if (r != ncclSuccess) {
-        ncclGroupEnd();
-        return fail(MOPT_ERR_RCCL, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
-      }
-    }
-    MOPT_NCCL_TRY(ncclGroupEnd());
-  }
-  mopt_cost *c0 = g->shards[0];
-  MOPT_HIP_TRY(hipSetDevice(c0->device));
-  MOPT_HIP_TRY(hipMemcpyAsync(c0->h_result + offset, c0->d_result + offset,
-                              n_doubles * sizeof(double), hipMemcpyDeviceToHost, c0->stream));
-  for (int k = G - 1; k >= 0; --k) {
-    MOPT_HIP_TRY(hipSetDevice(g->shards[k]->device));
-    MOPT_HIP_TRY(hipStreamSynchronize(g->shards[k]->stream));
-  }
-  return MOPT_OK;
-}
-
-int mopt_group_linearize(mopt_group *g, int jacobian_mode, const void *x, void *hessian, void *b,
-                         void *sum_sq) {
-  if (!g || !x) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
-  for (auto *c : g->shards) {
-    MOPT_HIP_TRY(hipSetDevice(c->device));
-    const int rc = linearizeAsyncImpl(c, jacobian_mode, x, c->d_result, c->stream);
-    if (rc != MOPT_OK) return rc;
-  }
-  const int rc = groupReduceAndFetch(g, 0, kResultDoubles);
-  if (rc != MOPT_OK) return rc;
-  storeResult(g->shards[0], g->shards[0]->h_result, hessian, b, sum_sq);
-  return MOPT_OK;
-}
-
-int mopt_group_compute(mopt_group *g, const void *x, void *sum_sq) {
-  if (!g || !x || !sum_sq) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
-  for (auto *c : g->shards) {
-    MOPT_HIP_TRY(hipSetDevice(c->device));
-    const int rc = costAsyncImpl(c, x, c->d_result + 42, c->stream);
-    if (rc != MOPT_OK) return rc;
-  }
-  const int rc = groupReduceAndFetch(g, 42, 1);
-  if (rc != MOPT_OK) return rc;
-  storeResult(g->shards[0], g->shards[0]->h_result, nullptr, nullptr, sum_sq);
   return MOPT_OK;
 }
 

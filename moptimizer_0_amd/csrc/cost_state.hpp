@@ -1,0 +1,159 @@
+// State behind the opaque handles of include/moptimizer_hip.h and the helpers the translation
+// units of the C ABI share (c_abi.cpp: costs and sweeps; icp.cpp: correspondence search;
+// group.cpp: single-process device group).  Internal to libmoptimizer_hip.so.
+#pragma once
+
+#include "moptimizer_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdlib>
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "jit_model.hpp"
+#include "sweep.hpp"
+
+namespace mopt_detail {
+
+// records the message for mopt_last_error() (thread-local) and returns `code`
+int fail(int code, const std::string &msg);
+
+
+#define MOPT_HIP_TRY(expr)                                                                  \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(MOPT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+  } while (0)
+
+#define MOPT_NCCL_TRY(expr)                                                                 \
+  do {                                                                                      \
+    ncclResult_t r_ = (expr);                                                               \
+    if (r_ != ncclSuccess)                                                                  \
+      return fail(MOPT_ERR_RCCL, std::string(#expr) + ": " + ncclGetErrorString(r_));      \
+  } while (0)
+
+enum ModelKind { kModelPoint2Point = 1, kModelReprojection = 2, kModelScalar = 3, kModelJit = 4 };
+constexpr int kMaxParamBytes = mopt::kMaxParams * 8;
+constexpr int kResultSlots = 96;  // >= n*n + n + 1 for n <= 8 (73)
+
+inline int envInt(const char *name, int fallback) {
+  const char *v = std::getenv(name);
+  if (!v || !*v) return fallback;
+  const int parsed = std::atoi(v);
+  return parsed > 0 ? parsed : fallback;
+}
+
+}  // namespace mopt_detail
+
+// Uniform grid over the target cloud of an ICP cost (built once on the host, resident in HBM).
+struct IcpMatcher {
+  void *d_sorted = nullptr;      // [num_targets][4] scalars grouped by cell
+  int *d_cell_start = nullptr;   // [cells + 1]
+  unsigned int *d_matched = nullptr;
+  double origin[3] = {0, 0, 0};
+  double cell = 1.0;
+  int dims[3] = {1, 1, 1};
+  double max_dist = 0.0;
+  long long num_targets = 0;
+  // Sources are stored in grid-cell order (of their un-warped position) so that neighbouring
+  // lanes visit neighbouring cells; slot k of the tiles holds the caller's source order[k].
+  std::vector<long long> order;
+};
+
+struct mopt_cost {
+  int device = 0;
+  int scalar_bytes = 8;
+  int model = mopt_detail::kModelPoint2Point;
+  int scalar_model = 0;  // mopt::ScalarModelKind when model == kModelScalar
+  int n_params = mopt::kNumParams;
+  int n_out = 3;
+  long long data_stride = 0;  // scalar models: elements per data plane
+  long long count = 0;
+  int num_tiles = 0;
+  int num_cus = 0;
+  int max_grid = 0;
+
+  void *d_tiles = nullptr;
+  long long capacity_tiles = 0;  // tiles allocated in d_tiles
+  double *d_partials = nullptr;
+  double *d_result = nullptr;  // kResultDoubles
+  // Mapped, fine-grained host memory the finalize kernel publishes into: 43 results + flag word.
+  double *h_result = nullptr;
+  unsigned long long *h_flag = nullptr;
+  double *h_result_dev = nullptr;  // the same memory as the device addresses it
+  unsigned long long *h_flag_dev = nullptr;
+  unsigned long long sequence = 0;
+  hipStream_t stream = nullptr;
+  ncclComm_t comm = nullptr;  // multi-process shard group (one rank per GPU), optional
+  int comm_size = 1;
+
+  double cov[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // row-major, stride 3 (m <= 3), as double
+  double cov_m[16] = {1};                        // row-major m x m compact (scalar models, m <= 4)
+  int cov_mode = mopt::kCovIdentity;
+  int loss_kind = MOPT_LOSS_NONE;
+  double loss_param = 0.0;
+  int variant = MOPT_KERNEL_AUTO;
+
+  double camera[12];
+  double frame[16];
+
+  std::unique_ptr<IcpMatcher> matcher;  // point2point costs created by mopt_icp_create
+  mopt::JitKernel jit;                  // kModelJit: the run-time compiled sweep
+
+  // LM calls computeCost(xi) and, when the step is accepted, linearize(xi) right after
+  // (levenberg_marquadt_dyn.cpp:86,112 then :55): with speculation on, computeCost runs the
+  // linearization sweep (same HBM traffic as the cost sweep) and keeps its H | b | sum_sq, so the
+  // following linearize at the same x costs no sweep at all.
+  bool speculate = true;
+  int last_jac_mode = -1;
+  unsigned long long state_version = 0;  // bumped when loss / covariance / variant change
+  struct {
+    bool valid = false;
+    int mode = -1;
+    unsigned long long version = 0;
+    unsigned char x[mopt_detail::kMaxParamBytes] = {0};
+    double result[mopt_detail::kResultSlots] = {0};
+  } cache;
+  long long stat_sweeps = 0;
+  long long stat_cache_hits = 0;
+
+  int profiling = 0;  // 0 off, N > 0: bracket every N-th sweep launch with events
+  long long profiling_tick = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
+  std::vector<hipEvent_t> free_events;
+  double sweep_ms_total = 0.0;
+  long long sweep_launches = 0;
+};
+
+namespace mopt_detail {
+
+using mopt::kNumParams;
+using mopt::kResultDoubles;
+
+int commonCreate(mopt_cost *c, int device);  // device, stream, partial / result buffers
+void destroyCost(mopt_cost *c);
+// enqueue one linearization / cost sweep + its finalize on `s`; results to d_result (+ optional
+// hand-over to mapped host memory)
+int linearizeAsyncImpl(mopt_cost *c, int jac_mode, const void *x, double *d_result, hipStream_t s,
+                       const mopt::HostPublish &pub = mopt::HostPublish());
+int costAsyncImpl(mopt_cost *c, const void *x, double *d_sum, hipStream_t s,
+                  const mopt::HostPublish &pub = mopt::HostPublish());
+// H | b | sum_sq as doubles -> the caller's arrays in the cost's scalar type
+void storeResult(const mopt_cost *c, const double *res, void *hessian, void *b, void *sum_sq);
+
+struct DeviceScratch {  // hipFree on scope exit
+  void *p = nullptr;
+  ~DeviceScratch() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+  template <typename T>
+  T *as() const { return static_cast<T *>(p); }
+};
+
+}  // namespace mopt_detail

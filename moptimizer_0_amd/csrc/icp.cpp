@@ -1,0 +1,203 @@
+// Correspondence search entry points (mopt_icp_*): the step upstream of the sweep, i.e. what a
+// registration model's update(x) does before every linearization (model.h:24-26,
+// levenberg_marquadt_dyn.cpp:54).  Grid construction and search run on the GPU (icp_grid.hip,
+// icpMatchKernel in sweep_kernels.hip); this file is their host side.
+#include "cost_state.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+#include "moptimizer_amd/so3.hpp"
+
+using namespace mopt_detail;
+
+namespace {
+// Grid over the targets and cell-ordered copy of the sources, built on the device (icp_grid.hip);
+// the host only chooses the resolution.  On return `d_src_sorted` holds the n sources in cell
+// order (packed xyz) and matcher->order the original index of each.
+template <typename S>
+int buildIcpGrid(const S *src, long long n, const S *tgt, long long m, double max_distance,
+                 hipStream_t s, std::unique_ptr<IcpMatcher> &out_matcher,
+                 DeviceScratch &d_src_sorted) {
+  auto mt = std::make_unique<IcpMatcher>();
+  mt->max_dist = max_distance;
+  mt->num_targets = m;
+  DeviceScratch d_tgt, d_src, d_perm_t, d_perm_s;
+  MOPT_HIP_TRY(d_tgt.alloc(size_t(m) * 3 * sizeof(S)));
+  MOPT_HIP_TRY(d_src.alloc(size_t(n) * 3 * sizeof(S)));
+  if (m > 0)
+    MOPT_HIP_TRY(hipMemcpyAsync(d_tgt.p, tgt, size_t(m) * 3 * sizeof(S), hipMemcpyHostToDevice, s));
+  if (n > 0)
+    MOPT_HIP_TRY(hipMemcpyAsync(d_src.p, src, size_t(n) * 3 * sizeof(S), hipMemcpyHostToDevice, s));
+  double lo[3], hi[3];
+  MOPT_HIP_TRY(mopt::icpBoundingBox<S>(d_tgt.as<S>(), m, lo, hi, s));
+  // cell edge a hair above the search radius, so the 27 cells around a query hold every target
+  // within it; enlarged when the box would need more than ~4 M cells
+  double cell = max_distance * 1.001;
+  for (;;) {
+    double cells = 1.0;
+    for (int a = 0; a < 3; ++a) cells *= std::floor((hi[a] - lo[a]) / cell) + 1.0;
+    if (cells <= double(1 << 22)) break;
+    cell *= 1.26;
+  }
+  mt->cell = cell;
+  long long ncells = 1;
+  for (int a = 0; a < 3; ++a) {
+    mt->origin[a] = lo[a];
+    mt->dims[a] = int(std::floor((hi[a] - lo[a]) / cell)) + 1;
+    ncells *= mt->dims[a];
+  }
+  out_matcher = std::move(mt);  // from here on the caller frees the matcher's device arrays
+  IcpMatcher &g = *out_matcher;
+  MOPT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_cell_start), size_t(ncells + 1) * sizeof(int)));
+  MOPT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_matched), 64));
+  MOPT_HIP_TRY(d_perm_t.alloc(size_t(m) * sizeof(int)));
+  MOPT_HIP_TRY(mopt::icpSortByCell<S>(d_tgt.as<S>(), m, g.origin, g.cell, g.dims, d_perm_t.as<int>(),
+                                      g.d_cell_start, s));
+  if (m > 0) {
+    MOPT_HIP_TRY(hipMalloc(&g.d_sorted, size_t(m) * 4 * sizeof(S)));
+    MOPT_HIP_TRY(mopt::icpGatherPoints<S>(d_tgt.as<S>(), d_perm_t.as<int>(), m,
+                                          static_cast<S *>(g.d_sorted), true, s));
+  }
+  // the sources in the cell order of their un-warped position
+  MOPT_HIP_TRY(d_perm_s.alloc(size_t(n) * sizeof(int)));
+  MOPT_HIP_TRY(mopt::icpSortByCell<S>(d_src.as<S>(), n, g.origin, g.cell, g.dims, d_perm_s.as<int>(),
+                                      nullptr, s));
+  MOPT_HIP_TRY(d_src_sorted.alloc(size_t(n) * 3 * sizeof(S)));
+  MOPT_HIP_TRY(mopt::icpGatherPoints<S>(d_src.as<S>(), d_perm_s.as<int>(), n, d_src_sorted.as<S>(),
+                                        false, s));
+  std::vector<int> perm(static_cast<size_t>(n));
+  if (n > 0)
+    MOPT_HIP_TRY(hipMemcpyAsync(perm.data(), d_perm_s.p, size_t(n) * sizeof(int),
+                                hipMemcpyDeviceToHost, s));
+  MOPT_HIP_TRY(hipStreamSynchronize(s));
+  g.order.assign(perm.begin(), perm.end());
+  return MOPT_OK;
+}
+
+template <typename S>
+int icpUpdate(mopt_cost *c, const S *x, int64_t *num_matched) {
+  const IcpMatcher &mt = *c->matcher;
+  mopt::IcpMatchArgs<S> a;
+  a.tiles = static_cast<S *>(c->d_tiles);
+  a.count = c->count;
+  a.num_tiles = c->num_tiles;
+  a.sorted = static_cast<const S *>(mt.d_sorted);
+  a.cell_start = mt.d_cell_start;
+  for (int k = 0; k < 3; ++k) {
+    a.origin[k] = S(mt.origin[k]);
+    a.dims[k] = mt.dims[k];
+  }
+  a.inv_cell = S(1.0 / mt.cell);
+  a.max_dist2 = S(mt.max_dist * mt.max_dist);
+  const auto T = moptimizer::so3::rigidFrom6DOF<S>(x);
+  std::memcpy(a.T, T.m, sizeof T.m);
+  a.matched = num_matched ? mt.d_matched : nullptr;
+  if (num_matched) MOPT_HIP_TRY(hipMemsetAsync(mt.d_matched, 0, sizeof(unsigned int), c->stream));
+  MOPT_HIP_TRY(mopt::launchIcpMatch<S>(a, c->stream));
+  c->cache.valid = false;
+  c->state_version += 1;
+  if (num_matched) {
+    unsigned int n = 0;
+    MOPT_HIP_TRY(hipMemcpyAsync(&n, mt.d_matched, sizeof n, hipMemcpyDeviceToHost, c->stream));
+    MOPT_HIP_TRY(hipStreamSynchronize(c->stream));
+    *num_matched = int64_t(n);
+  }
+  return MOPT_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int mopt_icp_create(mopt_cost **out, int device, int scalar_bytes, const void *src_xyz,
+                    int64_t num_src, const void *tgt_xyz, int64_t num_tgt, double max_distance) {
+  if (!out) return fail(MOPT_ERR_INVALID_ARGUMENT, "out is NULL");
+  *out = nullptr;
+  if (num_src < 0 || num_tgt < 0 || (num_src > 0 && !src_xyz) || (num_tgt > 0 && !tgt_xyz) ||
+      num_tgt > std::numeric_limits<int>::max() || num_src > std::numeric_limits<int>::max())
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "bad clouds");
+  if (!(max_distance > 0.0)) return fail(MOPT_ERR_INVALID_ARGUMENT, "max_distance must be > 0");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(MOPT_ERR_NO_DEVICE, "no HIP device is visible to this process");
+  if (device < 0 || device >= ndev) return fail(MOPT_ERR_INVALID_ARGUMENT, "device index out of range");
+  MOPT_HIP_TRY(hipSetDevice(device));
+  std::unique_ptr<IcpMatcher> matcher;
+  auto freeMatcher = [&]() {
+    if (!matcher) return;
+    if (matcher->d_sorted) (void)hipFree(matcher->d_sorted);
+    if (matcher->d_cell_start) (void)hipFree(matcher->d_cell_start);
+    if (matcher->d_matched) (void)hipFree(matcher->d_matched);
+  };
+  hipStream_t build_stream = nullptr;
+  MOPT_HIP_TRY(hipStreamCreateWithFlags(&build_stream, hipStreamNonBlocking));
+  DeviceScratch d_src_sorted;
+  int rc = scalar_bytes == 8
+               ? buildIcpGrid<double>(static_cast<const double *>(src_xyz), num_src,
+                                      static_cast<const double *>(tgt_xyz), num_tgt, max_distance,
+                                      build_stream, matcher, d_src_sorted)
+               : buildIcpGrid<float>(static_cast<const float *>(src_xyz), num_src,
+                                     static_cast<const float *>(tgt_xyz), num_tgt, max_distance,
+                                     build_stream, matcher, d_src_sorted);
+  (void)hipStreamSynchronize(build_stream);
+  (void)hipStreamDestroy(build_stream);
+  // the sources go into the resident tiles in cell order; the target planes are filled by the
+  // first search
+  mopt_cost *raw = nullptr;
+  if (rc == MOPT_OK)
+    rc = mopt_point2point_create(&raw, device, scalar_bytes, d_src_sorted.p, d_src_sorted.p, num_src,
+                                 MOPT_INPUT_DEVICE);
+  if (rc != MOPT_OK) {
+    freeMatcher();
+    return rc;
+  }
+  std::unique_ptr<mopt_cost, void (*)(mopt_cost *)> c(raw, destroyCost);
+  c->matcher = std::move(matcher);
+  const double zero8[6] = {0, 0, 0, 0, 0, 0};
+  const float zero4[6] = {0, 0, 0, 0, 0, 0};
+  rc = mopt_icp_update(c.get(), scalar_bytes == 8 ? static_cast<const void *>(zero8)
+                                                   : static_cast<const void *>(zero4), nullptr);
+  if (rc != MOPT_OK) return rc;
+  *out = c.release();
+  return MOPT_OK;
+}
+
+int mopt_icp_update(mopt_cost *c, const void *x, int64_t *num_matched) {
+  if (!c || !x) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (!c->matcher) return fail(MOPT_ERR_INVALID_ARGUMENT, "not a cost made by mopt_icp_create");
+  MOPT_HIP_TRY(hipSetDevice(c->device));
+  return c->scalar_bytes == 8 ? icpUpdate<double>(c, static_cast<const double *>(x), num_matched)
+                              : icpUpdate<float>(c, static_cast<const float *>(x), num_matched);
+}
+
+int mopt_icp_get_matches(mopt_cost *c, void *tgt_out_xyz) {
+  if (!c || !tgt_out_xyz) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (c->model != kModelPoint2Point) return fail(MOPT_ERR_INVALID_ARGUMENT, "not a point2point cost");
+  MOPT_HIP_TRY(hipSetDevice(c->device));
+  if (c->count == 0) return MOPT_OK;
+  const size_t bytes = size_t(c->count) * 3 * c->scalar_bytes;
+  void *d_tmp = nullptr;
+  MOPT_HIP_TRY(hipMalloc(&d_tmp, bytes));
+  hipError_t e = c->scalar_bytes == 8
+                     ? mopt::launchGatherTargets<double>(static_cast<const double *>(c->d_tiles),
+                                                         c->count, static_cast<double *>(d_tmp), c->stream)
+                     : mopt::launchGatherTargets<float>(static_cast<const float *>(c->d_tiles),
+                                                        c->count, static_cast<float *>(d_tmp), c->stream);
+  const bool permuted = c->matcher && !c->matcher->order.empty();
+  std::vector<unsigned char> staged(permuted ? bytes : 0);
+  void *host_dst = permuted ? static_cast<void *>(staged.data()) : tgt_out_xyz;
+  if (e == hipSuccess) e = hipMemcpyAsync(host_dst, d_tmp, bytes, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d_tmp);
+  if (e != hipSuccess) return fail(MOPT_ERR_HIP, std::string("gather: ") + hipGetErrorString(e));
+  if (permuted) {  // slot k holds the caller's source order[k]
+    const size_t triple = size_t(3) * c->scalar_bytes;
+    for (long long k = 0; k < c->count; ++k)
+      std::memcpy(static_cast<unsigned char *>(tgt_out_xyz) + size_t(c->matcher->order[size_t(k)]) * triple,
+                  staged.data() + size_t(k) * triple, triple);
+  }
+  return MOPT_OK;
+}
+
+}  // extern "C"
