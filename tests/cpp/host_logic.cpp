@@ -1,0 +1,314 @@
+// Host-side logic of the drop-in, without a GPU and without the HIP library: the LM caller's
+// status / error behaviour (levenberg_marquadt_dyn.cpp:34-119, optimizer.h:26-54), the pivoted
+// LDL^T it solves with, the dense matrix subset, SO(3) exp / log, loss weights, the logger and
+// the exception type.  Costs here are tiny closed-form CostFunctionBase subclasses written for
+// the test; nothing from oracle/ or the device path is involved.
+#include <cmath>
+#include <cstdio>
+#include <limits>
+#include <memory>
+#include <random>
+#include <sstream>
+#include <stdexcept>
+
+#include "moptimizer_amd/levenberg_marquadt.hpp"
+#include "moptimizer_amd/so3.hpp"
+
+using moptimizer::LevenbergMarquadtDynamic;
+using moptimizer::OptimizationStatus;
+namespace dense = moptimizer::dense;
+
+static int g_fail = 0, g_checks = 0;
+static void expectTrue(const char *what, bool ok) {
+  ++g_checks;
+  if (!ok) ++g_fail;
+  std::printf("%s %s\n", ok ? "PASS" : "FAIL", what);
+}
+static void expectNear(const char *what, double got, double want, double tol) {
+  ++g_checks;
+  const bool ok = std::fabs(got - want) <= tol && !std::isnan(got);
+  if (!ok) ++g_fail;
+  std::printf("%s %-58s got % .12g want % .12g tol %.1e\n", ok ? "PASS" : "FAIL", what, got, want, tol);
+}
+
+// r_i = a_i . x - y_i  (linear least squares): LM must land on the normal-equation solution.
+class LinearCost : public moptimizer::CostFunctionBase<double> {
+ public:
+  LinearCost(int n, int rows, unsigned seed) : CostFunctionBase<double>(nullptr, rows), n_(n) {
+    std::mt19937 gen(seed);
+    std::normal_distribution<double> dist(0.0, 1.0);
+    a_.resize(rows, n);
+    y_.resize(rows, 1);
+    truth_.resize(n, 1);
+    for (int j = 0; j < n; ++j) truth_[j] = 0.5 + j;
+    for (int i = 0; i < rows; ++i) {
+      double v = 0;
+      for (int j = 0; j < n; ++j) {
+        a_(i, j) = dist(gen);
+        v += a_(i, j) * truth_[j];
+      }
+      y_[i] = v;
+    }
+  }
+  double computeCost(const double *x) override {
+    double s = 0;
+    for (int i = 0; i < a_.rows(); ++i) s += residual(x, i) * residual(x, i);
+    return s;
+  }
+  double linearize(const double *x, double *H, double *b) override {
+    for (int k = 0; k < n_ * n_; ++k) H[k] = 0;
+    for (int k = 0; k < n_; ++k) b[k] = 0;
+    double s = 0;
+    for (int i = 0; i < a_.rows(); ++i) {
+      const double r = residual(x, i);
+      for (int c = 0; c < n_; ++c) {
+        for (int rr = 0; rr < n_; ++rr) H[c * n_ + rr] += a_(i, rr) * a_(i, c);
+        b[c] += a_(i, c) * r;
+      }
+      s += r * r;
+    }
+    return s;
+  }
+  const dense::Matrix<double> &truth() const { return truth_; }
+
+ private:
+  double residual(const double *x, int i) const {
+    double v = -y_[i];
+    for (int j = 0; j < n_; ++j) v += a_(i, j) * x[j];
+    return v;
+  }
+  int n_;
+  dense::Matrix<double> a_, y_, truth_;
+};
+
+// cost whose trial evaluation is NaN: the optimizer must stop with NUMERIC_ERROR (:88-91)
+class NanTrialCost : public moptimizer::CostFunctionBase<double> {
+ public:
+  NanTrialCost() : CostFunctionBase<double>(nullptr, 1) {}
+  double computeCost(const double *) override { return std::numeric_limits<double>::quiet_NaN(); }
+  double linearize(const double *, double *H, double *b) override {
+    H[0] = 1.0;
+    b[0] = 1.0;
+    return 1.0;
+  }
+};
+
+// cost that never decreases: every trial is rejected (rho < 0)
+class StubbornCost : public moptimizer::CostFunctionBase<double> {
+ public:
+  explicit StubbornCost(double gradient) : CostFunctionBase<double>(nullptr, 1), g_(gradient) {}
+  double computeCost(const double *) override { return 2.0; }
+  double linearize(const double *, double *H, double *b) override {
+    H[0] = 1.0;
+    b[0] = g_;
+    return 1.0;
+  }
+  int linearizations = 0;
+
+ private:
+  double g_;
+};
+
+static void optimizerStatuses() {
+  {
+    LevenbergMarquadtDynamic<double> lm(3);
+    bool threw = false;
+    double x[3] = {0, 0, 0};
+    try {
+      lm.minimize(x);
+    } catch (const std::runtime_error &) {
+      threw = true;
+    }
+    expectTrue("minimize without costs throws std::runtime_error (optimizer.h:48-54)", threw);
+    threw = false;
+    try {
+      lm.setMaximumIterations(-1);
+    } catch (const std::invalid_argument &) {
+      threw = true;
+    }
+    expectTrue("setMaximumIterations(-1) throws std::invalid_argument (optimizer.h:33-37)", threw);
+    expectTrue("default maximum iterations is 15", lm.getMaximumIterations() == 15);
+    expectTrue("default inner LM iterations is 3", lm.getLevenbergMarquadtIterations() == 3);
+  }
+  {
+    LinearCost cost(4, 40, 7);
+    LevenbergMarquadtDynamic<double> lm(4);
+    lm.addCost(&cost);
+    double x[4] = {0, 0, 0, 0};
+    const OptimizationStatus st = lm.minimize(x);
+    expectTrue("linear least squares: CONVERGED (cost below 8 eps)", st == OptimizationStatus::CONVERGED);
+    for (int j = 0; j < 4; ++j) expectNear("linear least squares x[j]", x[j], cost.truth()[j], 1e-9);
+    expectTrue("linear least squares: a handful of iterations", lm.getExecutedIterations() <= 5);
+  }
+  {
+    // two costs are summed (multi-objective, levenberg_marquadt_dyn.cpp:48-60)
+    LinearCost a(3, 20, 1), b(3, 25, 2);
+    LevenbergMarquadtDynamic<double> lm(3);
+    lm.addCost(&a);
+    lm.addCost(&b);
+    double x[3] = {5, -5, 5};
+    lm.minimize(x);
+    for (int j = 0; j < 3; ++j) expectNear("two summed costs x[j]", x[j], a.truth()[j], 1e-9);
+    lm.clearCosts();
+    bool threw = false;
+    try {
+      lm.minimize(x);
+    } catch (const std::runtime_error &) {
+      threw = true;
+    }
+    expectTrue("clearCosts() empties the optimizer", threw);
+  }
+  {
+    NanTrialCost cost;
+    LevenbergMarquadtDynamic<double> lm(1);
+    std::ostringstream sink;
+    lm.setLogger(std::make_shared<duna::Logger>(sink, duna::Logger::L_ERROR, "test"));
+    lm.addCost(&cost);
+    double x[1] = {1.0};
+    expectTrue("NaN trial cost -> NUMERIC_ERROR", lm.minimize(x) == OptimizationStatus::NUMERIC_ERROR);
+    expectTrue("x is left untouched by a rejected NaN trial", x[0] == 1.0);
+    expectTrue("the error is logged at L_ERROR", sink.str().find("Numeric Error") != std::string::npos);
+  }
+  {
+    StubbornCost cost(1.0);
+    LevenbergMarquadtDynamic<double> lm(1);
+    lm.setMaximumIterations(4);
+    lm.addCost(&cost);
+    double x[1] = {3.0};
+    expectTrue("always-rejected steps -> MAXIMUM_ITERATIONS_REACHED",
+               lm.minimize(x) == OptimizationStatus::MAXIMUM_ITERATIONS_REACHED);
+    expectTrue("rejected steps never move x", x[0] == 3.0);
+    expectTrue("executed iterations == maximum", lm.getExecutedIterations() == 4);
+  }
+  {
+    StubbornCost cost(1e-12);  // delta = -b / H(1 + lambda) is below sqrt(eps): SMALL_DELTA (delta.h:11-16)
+    LevenbergMarquadtDynamic<double> lm(1);
+    lm.addCost(&cost);
+    double x[1] = {3.0};
+    expectTrue("rejected step with |delta| < sqrt(eps) -> SMALL_DELTA",
+               lm.minimize(x) == OptimizationStatus::SMALL_DELTA);
+  }
+}
+
+static void ldlt() {
+  std::mt19937 gen(11);
+  std::normal_distribution<double> dist(0.0, 1.0);
+  for (int n : {1, 2, 6, 8}) {
+    // SPD: A = B^T B + I
+    dense::Matrix<double> B(n + 3, n), A(n, n), x(n, 1), rhs(n, 1);
+    for (int i = 0; i < n + 3; ++i)
+      for (int j = 0; j < n; ++j) B(i, j) = dist(gen);
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < n; ++j) {
+        double v = i == j ? 1.0 : 0.0;
+        for (int k = 0; k < n + 3; ++k) v += B(k, i) * B(k, j);
+        A(i, j) = v;
+      }
+    for (int i = 0; i < n; ++i) x[i] = dist(gen);
+    for (int i = 0; i < n; ++i) {
+      double v = 0;
+      for (int j = 0; j < n; ++j) v += A(i, j) * x[j];
+      rhs[i] = v;
+    }
+    const auto got = dense::PivotedLDLT<double>(A).solve(rhs);
+    double err = 0;
+    for (int i = 0; i < n; ++i) err = std::max(err, std::fabs(got[i] - x[i]));
+    char label[64];
+    std::snprintf(label, sizeof label, "PivotedLDLT SPD n=%d max error", n);
+    expectNear(label, err, 0.0, 1e-10);
+  }
+  {
+    // indefinite but non-singular, needs the diagonal pivoting
+    dense::Matrix<double> A(3, 3), rhs(3, 1);
+    const double a[3][3] = {{1e-12, 2, 0}, {2, -3, 1}, {0, 1, 5}};
+    const double want[3] = {1.0, -2.0, 0.5};
+    for (int i = 0; i < 3; ++i) {
+      rhs[i] = 0;
+      for (int j = 0; j < 3; ++j) {
+        A(i, j) = a[i][j];
+        rhs[i] += a[i][j] * want[j];
+      }
+    }
+    const auto got = dense::PivotedLDLT<double>(A).solve(rhs);
+    for (int i = 0; i < 3; ++i) expectNear("PivotedLDLT indefinite x[i]", got[i], want[i], 1e-9);
+  }
+  {
+    // rank-deficient (a zero row / column, as the as-written point2point Jacobian produces,
+    // SURVEY 8a-9): the step is finite and zero along the null direction
+    dense::Matrix<double> A(3, 3), rhs(3, 1);
+    A.setZero();
+    A(0, 0) = 4;
+    A(2, 2) = 2;
+    rhs[0] = 8;
+    rhs[1] = 0;
+    rhs[2] = -2;
+    const auto got = dense::PivotedLDLT<double>(A).solve(rhs);
+    expectNear("PivotedLDLT singular x[0]", got[0], 2.0, 1e-14);
+    expectNear("PivotedLDLT singular x[1] (null direction)", got[1], 0.0, 0.0);
+    expectNear("PivotedLDLT singular x[2]", got[2], -1.0, 1e-14);
+  }
+}
+
+static void denseAndSo3() {
+  dense::Matrix<double> m(2, 3);
+  m.setConstant(2.0);
+  m(1, 2) = 7.0;
+  expectTrue("Matrix is column-major (data()[c * rows + r])", m.data()[2 * 2 + 1] == 7.0 && m(5) == 7.0);
+  m *= 0.5;
+  expectNear("Matrix *= scalar", m(1, 2), 3.5, 0);
+  m.setIdentity();
+  expectTrue("setIdentity on a 2x3", m(0, 0) == 1 && m(1, 1) == 1 && m(0, 1) == 0 && m(1, 2) == 0);
+  moptimizer::covariance::Matrix<float> cov;
+  cov.resize(3, 3);
+  cov.setIdentity();
+  cov *= 0.25f;
+  expectNear("covariance::Matrix scaling", cov(2, 2), 0.25, 0);
+
+  // exp / log round trip and the small-angle branch (so3.cpp:43-57: identity below 10 eps)
+  const double w[3] = {0.3, -0.2, 0.5};
+  double R[9], back[3];
+  moptimizer::so3::expSO3(w, R);
+  moptimizer::so3::logSO3(R, back);
+  for (int a = 0; a < 3; ++a) expectNear("log(exp(w)) == w", back[a], w[a], 1e-14);
+  double det = R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) +
+               R[2] * (R[3] * R[7] - R[4] * R[6]);
+  expectNear("det exp(w) == 1", det, 1.0, 1e-14);
+  const double tiny[3] = {1e-17, 0, 0};
+  moptimizer::so3::expSO3(tiny, R);
+  expectTrue("exp of a rotation below 10 eps is exactly I", R[0] == 1 && R[4] == 1 && R[8] == 1 && R[1] == 0 && R[5] == 0);
+  double x[6] = {1, 2, 3, 0, 0, M_PI / 2}, T[16];
+  moptimizer::so3::convert6DOFParameterToMatrix(x, T);  // column-major 4x4
+  expectNear("convert6DOFParameterToMatrix translation", T[12] + T[13] + T[14], 6.0, 0);
+  expectNear("convert6DOFParameterToMatrix Rz(90): R(1,0)", T[1], 1.0, 1e-15);
+  expectNear("convert6DOFParameterToMatrix Rz(90): R(0,1)", T[4], -1.0, 1e-15);
+  expectNear("convert6DOFParameterToMatrix bottom row", T[3] + T[7] + T[11] + T[15], 1.0, 0);
+
+  moptimizer::loss::GemmanMCClure<double> gm(100.0);
+  expectNear("GemmanMCClure weight t^2/(s+t)^2", gm.weight(25.0), 100.0 * 100.0 / (125.0 * 125.0), 1e-16);
+  moptimizer::loss::NoLoss<double> none;
+  expectNear("NoLoss weight", none.weight(1e9), 1.0, 0);
+
+  std::ostringstream sink;
+  duna::Logger log(sink, duna::Logger::L_WARN, "unit");
+  log.log(duna::Logger::L_DEBUG, "hidden");
+  log.log(duna::Logger::L_ERROR, "shown ", 42);
+  expectTrue("Logger filters by level and prefixes the line",
+             sink.str() == "[ERROR] duna::unit::shown 42\n");
+  log.setLogLevel(duna::Logger::L_DEBUG);
+  log.log(duna::Logger::L_DEBUG, "now");
+  expectTrue("Logger::setLogLevel", sink.str().find("[DEBUG] duna::unit::now") != std::string::npos);
+
+  try {
+    throw moptimizer::Exception("boom");
+  } catch (const std::exception &e) {
+    expectTrue("moptimizer::Exception is a std::exception carrying its text", std::string(e.what()) == "boom");
+  }
+}
+
+int main() {
+  optimizerStatuses();
+  ldlt();
+  denseAndSo3();
+  std::printf("SUMMARY %d checks, failures=%d\n", g_checks, g_fail);
+  return g_fail == 0 ? 0 : 1;
+}
