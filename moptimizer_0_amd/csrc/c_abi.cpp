@@ -656,6 +656,9 @@ int mopt_point2point_set_data(mopt_cost *c, const void *src_xyz, const void *tgt
                               int64_t count, unsigned flags) {
   if (!c || c->model != kModelPoint2Point)
     return fail(MOPT_ERR_INVALID_ARGUMENT, "not a point2point cost");
+  if (c->matcher)
+    return fail(MOPT_ERR_UNSUPPORTED,
+                "a cost made by mopt_icp_create owns its correspondences (mopt_icp_update)");
   if (count < 0 || (count > 0 && (!src_xyz || !tgt_xyz)))
     return fail(MOPT_ERR_INVALID_ARGUMENT, "bad point arrays / count");
   MOPT_HIP_TRY(hipSetDevice(c->device));

@@ -663,6 +663,14 @@ def test_icp_matcher_equals_brute_force(hip_lib, dtype):
                 both = ~miss_g & ~miss_w
                 assert (np.abs(got[both] - want[both]).max(1) > 0).mean() < 2e-3
             assert n == int((~miss_g).sum())
+    with pytest.raises(hip_lib.MoptError):   # the search owns the correspondences of such a cost
+        cost.set_data(src, src)
+    # degenerate clouds: no targets at all, and a single target far away -> nothing matched
+    empty = hip_lib.IcpCost(src, np.zeros((0, 3), dtype=dtype), 0.5, dtype=dtype)
+    assert empty.update(np.zeros(6, dtype=dtype)) == 0
+    assert not empty.linearize(np.zeros(6, dtype=dtype), 0)[0].any()
+    far = hip_lib.IcpCost(src, np.full((1, 3), 1e3, dtype=dtype), 0.5, dtype=dtype)
+    assert far.update(np.zeros(6, dtype=dtype)) == 0 and np.isnan(far.matches()).all()
 
 
 def test_icp_solve_with_gpu_correspondence_search(hip_lib, oracle):
