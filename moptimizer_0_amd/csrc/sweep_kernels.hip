@@ -569,36 +569,52 @@ __global__ __launch_bounds__(kBlockThreads) void icpMatchKernel(const IcpMatchAr
     if (inside) {
       const int c[3] = {int(g[0]), int(g[1]), int(g[2])};
       S best_d = A.max_dist2;
-      for (int dz = -1; dz <= 1; ++dz) {
-        const int z = c[2] + dz;
-        if (z < 0 || z >= A.dims[2]) continue;
-        for (int dy = -1; dy <= 1; ++dy) {
-          const int y = c[1] + dy;
-          if (y < 0 || y >= A.dims[1]) continue;
-          // the three x-neighbours are consecutive cells: one contiguous candidate range
-          const int x0 = c[0] - 1 < 0 ? 0 : c[0] - 1;
-          const int x1 = c[0] + 1 >= A.dims[0] ? A.dims[0] - 1 : c[0] + 1;
-          if (x0 > x1) continue;
-          const long long row = ((long long)z * A.dims[1] + y) * A.dims[0];
-          const int begin = A.cell_start[row + x0], end = A.cell_start[row + x1 + 1];
-          for (int k = begin; k < end; ++k) {
-            const Pack<S> *cand = reinterpret_cast<const Pack<S> *>(A.sorted + size_t(k) * 4);
-            S q[4];
-            if (sizeof(S) == 8) {
-              const Pack<S> lo = cand[0], hi = cand[1];
-              q[0] = lo.v[0]; q[1] = lo.v[1]; q[2] = hi.v[0];
-            } else {
-              const Pack<S> all = cand[0];
-              q[0] = all.v[0]; q[1] = all.v[1]; q[2] = all.v[2];
-            }
-            const S d0 = w[0] - q[0], d1 = w[1] - q[1], d2 = w[2] - q[2];
-            const S dist = d0 * d0 + d1 * d1 + d2 * d2;
-            if (dist <= A.max_dist2 && (!found || dist < best_d)) {
-              found = true;
-              best_d = dist;
-              best[0] = q[0]; best[1] = q[1]; best[2] = q[2];
-            }
-          }
+      // The three x-neighbours of a (y, z) row are consecutive cells: one contiguous candidate
+      // range per row.  All 18 range bounds are fetched first (independent loads, one memory
+      // round trip instead of nine dependent ones); rows outside the grid get an empty range.
+      const int x0 = c[0] - 1 < 0 ? 0 : c[0] - 1;
+      const int x1 = c[0] + 1 >= A.dims[0] ? A.dims[0] - 1 : c[0] + 1;
+      int begin[9], end[9];
+#pragma unroll
+      for (int r = 0; r < 9; ++r) {
+        const int z = c[2] + r / 3 - 1, y = c[1] + r % 3 - 1;
+        const bool ok = z >= 0 && z < A.dims[2] && y >= 0 && y < A.dims[1] && x0 <= x1;
+        const long long row = ok ? ((long long)z * A.dims[1] + y) * A.dims[0] : 0;
+        const int lo = A.cell_start[row + (ok ? x0 : 0)];
+        const int hi = A.cell_start[row + (ok ? x1 + 1 : 0)];
+        begin[r] = lo;
+        end[r] = ok ? hi : lo;
+      }
+      auto consider = [&](const S (&q)[3]) {
+        const S d0 = w[0] - q[0], d1 = w[1] - q[1], d2 = w[2] - q[2];
+        const S dist = d0 * d0 + d1 * d1 + d2 * d2;
+        if (dist <= A.max_dist2 && (!found || dist < best_d)) {
+          found = true;
+          best_d = dist;
+          best[0] = q[0]; best[1] = q[1]; best[2] = q[2];
+        }
+      };
+      auto fetch = [&](int k, S (&q)[3]) {
+        const Pack<S> *cand = reinterpret_cast<const Pack<S> *>(A.sorted + size_t(k) * 4);
+        if (sizeof(S) == 8) {
+          const Pack<S> lo = cand[0], hi = cand[1];
+          q[0] = lo.v[0]; q[1] = lo.v[1]; q[2] = hi.v[0];
+        } else {
+          const Pack<S> all = cand[0];
+          q[0] = all.v[0]; q[1] = all.v[1]; q[2] = all.v[2];
+        }
+      };
+#pragma unroll
+      for (int r = 0; r < 9; ++r) {
+        // two candidates per step, both loads issued before either is used; order of
+        // consideration (and so the tie-break) is the stored order
+        for (int k = begin[r]; k < end[r]; k += 2) {
+          S qa[3], qb[3];
+          const bool pair = k + 1 < end[r];
+          fetch(k, qa);
+          fetch(pair ? k + 1 : k, qb);
+          consider(qa);
+          if (pair) consider(qb);
         }
       }
     }
@@ -607,7 +623,11 @@ __global__ __launch_bounds__(kBlockThreads) void icpMatchKernel(const IcpMatchAr
   slot[3 * TP] = found ? best[0] : nan;
   slot[4 * TP] = found ? best[1] : nan;
   slot[5 * TP] = found ? best[2] : nan;
-  if (found && A.matched) atomicAdd(A.matched, 1u);
+  // one counter update per workgroup (the grid covers whole tiles, so no thread has left early)
+  if (A.matched) {
+    const int in_block = __syncthreads_count(found ? 1 : 0);
+    if (threadIdx.x == 0 && in_block > 0) atomicAdd(A.matched, (unsigned int)in_block);
+  }
 }
 
 template <typename S>
