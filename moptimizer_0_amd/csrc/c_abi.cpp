@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <map>
+#include <mutex>
 #include <new>
 
 #include "moptimizer_amd/so3.hpp"
@@ -506,6 +508,30 @@ int blockingSweep(mopt_cost *c, bool cost_only, int jac_mode, const void *x) {
 }  // namespace
 
 namespace mopt_detail {
+namespace {
+std::mutex g_stream_pool_mutex;
+std::map<int, std::vector<hipStream_t>> g_stream_pool;
+}  // namespace
+
+hipError_t acquireStream(int device, hipStream_t *out) {
+  {
+    std::lock_guard<std::mutex> lock(g_stream_pool_mutex);
+    auto &pool = g_stream_pool[device];
+    if (!pool.empty()) {
+      *out = pool.back();
+      pool.pop_back();
+      return hipSuccess;
+    }
+  }
+  return hipStreamCreateWithFlags(out, hipStreamNonBlocking);  // current device == `device`
+}
+
+void releaseStream(int device, hipStream_t stream) {
+  if (!stream) return;
+  std::lock_guard<std::mutex> lock(g_stream_pool_mutex);
+  g_stream_pool[device].push_back(stream);
+}
+
 void storeResult(const mopt_cost *c, const double *res, void *hessian, void *b, void *sum_sq) {
   const int n = c->n_params, nn = n * n;
   if (c->scalar_bytes == 8) {
@@ -533,10 +559,10 @@ int commonCreate(mopt_cost *c, int device) {
   MOPT_HIP_TRY(hipGetDeviceProperties(&prop, device));
   c->num_cus = prop.multiProcessorCount;
   c->max_grid = c->num_cus * 16;
-  MOPT_HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  MOPT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_partials),
+  MOPT_HIP_TRY(acquireStream(device, &c->stream));
+  MOPT_HIP_TRY(deviceAlloc(reinterpret_cast<void **>(&c->d_partials),
                          size_t(c->max_grid) * kResultSlots * sizeof(double)));
-  MOPT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_result), kResultSlots * sizeof(double)));
+  MOPT_HIP_TRY(deviceAlloc(reinterpret_cast<void **>(&c->d_result), kResultSlots * sizeof(double)));
   // results (43) + padding + flag word in one mapped, coherent host allocation
   MOPT_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_result),
                              (kResultSlots + 16) * sizeof(double),
@@ -559,31 +585,35 @@ void destroyCost(mopt_cost *c) {
   for (auto e : c->free_events) (void)hipEventDestroy(e);
   if (c->comm) ncclCommDestroy(c->comm);
   if (c->matcher) {
-    if (c->matcher->d_sorted) (void)hipFree(c->matcher->d_sorted);
-    if (c->matcher->d_cell_start) (void)hipFree(c->matcher->d_cell_start);
-    if (c->matcher->d_matched) (void)hipFree(c->matcher->d_matched);
+    deviceRelease(c->matcher->d_sorted);
+    deviceRelease(c->matcher->d_cell_start);
+    deviceRelease(c->matcher->d_matched);
   }
   mopt::jitRelease(c->jit);
-  if (c->d_tiles) (void)hipFree(c->d_tiles);
-  if (c->d_partials) (void)hipFree(c->d_partials);
-  if (c->d_result) (void)hipFree(c->d_result);
+  deviceRelease(c->d_tiles);
+  deviceRelease(c->d_partials);
+  deviceRelease(c->d_result);
   if (c->h_result) (void)hipHostFree(c->h_result);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  releaseStream(c->device, c->stream);  // synchronised at the top of this function
   delete c;
 }
 
 }  // namespace mopt_detail
 
 namespace {
+constexpr size_t kBounceBytes = size_t(8) << 20;
+std::mutex g_bounce_mutex;
+void *g_bounce = nullptr;  // pinned, allocated on first use, kept for the life of the process
+
 // Copies (or adopts) two input arrays into device staging memory and returns device pointers.
 struct Staging {
   void *a = nullptr, *b = nullptr;
-  bool owned = false;
+  void *block = nullptr;  // one allocation behind both copies
+  hipStream_t stream = nullptr;
   ~Staging() {
-    if (owned) {
-      if (a) (void)hipFree(a);
-      if (b) (void)hipFree(b);
-    }
+    if (!block) return;
+    (void)hipStreamSynchronize(stream);  // an early error return may leave a copy in flight
+    deviceRelease(block);
   }
 };
 
@@ -592,18 +622,29 @@ int stageInputs(const void *ha, size_t bytes_a, const void *hb, size_t bytes_b, 
   if (flags & MOPT_INPUT_DEVICE) {
     st.a = const_cast<void *>(ha);
     st.b = const_cast<void *>(hb);
-    st.owned = false;
     return MOPT_OK;
   }
-  st.owned = true;
-  if (bytes_a) {
-    MOPT_HIP_TRY(hipMalloc(&st.a, bytes_a));
-    MOPT_HIP_TRY(hipMemcpyAsync(st.a, ha, bytes_a, hipMemcpyHostToDevice, s));
+  const size_t offset_b = (bytes_a + 255) & ~size_t(255);
+  if (bytes_a + bytes_b == 0) return MOPT_OK;
+  st.stream = s;
+  MOPT_HIP_TRY(deviceAlloc(&st.block, offset_b + bytes_b));
+  st.a = st.block;
+  st.b = static_cast<char *>(st.block) + offset_b;
+  // Small inputs go through a pinned bounce buffer owned by the library: a copy straight from
+  // pageable memory makes the runtime pin the caller's pages first, which costs 4-8 ms for an
+  // address range it has not seen before, whatever its size (measured: a 30 k-point cost took
+  // 8 ms to construct, 1.4 MB of input).  Large inputs amortise that and skip the extra host copy.
+  if (offset_b + bytes_b <= kBounceBytes) {
+    std::lock_guard<std::mutex> lock(g_bounce_mutex);
+    if (!g_bounce) MOPT_HIP_TRY(hipHostMalloc(&g_bounce, kBounceBytes, hipHostMallocPortable));
+    if (bytes_a) std::memcpy(g_bounce, ha, bytes_a);
+    if (bytes_b) std::memcpy(static_cast<char *>(g_bounce) + offset_b, hb, bytes_b);
+    MOPT_HIP_TRY(hipMemcpyAsync(st.block, g_bounce, offset_b + bytes_b, hipMemcpyHostToDevice, s));
+    MOPT_HIP_TRY(hipStreamSynchronize(s));  // the bounce buffer is free again
+    return MOPT_OK;
   }
-  if (bytes_b) {
-    MOPT_HIP_TRY(hipMalloc(&st.b, bytes_b));
-    MOPT_HIP_TRY(hipMemcpyAsync(st.b, hb, bytes_b, hipMemcpyHostToDevice, s));
-  }
+  if (bytes_a) MOPT_HIP_TRY(hipMemcpyAsync(st.a, ha, bytes_a, hipMemcpyHostToDevice, s));
+  if (bytes_b) MOPT_HIP_TRY(hipMemcpyAsync(st.b, hb, bytes_b, hipMemcpyHostToDevice, s));
   return MOPT_OK;
 }
 
@@ -670,10 +711,10 @@ int mopt_point2point_set_data(mopt_cost *c, const void *src_xyz, const void *tgt
   const size_t tile_bytes = size_t(tile_points) * 6 * c->scalar_bytes;
   MOPT_HIP_TRY(hipStreamSynchronize(c->stream));
   if (tiles > c->capacity_tiles) {
-    if (c->d_tiles) MOPT_HIP_TRY(hipFree(c->d_tiles));
+    deviceRelease(c->d_tiles);  // the stream was synchronised above
     c->d_tiles = nullptr;
     c->capacity_tiles = 0;
-    MOPT_HIP_TRY(hipMalloc(&c->d_tiles, tile_bytes * size_t(tiles)));
+    MOPT_HIP_TRY(deviceAlloc(&c->d_tiles, tile_bytes * size_t(tiles)));
     c->capacity_tiles = tiles;
   }
   c->count = count;
@@ -721,7 +762,7 @@ int mopt_reprojection_create(mopt_cost **out, int device, const double *points_x
   c->num_tiles = int(tiles);
   int rc = commonCreate(c.get(), device);
   if (rc != MOPT_OK) return rc;
-  MOPT_HIP_TRY(hipMalloc(&c->d_tiles, size_t(mopt::kReprojTileBytes) * c->num_tiles));
+  MOPT_HIP_TRY(deviceAlloc(&c->d_tiles, size_t(mopt::kReprojTileBytes) * c->num_tiles));
   Staging st;
   rc = stageInputs(points_xyzw, size_t(count) * 32, pixels_uv, size_t(count) * 8, flags, c->stream,
                    st);
@@ -771,7 +812,7 @@ int mopt_scalar_model_create(mopt_cost **out, int device, int scalar_bytes, int 
       for (int64_t i = 0; i < count; ++i)
         std::memcpy(&staged[(size_t(p) * count + size_t(i)) * scalar_bytes],
                     src[p] + size_t(i) * size_t(stride_scalars) * scalar_bytes, scalar_bytes);
-    MOPT_HIP_TRY(hipMalloc(&c->d_tiles, staged.size()));
+    MOPT_HIP_TRY(deviceAlloc(&c->d_tiles, staged.size()));
     MOPT_HIP_TRY(hipMemcpy(c->d_tiles, staged.data(), staged.size(), hipMemcpyHostToDevice));
   }
   mopt_cost_set_covariance(c.get(), nullptr);
@@ -806,7 +847,7 @@ int mopt_jit_model_create(mopt_cost **out, int device, int scalar_bytes, int n_p
     return fail(MOPT_ERR_INVALID_ARGUMENT, mopt::jitLastError());
   if (n_planes > 0) {
     const size_t row = size_t(count) * scalar_bytes;
-    MOPT_HIP_TRY(hipMalloc(&c->d_tiles, row * n_planes));
+    MOPT_HIP_TRY(deviceAlloc(&c->d_tiles, row * n_planes));
     MOPT_HIP_TRY(hipMemcpy2D(c->d_tiles, row, data, size_t(plane_stride) * scalar_bytes, row,
                              size_t(n_planes),
                              (flags & MOPT_INPUT_DEVICE) ? hipMemcpyDeviceToDevice

@@ -135,6 +135,18 @@ namespace mopt_detail {
 using mopt::kNumParams;
 using mopt::kResultDoubles;
 
+// Non-blocking streams are recycled per device: creating one costs the runtime ~1.5 ms and
+// destroying it ~1.2 ms, which would dominate the construction of a small cost.  A released
+// stream has been synchronised by its last owner.  (Streams still pooled at process exit are
+// left to the runtime's own teardown.)
+hipError_t acquireStream(int device, hipStream_t *out);
+void releaseStream(int device, hipStream_t stream);
+
+// Device memory of the current device through the size-class cache of device_pool.cpp.  Release
+// only after the work that used the block has completed.
+hipError_t deviceAlloc(void **out, size_t bytes);
+void deviceRelease(void *p);
+
 int commonCreate(mopt_cost *c, int device);  // device, stream, partial / result buffers
 void destroyCost(mopt_cost *c);
 // enqueue one linearization / cost sweep + its finalize on `s`; results to d_result (+ optional

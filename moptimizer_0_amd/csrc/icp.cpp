@@ -50,13 +50,13 @@ int buildIcpGrid(const S *src, long long n, const S *tgt, long long m, double ma
   }
   out_matcher = std::move(mt);  // from here on the caller frees the matcher's device arrays
   IcpMatcher &g = *out_matcher;
-  MOPT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_cell_start), size_t(ncells + 1) * sizeof(int)));
-  MOPT_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g.d_matched), 64));
+  MOPT_HIP_TRY(deviceAlloc(reinterpret_cast<void **>(&g.d_cell_start), size_t(ncells + 1) * sizeof(int)));
+  MOPT_HIP_TRY(deviceAlloc(reinterpret_cast<void **>(&g.d_matched), 64));
   MOPT_HIP_TRY(d_perm_t.alloc(size_t(m) * sizeof(int)));
   MOPT_HIP_TRY(mopt::icpSortByCell<S>(d_tgt.as<S>(), m, g.origin, g.cell, g.dims, d_perm_t.as<int>(),
                                       g.d_cell_start, s));
   if (m > 0) {
-    MOPT_HIP_TRY(hipMalloc(&g.d_sorted, size_t(m) * 4 * sizeof(S)));
+    MOPT_HIP_TRY(deviceAlloc(&g.d_sorted, size_t(m) * 4 * sizeof(S)));
     MOPT_HIP_TRY(mopt::icpGatherPoints<S>(d_tgt.as<S>(), d_perm_t.as<int>(), m,
                                           static_cast<S *>(g.d_sorted), true, s));
   }
@@ -126,12 +126,12 @@ int mopt_icp_create(mopt_cost **out, int device, int scalar_bytes, const void *s
   std::unique_ptr<IcpMatcher> matcher;
   auto freeMatcher = [&]() {
     if (!matcher) return;
-    if (matcher->d_sorted) (void)hipFree(matcher->d_sorted);
-    if (matcher->d_cell_start) (void)hipFree(matcher->d_cell_start);
-    if (matcher->d_matched) (void)hipFree(matcher->d_matched);
+    deviceRelease(matcher->d_sorted);
+    deviceRelease(matcher->d_cell_start);
+    deviceRelease(matcher->d_matched);
   };
   hipStream_t build_stream = nullptr;
-  MOPT_HIP_TRY(hipStreamCreateWithFlags(&build_stream, hipStreamNonBlocking));
+  MOPT_HIP_TRY(acquireStream(device, &build_stream));
   DeviceScratch d_src_sorted;
   int rc = scalar_bytes == 8
                ? buildIcpGrid<double>(static_cast<const double *>(src_xyz), num_src,
@@ -141,7 +141,7 @@ int mopt_icp_create(mopt_cost **out, int device, int scalar_bytes, const void *s
                                      static_cast<const float *>(tgt_xyz), num_tgt, max_distance,
                                      build_stream, matcher, d_src_sorted);
   (void)hipStreamSynchronize(build_stream);
-  (void)hipStreamDestroy(build_stream);
+  releaseStream(device, build_stream);
   // the sources go into the resident tiles in cell order; the target planes are filled by the
   // first search
   mopt_cost *raw = nullptr;

@@ -1,0 +1,98 @@
+// Time to solution of the reference's registration problem (tst/point2point.cpp:192-217: LM from
+// x0 = 0 to the fixture pose with the numerical cost), same LM loop, two cost implementations:
+//   CPU  oracle::CostFunctionNumericalDynamic  (restatement of the reference cost, its linearize
+//        single-threaded like the original)
+//   HIP  moptimizer::hip::CostFunctionNumericalDynamic (construction = PCIe copy included)
+//   bench_solve [N ...]     default 30000 1000000 10000000
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "moptimizer_amd/cost_function_hip.hpp"
+#include "moptimizer_amd/levenberg_marquadt.hpp"
+#include "moptimizer_amd/so3.hpp"
+
+#include "cpu_costs.hpp"
+#include "test_models.hpp"
+
+namespace mh = moptimizer::hip;
+using Clock = std::chrono::steady_clock;
+static double msSince(Clock::time_point t0) {
+  return std::chrono::duration<double, std::milli>(Clock::now() - t0).count();
+}
+
+int main(int argc, char **argv) {
+  std::vector<long> sizes;
+  for (int a = 1; a < argc; ++a) sizes.push_back(std::atol(argv[a]));
+  if (sizes.empty()) sizes = {30000L, 1000000L, 10000000L};
+  const double xt[6] = {10.5, 10.2, 0.1, 0.38994502377414, 0.31542006718654, 0.54962215934141};
+  double T[16];
+  moptimizer::so3::convert6DOFParameterToMatrix<double>(xt, T);
+  try {
+    {  // HIP context creation is a per-process cost, not a per-solve one
+      double p[6] = {0, 0, 0, 1, 1, 1};
+      auto warm = std::make_shared<mh::Point2PointDeviceModel<double>>(p, p + 3, size_t(1));
+      mh::CostFunctionNumericalDynamic<double> cost(warm, 6, 3, 1);
+      double x[6] = {0, 0, 0, 0, 0, 0}, H[36], b[6];
+      for (int k = 0; k < 700; ++k) cost.linearize(x, H, b);
+    }
+    std::printf("| N | CPU solve ms (iterations) | HIP construct ms | HIP solve ms (iterations, sweeps) | "
+                "solve speed-up | incl. construction | max |x_cpu - x_hip| |\n|---|---|---|---|---|---|---|\n");
+    for (long n : sizes) {
+      std::vector<double> src(size_t(n) * 3), tgt(size_t(n) * 3);
+      std::mt19937_64 gen(42);
+      std::uniform_real_distribution<double> uni(0.0, 10.0);
+      std::normal_distribution<double> noise(0.0, 0.01);
+      for (long i = 0; i < n; ++i) {
+        for (int k = 0; k < 3; ++k) src[3 * i + k] = uni(gen);
+        for (int r = 0; r < 3; ++r)
+          tgt[3 * i + r] = T[0 * 4 + r] * src[3 * i] + T[1 * 4 + r] * src[3 * i + 1] +
+                           T[2 * 4 + r] * src[3 * i + 2] + T[3 * 4 + r] + noise(gen);
+      }
+      double x_cpu[6] = {0, 0, 0, 0, 0, 0}, x_hip[6] = {0, 0, 0, 0, 0, 0};
+      unsigned it_cpu = 0, it_hip = 0;
+      double cpu_ms = 0, build_ms = 0, hip_ms = 0;
+      long long sweeps = 0;
+      {
+        auto model = std::make_shared<oracle::Point2Point<double>>(src.data(), tgt.data());
+        oracle::CostFunctionNumericalDynamic<double> cost(model, 6, 3, int(n));
+        moptimizer::LevenbergMarquadtDynamic<double> lm(6);
+        lm.setMaximumIterations(50);
+        lm.addCost(&cost);
+        const auto t0 = Clock::now();
+        lm.minimize(x_cpu);
+        cpu_ms = msSince(t0);
+        it_cpu = lm.getExecutedIterations();
+      }
+      {
+        auto t0 = Clock::now();
+        auto model = std::make_shared<mh::Point2PointDeviceModel<double>>(src.data(), tgt.data(), size_t(n));
+        mh::CostFunctionNumericalDynamic<double> cost(model, 6, 3, int(n));
+        build_ms = msSince(t0);
+        moptimizer::LevenbergMarquadtDynamic<double> lm(6);
+        lm.setMaximumIterations(50);
+        lm.addCost(&cost);
+        std::int64_t s0 = 0, s1 = 0, h = 0;
+        mopt_cost_stats(cost.handle(), &s0, &h);
+        t0 = Clock::now();
+        lm.minimize(x_hip);
+        hip_ms = msSince(t0);
+        mopt_cost_stats(cost.handle(), &s1, &h);
+        sweeps = s1 - s0;
+        it_hip = lm.getExecutedIterations();
+      }
+      double diff = 0;
+      for (int i = 0; i < 6; ++i) diff = std::max(diff, std::fabs(x_cpu[i] - x_hip[i]));
+      std::printf("| %ld | %.1f (%u) | %.2f | %.3f (%u, %lld) | %.0fx | %.0fx | %.1e |\n", n, cpu_ms, it_cpu,
+                  build_ms, hip_ms, it_hip, sweeps, cpu_ms / hip_ms, cpu_ms / (hip_ms + build_ms), diff);
+      std::fflush(stdout);
+    }
+  } catch (const std::exception &e) {
+    std::printf("error: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}
