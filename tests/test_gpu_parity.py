@@ -765,6 +765,48 @@ def test_parallel_cost_test_of_the_reference(hip_lib, oracle):
     assert abs(moved.compute_cost(x) - 14.0e6) <= 1e-12 * 14.0e6
 
 
+def test_costs_used_concurrently_from_threads(hip_lib, oracle):
+    """Header contract: a cost is used by one thread at a time, different costs may be used
+    concurrently.  Four threads, each constructing its own cost (different sizes, so the stream
+    and buffer caches are exercised from several threads), sweeping it repeatedly and destroying
+    it; every result must equal the single-threaded answer bit for bit."""
+    import threading
+    sizes = (3001, 20_000, 777, 65_537)
+    data = [ds.synthetic_pair(n, seed=80 + k, noise=0.02) for k, n in enumerate(sizes)]
+    want = []
+    for src, tgt in data:
+        c = hip_lib.Point2PointCost(src, tgt)
+        c.set_speculation(False)
+        want.append((c.linearize(ds.X_GENERIC, 2), c.compute_cost(ds.X_GENERIC)))
+        check(want[-1][0], oracle_ref(oracle, src, tgt, ds.X_GENERIC, 2), tol=fd_tolerance(ds.X_GENERIC))
+        c.close()
+    errors = []
+
+    def worker(k):
+        try:
+            src, tgt = data[k]
+            for _ in range(5):
+                c = hip_lib.Point2PointCost(src, tgt)
+                c.set_speculation(False)
+                for _ in range(40):
+                    H, b, s = c.linearize(ds.X_GENERIC, 2)
+                    if not (np.array_equal(H, want[k][0][0]) and np.array_equal(b, want[k][0][1])
+                            and s == want[k][0][2] and c.compute_cost(ds.X_GENERIC) == want[k][1]):
+                        errors.append("thread %d: result differs" % k)
+                        return
+                c.close()
+        except Exception as e:   # noqa: BLE001 - reported to the main thread
+            errors.append("thread %d: %r" % (k, e))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(len(sizes))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    assert not any(t.is_alive() for t in threads)
+
+
 def test_group_shards_on_one_gpu(hip_lib, oracle):
     """mopt_group_* with a repeated device: three contiguous shards of a ragged count on GPU 0.
     Same result as one cost over everything (shard invariance) and as the oracle."""
