@@ -6,7 +6,11 @@
                  mopt kernel, corrected as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE
                  counts 64 B per 128-B request of a 16-B-per-lane stream: x2; WRITE_SIZE exact; both
                  in KiB), collected in separate --pmc passes.
-Usage: summarize_profiles.py TAG STATS_CSV [FETCH_COUNTER_CSV WRITE_COUNTER_CSV]"""
+Usage: summarize_profiles.py TAG STATS_CSV [FETCH_COUNTER_CSV WRITE_COUNTER_CSV [BENCH_KEY]]
+STATS_CSV may be "-" (PMC passes only).  BENCH_KEY ("<mode>_<dtype>_n<N>", e.g. analytic_f64_n10000000)
+also records the sweep kernel's bytes per launch in profiles/hbm_traffic.json, the file bench.py reads
+`roofline.traffic` from: the sweep kernel is the mopt kernel with the most bytes per launch among those
+launched more than twice (which excludes the one-off re-layout)."""
 import collections
 import csv
 import json
@@ -25,16 +29,17 @@ def main():
     tag, stats = sys.argv[1], sys.argv[2]
     out_dir = os.path.join(ROOT, "profiles")
     os.makedirs(out_dir, exist_ok=True)
-    rows = list(csv.DictReader(open(stats)))
+    rows = list(csv.DictReader(open(stats))) if stats != "-" else []
     keep = [r for r in rows if "mopt" in r["Name"] or "copyBuffer" in r["Name"]
             or "rccl" in r["Name"].lower() or "nccl" in r["Name"].lower()]
-    with open(os.path.join(out_dir, "%s_kernel_stats.csv" % tag), "w", newline="") as f:
-        w = csv.writer(f)
-        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
-        for r in keep:
-            w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"],
-                        r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
-    print("wrote", "%s_kernel_stats.csv" % tag, len(keep), "rows")
+    if stats != "-":
+        with open(os.path.join(out_dir, "%s_kernel_stats.csv" % tag), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+            for r in keep:
+                w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"],
+                            r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+        print("wrote", "%s_kernel_stats.csv" % tag, len(keep), "rows")
     if len(sys.argv) >= 5:
         res = collections.OrderedDict()
         for cname, path in (("FETCH_SIZE", sys.argv[3]), ("WRITE_SIZE", sys.argv[4])):
@@ -54,6 +59,16 @@ def main():
         with open(os.path.join(out_dir, "%s_hbm_traffic.json" % tag), "w") as f:
             json.dump(res, f, indent=1)
         print(json.dumps(res, indent=1))
+        if len(sys.argv) >= 6:
+            sweeps = {k: d for k, d in res.items() if d.get("launches_FETCH_SIZE", 0) > 2}
+            name = max(sweeps, key=lambda k: sweeps[k]["hbm_bytes_per_launch"])
+            tpath = os.path.join(out_dir, "hbm_traffic.json")
+            table = json.load(open(tpath)) if os.path.exists(tpath) else {}
+            table[sys.argv[5]] = res[name]["hbm_bytes_per_launch"]
+            table["_source"] = ("profiles/*_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE "
+                                "passes, gfx950 x2 correction on FETCH_SIZE); bytes per launch of the sweep kernel")
+            json.dump(table, open(tpath, "w"), indent=1)
+            print("hbm_traffic.json:", sys.argv[5], "=", table[sys.argv[5]], "from", name)
 
 
 if __name__ == "__main__":
