@@ -53,7 +53,7 @@ def parse_args():
     ap.add_argument("--collective", choices=["rccl", "torch"], default="rccl",
                     help="N>1: all-reduce inside the C-ABI library on the cost's stream (rccl), or "
                          "torch.distributed.all_reduce on the async result (torch)")
-    ap.add_argument("--event-every", type=int, default=4,
+    ap.add_argument("--event-every", type=int, default=8,
                     help="bracket every N-th sweep launch of the timed region with HIP events "
                          "(a recorded pair costs the host ~5 us; 1 = every launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
