@@ -765,6 +765,61 @@ def test_parallel_cost_test_of_the_reference(hip_lib, oracle):
     assert abs(moved.compute_cost(x) - 14.0e6) <= 1e-12 * 14.0e6
 
 
+def test_randomized_configurations_against_oracle(hip_lib, oracle):
+    """Seeded sweep over the configuration space of the path: size (incl. exact tile multiples and
+    one past), pose (zero components, rotations up to ~3 rad, sub-epsilon rotation), Jacobian
+    mode, kernel variant, loss and covariance (identity / diagonal / symmetric / general) — every
+    combination against the CPU restatement on the same inputs."""
+    rng = np.random.default_rng(2026)
+    sizes = [1, 2, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 4096, 5000, 12_345]
+    for trial in range(48):
+        n = int(sizes[trial % len(sizes)])
+        src, tgt = ds.synthetic_pair(n, seed=1000 + trial, noise=float(rng.choice([0.0, 0.01, 0.5])))
+        kind = trial % 6
+        if kind == 0:
+            x = np.zeros(6)
+        elif kind == 1:
+            x = np.concatenate([rng.normal(0, 5.0, 3), np.zeros(3)])           # pure translation
+        elif kind == 2:
+            x = np.concatenate([np.zeros(3), rng.normal(0, 1.0, 3)])           # pure rotation
+        elif kind == 3:
+            w = rng.normal(0, 1.0, 3)
+            x = np.concatenate([rng.normal(0, 1.0, 3), w / np.linalg.norm(w) * 3.0])   # near pi
+        elif kind == 4:
+            x = np.concatenate([rng.normal(0, 1.0, 3), [1e-17, 0.0, 0.0]])     # below 10 eps: R = I
+        else:
+            x = rng.normal(0, 0.7, 6)
+        jac_mode = int(rng.integers(0, 3))
+        variant = int(rng.integers(0, 3))
+        cov_kind = int(rng.integers(0, 4))
+        if cov_kind == 0:
+            cov = None
+        elif cov_kind == 1:
+            cov = np.diag(rng.uniform(0.1, 3.0, 3))
+        elif cov_kind == 2:
+            a = rng.normal(0, 1.0, (3, 3))
+            cov = a @ a.T + 0.1 * np.eye(3)
+        else:
+            cov = rng.normal(0, 1.0, (3, 3))
+        loss = None if rng.random() < 0.5 else float(rng.choice([0.01, 1.0, 100.0]))
+        cost = hip_lib.Point2PointCost(src, tgt)
+        cost.set_kernel_variant(variant)
+        cost.set_covariance(cov)
+        cost.set_loss(0 if loss is None else 1, loss or 0.0)
+        want = oracle_ref(oracle, src, tgt, x, jac_mode, cov=cov,
+                          loss_kind=0 if loss is None else 1, loss_param=loss or 0.0)
+        tol = fd_tolerance(x) if jac_mode == 2 else REL
+        try:
+            check(cost.linearize(x, jac_mode), want, tol=tol)
+            w = oracle.p2p_cost(src, tgt, x)
+            cost.set_speculation(False)
+            assert abs(cost.compute_cost(x) - w) <= REL * w + 1e-300
+        except AssertionError as e:
+            raise AssertionError("trial %d: n=%d x=%s mode=%d variant=%d cov=%d loss=%s: %s"
+                                 % (trial, n, x, jac_mode, variant, cov_kind, loss, e))
+        cost.close()
+
+
 def test_costs_used_concurrently_from_threads(hip_lib, oracle):
     """Header contract: a cost is used by one thread at a time, different costs may be used
     concurrently.  Four threads, each constructing its own cost (different sizes, so the stream
