@@ -53,9 +53,10 @@ def parse_args():
     ap.add_argument("--collective", choices=["rccl", "torch"], default="rccl",
                     help="N>1: all-reduce inside the C-ABI library on the cost's stream (rccl), or "
                          "torch.distributed.all_reduce on the async result (torch)")
-    ap.add_argument("--event-every", type=int, default=8,
+    ap.add_argument("--event-every", type=int, default=0,
                     help="bracket every N-th sweep launch of the timed region with HIP events "
-                         "(a recorded pair costs the host ~5 us; 1 = every launch)")
+                         "(a recorded pair costs the host ~5 us; 1 = every launch; 0 = choose so "
+                         "that about 25 launches are timed, at most every 8th)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="target CPU time of the cpu_baseline sample")
@@ -272,7 +273,9 @@ def main():
     for k in range(args.warmup):
         step(k)
     barrier()
-    cost.set_profiling(max(1, args.event_every))
+    if args.event_every <= 0:
+        args.event_every = min(8, max(1, args.steps // 25))
+    cost.set_profiling(args.event_every)
     t0 = time.perf_counter()
     for k in range(args.steps):
         H, b, s = step(k)
