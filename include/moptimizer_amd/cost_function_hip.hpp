@@ -233,10 +233,12 @@ class PowellDeviceModel : public DeviceModel<double> {
 };
 
 /// A model written by the user: the device counterpart of deriving from BaseModel /
-/// BaseModelJacobian (model.h:29-47).  `residual_body` / `jacobian_body` are the statements of
-///   void f   (const Scalar *x, const Scalar *d, Scalar *r)      // r: num_outputs values
-///   void f_df(const Scalar *x, const Scalar *d, Scalar *J)      // J: num_outputs x n, row-major
-/// in HIP C++ (`S` names the scalar type); d holds the element's value from each data plane.
+/// BaseModelJacobian (model.h:29-47).  The bodies are the statements of
+///   void setup(const Scalar *x, Scalar *a)                                    // optional: num_aux per-x values
+///   void f    (const Scalar *x, const Scalar *a, const Scalar *d, Scalar *r)  // r: num_outputs values
+///   void f_df (const Scalar *x, const Scalar *a, const Scalar *d, Scalar *J)  // J: num_outputs x n, row-major
+/// in HIP C++ (`S` names the scalar type); d holds the element's value from each data plane and
+/// `a` what setup computed for this parameter vector (IBaseModel::setup, model.h:19-22).
 /// Compiled for the GPU when the cost function is constructed; a model without a Jacobian body
 /// behaves as BaseModel does (f_df throws).
 template <typename Scalar>
@@ -244,9 +246,11 @@ class JitDeviceModel : public DeviceModel<Scalar> {
  public:
   using Ptr = std::shared_ptr<JitDeviceModel>;
   JitDeviceModel(int num_parameters, int num_outputs, std::string residual_body,
-                 std::string jacobian_body, std::vector<const Scalar *> planes)
-      : n_(num_parameters), m_(num_outputs), residual_(std::move(residual_body)),
-        jacobian_(std::move(jacobian_body)), planes_(std::move(planes)) {}
+                 std::string jacobian_body, std::vector<const Scalar *> planes, int num_aux = 0,
+                 std::string setup_body = std::string())
+      : n_(num_parameters), m_(num_outputs), aux_(num_aux), residual_(std::move(residual_body)),
+        jacobian_(std::move(jacobian_body)), setup_(std::move(setup_body)),
+        planes_(std::move(planes)) {}
   typename IBaseModel<Scalar>::Ptr clone() const override {
     return std::make_shared<JitDeviceModel>(*this);
   }
@@ -257,6 +261,7 @@ class JitDeviceModel : public DeviceModel<Scalar> {
       std::copy(planes_[p], planes_[p] + num_residuals, staged.begin() + p * num_residuals);
     mopt_cost *h = nullptr;
     throwOnError(mopt_jit_model_create(&h, device, int(sizeof(Scalar)), n_, m_, int(planes_.size()),
+                                       aux_, setup_.empty() ? nullptr : setup_.c_str(),
                                        residual_.c_str(), jacobian_.empty() ? nullptr : jacobian_.c_str(),
                                        staged.data(), num_residuals, num_residuals, MOPT_INPUT_HOST),
                  "mopt_jit_model_create");
@@ -266,8 +271,8 @@ class JitDeviceModel : public DeviceModel<Scalar> {
   int numParameters() const override { return n_; }
 
  private:
-  int n_, m_;
-  std::string residual_, jacobian_;
+  int n_, m_, aux_;
+  std::string residual_, jacobian_, setup_;
   std::vector<const Scalar *> planes_;
 };
 

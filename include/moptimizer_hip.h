@@ -154,27 +154,35 @@ MOPT_API int mopt_scalar_model_create(mopt_cost **out, int device, int scalar_by
                                       int64_t count);
 
 /* A user-defined model: the device counterpart of subclassing IBaseModel (model.h:11-47).  The
- * reference calls the user's f(x, f_x, index) / f_df(x, f_x, jacobian, index) per index through a
- * virtual; a GPU sweep cannot, so the model is handed over as the *bodies* of those two functions
- * in HIP C++ and compiled for gfx950 at run time (hipRTC) into the per-element sweep:
+ * reference calls the user's setup(x) once per parameter vector and f(x, f_x, index) /
+ * f_df(x, f_x, jacobian, index) per index through virtuals; a GPU sweep cannot, so the model is
+ * handed over as the *bodies* of those functions in HIP C++ and compiled for gfx950 at run time
+ * (hipRTC) into the per-element sweep:
  *
- *   residual_body  statements of   void residual(const S *x, const S *d, S *r)
- *                  x = the n parameters, d = the element's n_planes data values, r = m outputs
- *   jacobian_body  statements of   void jacobian(const S *x, const S *d, S *J)
- *                  J = m x n row-major (J[a*n + j] = d r_a / d x_j), as IBaseModel::f_df fills it;
+ *   setup_body     statements of   void setup(const S *x, S *a)
+ *                  fills the n_aux per-x values `a` (e.g. x -> rotation matrix); runs once per
+ *                  sweep for x and, for forward differences, once per x + h_j e_j - the
+ *                  reference sets up one model clone per perturbed vector (linearization.h:91-95).
+ *                  NULL with n_aux = 0 when the model needs none
+ *   residual_body  statements of   void residual(const S *x, const S *a, const S *d, S *r)
+ *                  x = the n parameters, a = setup's output for this x, d = the element's n_planes
+ *                  data values, r = m outputs
+ *   jacobian_body  statements of   void jacobian(const S *x, const S *a, const S *d, S *J)
+ *                  J = m x n row-major (J[i*n + j] = d r_i / d x_j), as IBaseModel::f_df fills it;
  *                  NULL or "" -> only MOPT_JAC_NUMERIC is available (BaseModel without f_df,
  *                  model.h:29-33: the reference throws on f_df, so does mopt_cost_linearize)
  *
- * S is `double` or `float` per scalar_bytes; 1 <= n <= 8, 1 <= m <= 4, 0 <= n_planes <= 16.
- * data: n_planes arrays of `count` scalars, plane p at data + p * plane_stride (host memory, or
- * device memory with MOPT_INPUT_DEVICE); copied once.  Everything else (loss, covariance, numeric
- * differentiation with the reference's step, the returned unweighted cost, speculation, async
- * calls, communicators) is that of the built-in models.  A body that does not compile returns
- * MOPT_ERR_INVALID_ARGUMENT with the compiler log in mopt_last_error(). */
+ * S is `double` or `float` per scalar_bytes; 1 <= n <= 8, 1 <= m <= 4, 0 <= n_planes <= 16,
+ * 0 <= n_aux <= 64.  data: n_planes arrays of `count` scalars, plane p at data + p * plane_stride
+ * (host memory, or device memory with MOPT_INPUT_DEVICE); copied once.  Everything else (loss,
+ * covariance, numeric differentiation with the reference's step, the returned unweighted cost,
+ * speculation, async calls, communicators) is that of the built-in models.  A body that does not
+ * compile returns MOPT_ERR_INVALID_ARGUMENT with the compiler log in mopt_last_error(). */
 MOPT_API int mopt_jit_model_create(mopt_cost **out, int device, int scalar_bytes, int n_params,
-                                   int n_outputs, int n_planes, const char *residual_body,
-                                   const char *jacobian_body, const void *data,
-                                   int64_t plane_stride, int64_t count, unsigned flags);
+                                   int n_outputs, int n_planes, int n_aux, const char *setup_body,
+                                   const char *residual_body, const char *jacobian_body,
+                                   const void *data, int64_t plane_stride, int64_t count,
+                                   unsigned flags);
 
 MOPT_API int mopt_cost_destroy(mopt_cost *cost);
 

@@ -60,8 +60,9 @@ def load():
                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                      ctypes.c_int64],
         "mopt_jit_model_create": [c_void_pp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                  ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p,
-                                  ctypes.c_int64, ctypes.c_int64, ctypes.c_uint],
+                                  ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p,
+                                  ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                  ctypes.c_uint],
         "mopt_cost_destroy": [ctypes.c_void_p],
         "mopt_cost_set_covariance": [ctypes.c_void_p, ctypes.c_void_p],
         "mopt_cost_set_loss": [ctypes.c_void_p, ctypes.c_int, ctypes.c_double],
@@ -371,10 +372,11 @@ class ScalarModelCost(_CostBase):
 
 
 class JitModelCost(_CostBase):
-    """A user-defined model given as HIP source for its residual (and optionally Jacobian) body."""
+    """A user-defined model given as HIP source for its residual (and optionally setup and
+    Jacobian) bodies."""
 
     def __init__(self, n_params, n_outputs, residual_body, jacobian_body=None, planes=None,
-                 device=0, dtype=np.float64):
+                 device=0, dtype=np.float64, n_aux=0, setup_body=None):
         super().__init__()
         self.scalar_bytes = np.dtype(dtype).itemsize
         self.n_params, self.n_out = int(n_params), int(n_outputs)
@@ -385,8 +387,9 @@ class JitModelCost(_CostBase):
             assert data.ndim == 2
             n_planes, count = data.shape
         jac = None if not jacobian_body else jacobian_body.encode()
+        setup = None if not setup_body else setup_body.encode()
         check(load().mopt_jit_model_create(ctypes.byref(self._h), device, self.scalar_bytes,
-                                           self.n_params, self.n_out, n_planes,
+                                           self.n_params, self.n_out, n_planes, int(n_aux), setup,
                                            residual_body.encode(), jac,
                                            None if data is None else _ptr(data), count, count, 0))
         self.count = count

@@ -377,9 +377,7 @@ int jitSweepAsync(mopt_cost *c, bool cost_only, int jac_mode, const S *x, double
   args.count = filled.count;
   args.stride = filled.stride;
   args.loss_kind = filled.loss_kind;
-  args.numeric = jac_mode == MOPT_JAC_NUMERIC ? 1 : 0;
-  args.cost_only = cost_only ? 1 : 0;
-  args.pad_ = 0;
+  args.pad_[0] = args.pad_[1] = args.pad_[2] = 0;
   args.loss_param = filled.loss_param;
   for (int k = 0; k < 8; ++k) {
     args.x[k] = filled.x[k];
@@ -387,18 +385,23 @@ int jitSweepAsync(mopt_cost *c, bool cost_only, int jac_mode, const S *x, double
   }
   for (int k = 0; k < 16; ++k) args.cov[k] = filled.cov[k];
   args.partials = c->d_partials;
+  const int mode = cost_only ? 0 : (jac_mode == MOPT_JAC_NUMERIC ? 2 : 1);
+  const bool cov_symmetric = c->cov_mode != mopt::kCovGeneral;
+  const mopt::JitVariant *variant = mopt::jitVariant(c->jit, mode, cov_symmetric);
+  if (!variant) return fail(MOPT_ERR_INVALID_ARGUMENT, mopt::jitLastError());
   long long blocks = (c->count + mopt::kBlockThreads - 1) / mopt::kBlockThreads;
   if (blocks > c->num_cus * 4) blocks = c->num_cus * 4;
   if (blocks < 1) blocks = 1;
   const int grid = int(blocks);
   const int n = c->n_params;
   SweepTimer timer(c, s);
-  MOPT_HIP_TRY(mopt::jitLaunch(c->jit, &args, sizeof args, grid, s));
+  MOPT_HIP_TRY(mopt::jitLaunch(*variant, &args, sizeof args, grid, s));
   timer.stop();
   if (cost_only) {
     MOPT_HIP_TRY(mopt::launchFinalizeCost(c->d_partials, grid, d_out, pub, s));
   } else {
-    MOPT_HIP_TRY(mopt::launchFinalizeDense(c->d_partials, grid, n * n + n + 1, n, d_out, pub, s));
+    const int nacc = cov_symmetric ? n * (n + 1) / 2 + n + 1 : n * n + n + 1;
+    MOPT_HIP_TRY(mopt::launchFinalizeDense(c->d_partials, grid, nacc, n, d_out, pub, s));
   }
   return MOPT_OK;
 }
@@ -822,9 +825,9 @@ int mopt_scalar_model_create(mopt_cost **out, int device, int scalar_bytes, int 
 }
 
 int mopt_jit_model_create(mopt_cost **out, int device, int scalar_bytes, int n_params,
-                          int n_outputs, int n_planes, const char *residual_body,
-                          const char *jacobian_body, const void *data, int64_t plane_stride,
-                          int64_t count, unsigned flags) {
+                          int n_outputs, int n_planes, int n_aux, const char *setup_body,
+                          const char *residual_body, const char *jacobian_body, const void *data,
+                          int64_t plane_stride, int64_t count, unsigned flags) {
   if (!out) return fail(MOPT_ERR_INVALID_ARGUMENT, "out is NULL");
   *out = nullptr;
   if (scalar_bytes != 4 && scalar_bytes != 8)
@@ -842,8 +845,8 @@ int mopt_jit_model_create(mopt_cost **out, int device, int scalar_bytes, int n_p
   c->data_stride = count;
   int rc = commonCreate(c.get(), device);
   if (rc != MOPT_OK) return rc;
-  if (!mopt::jitCompile(scalar_bytes, n_params, n_outputs, n_planes, residual_body, jacobian_body,
-                        c->jit))
+  if (!mopt::jitCreate(scalar_bytes, n_params, n_outputs, n_planes, n_aux, setup_body,
+                       residual_body, jacobian_body, c->jit))
     return fail(MOPT_ERR_INVALID_ARGUMENT, mopt::jitLastError());
   if (n_planes > 0) {
     const size_t row = size_t(count) * scalar_bytes;

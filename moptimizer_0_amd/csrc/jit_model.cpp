@@ -1,11 +1,18 @@
 // User-defined device models: the GPU counterpart of subclassing moptimizer::IBaseModel.
 //
-// In the reference a new model is a C++ class whose f() (and optionally f_df()) the sweep calls
-// per index through a virtual (include/moptimizer/model.h:11-47).  Device code cannot call host
-// virtuals, so here a model is the *text* of those two function bodies; hipRTC compiles it for
-// gfx950 into the same per-element sweep the built-in models use (residual, forward-difference
-// or supplied Jacobian, loss weight, w J^T S J / w J^T S r / r^T r accumulation, one partial row
-// per workgroup).  The workgroup rows are finished by the library's finalizeDenseKernel.
+// In the reference a new model is a C++ class whose setup() runs once per parameter vector and
+// whose f() (and optionally f_df()) the sweep calls per index through a virtual
+// (include/moptimizer/model.h:11-47).  Device code cannot call host virtuals, so here a model is
+// the *text* of those function bodies; hipRTC compiles it for gfx950 into the same per-element
+// sweep the built-in models use (residual, forward-difference or supplied Jacobian, loss weight,
+// w J^T S J / w J^T S r / r^T r accumulation, one partial row per workgroup).  The workgroup rows
+// are finished by the library's finalizeDenseKernel.
+//
+// One kernel is compiled per (sweep kind, covariance form) the cost is actually used with -
+// cost only / supplied Jacobian / forward differences, symmetric or general covariance - so that
+// each carries only its own registers: a single kernel with run-time switches held both Jacobian
+// paths and all n*n accumulators live and ran the point-to-point model at occupancy 1 with
+// scratch spills (825 us for 10 M elements against 76 us for the hand-written sweep).
 #include "jit_model.hpp"
 
 #include <hip/hiprtc.h>
@@ -17,31 +24,32 @@
 namespace mopt {
 namespace {
 
-// Compiled at run time as  kJitPrologue + the two user functions + kJitSweep;  MOPT_S / MOPT_N /
-// MOPT_M / MOPT_D arrive as -D options.
+// Compiled at run time as  kJitPrologue + the three user functions + kJitSweep;  MOPT_S / MOPT_N /
+// MOPT_M / MOPT_D / MOPT_A / MOPT_MODE / MOPT_COVSYM arrive as -D options.
 const char *const kJitPrologue = R"JIT(
 #define kBlock 256
 typedef MOPT_S S;
 #define N MOPT_N
 #define M MOPT_M
 #define D MOPT_D
-#define NACC (N * N + N + 1)
+#define AUX MOPT_A
+#define MODE MOPT_MODE       /* 0 cost only, 1 supplied Jacobian, 2 forward differences */
+#define COVSYM MOPT_COVSYM   /* 1: S symmetric -> H symmetric, upper triangle only */
+#define NH (COVSYM ? N * (N + 1) / 2 : N * N)
+#define NACC (MODE == 0 ? 1 : NH + N + 1)
 
 struct JitArgs {
   const S *data;       // planes: data[p * stride + i]
   long long count;
   long long stride;
   int loss_kind;       // 0 none, 1 Geman-McClure
-  int numeric;         // 1: forward differences, 0: the supplied Jacobian
-  int cost_only;
-  int pad_;
+  int pad_[3];
   S loss_param;
   S x[8];
   S h[8];
   S cov[16];           // row-major M x M
-  double *partials;    // [grid][NACC] (or [grid] when cost_only)
+  double *partials;    // [grid][NACC]
 };
-
 )JIT";
 
 const char *const kJitSweep = R"JIT(
@@ -52,73 +60,107 @@ __device__ inline double wave_sum(double v) {
 
 extern "C" __global__ __launch_bounds__(kBlock) void mopt_jit_sweep(const JitArgs A) {
   __shared__ double lds[kBlock / 64][NACC];
+  // IBaseModel::setup (model.h:19-22): once per parameter vector, here once per workgroup and
+  // parameter vector - x itself and, for forward differences, x + h_j e_j (the reference sets
+  // up one clone of the model per perturbed vector, linearization.h:91-95).
+  __shared__ S aux[(N + 1) * (AUX > 0 ? AUX : 1)];
+  if (AUX > 0) {
+    const int variants = MODE == 2 ? N + 1 : 1;
+    if ((int)threadIdx.x < variants) {
+      S xs[N];
+#pragma unroll
+      for (int k = 0; k < N; ++k) xs[k] = A.x[k] + ((int)threadIdx.x == k + 1 ? A.h[k] : S(0));
+      user_setup(xs, aux + threadIdx.x * AUX);
+    }
+    __syncthreads();
+  }
   double acc[NACC];
+#pragma unroll
   for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
   for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < A.count;
        i += (long long)gridDim.x * kBlock) {
+    // the per-x values stay in LDS: without this the compiler keeps all (N + 1) * AUX of them in
+    // registers across the loop
+    asm volatile("" ::: "memory");
     S d[D > 0 ? D : 1];
+#pragma unroll
     for (int p = 0; p < D; ++p) d[p] = A.data[p * A.stride + i];
     S r[M];
-    user_residual(A.x, d, r);
+    user_residual(A.x, aux, d, r);
     S rr = 0;
+#pragma unroll
     for (int a = 0; a < M; ++a) rr += r[a] * r[a];
-    if (A.cost_only) {
-      acc[0] += (double)rr;
-      continue;
-    }
+#if MODE == 0
+    acc[0] += (double)rr;
+#else
     S J[M * N];  // row-major, as IBaseModel::f_df fills it
-    if (A.numeric) {
-      for (int j = 0; j < N; ++j) {
-        S xp[N];
-        for (int k = 0; k < N; ++k) xp[k] = A.x[k];
-        xp[j] += A.h[j];
-        S rp[M];
-        user_residual(xp, d, rp);
-        for (int a = 0; a < M; ++a) J[a * N + j] = (rp[a] - r[a]) / A.h[j];
-      }
-    } else {
-      user_jacobian(A.x, d, J);
+#if MODE == 2
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      S xp[N];
+#pragma unroll
+      for (int k = 0; k < N; ++k) xp[k] = A.x[k];
+      xp[j] += A.h[j];                                   // linearization.h:89
+      asm volatile("" ::: "memory");                     // fetch this vector's per-x values now
+      S rp[M];
+      user_residual(xp, aux + (1 + j) * AUX, d, rp);
+#pragma unroll
+      for (int a = 0; a < M; ++a) J[a * N + j] = (rp[a] - r[a]) / A.h[j];   // :105
     }
+#else
+    user_jacobian(A.x, aux, d, J);
+#endif
     S w = 1;
     if (A.loss_kind == 1) {
       const S den = rr + A.loss_param;
       w = (A.loss_param * A.loss_param) / (den * den);
     }
     S SJ[M * N], Sr[M];
+#pragma unroll
     for (int a = 0; a < M; ++a) {
+#pragma unroll
       for (int j = 0; j < N; ++j) {
         S v = 0;
+#pragma unroll
         for (int c = 0; c < M; ++c) v += A.cov[a * M + c] * J[c * N + j];
         SJ[a * N + j] = v;
       }
       S v = 0;
+#pragma unroll
       for (int c = 0; c < M; ++c) v += A.cov[a * M + c] * r[c];
       Sr[a] = v;
     }
+#pragma unroll
     for (int j = 0; j < N; ++j)
-      for (int i2 = 0; i2 < N; ++i2) {
+#pragma unroll
+      for (int i2 = 0; i2 < (COVSYM ? j + 1 : N); ++i2) {
         S v = 0;
+#pragma unroll
         for (int a = 0; a < M; ++a) v += (w * J[a * N + i2]) * SJ[a * N + j];
-        acc[j * N + i2] += (double)v;
+        acc[COVSYM ? j * (j + 1) / 2 + i2 : j * N + i2] += (double)v;   // H(i2, j)
       }
+#pragma unroll
     for (int i2 = 0; i2 < N; ++i2) {
       S v = 0;
+#pragma unroll
       for (int a = 0; a < M; ++a) v += (w * J[a * N + i2]) * Sr[a];
-      acc[N * N + i2] += (double)v;
+      acc[NH + i2] += (double)v;
     }
-    acc[N * N + N] += (double)rr;
+    acc[NH + N] += (double)rr;
+#endif
   }
-  const int nacc = A.cost_only ? 1 : NACC;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int k = 0; k < nacc; ++k) {
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) {
     const double v = wave_sum(acc[k]);
     if (lane == 0) lds[wave][k] = v;
   }
   __syncthreads();
-  if ((int)threadIdx.x < nacc) {
+  if ((int)threadIdx.x < NACC) {
     double v = 0.0;
+#pragma unroll
     for (int w2 = 0; w2 < kBlock / 64; ++w2) v += lds[w2][threadIdx.x];
-    A.partials[(size_t)blockIdx.x * nacc + threadIdx.x] = v;
+    A.partials[(size_t)blockIdx.x * NACC + threadIdx.x] = v;
   }
 }
 )JIT";
@@ -128,29 +170,15 @@ std::string &jitError() {
   return e;
 }
 
-}  // namespace
-
-const char *jitLastError() { return jitError().c_str(); }
-
-bool jitCompile(int scalar_bytes, int n_params, int n_outputs, int n_planes,
-                const char *residual_body, const char *jacobian_body, JitKernel &out) {
-  if (!residual_body || n_params < 1 || n_params > kMaxParams || n_outputs < 1 || n_outputs > 4 ||
-      n_planes < 0 || n_planes > 16) {
-    jitError() = "bad model shape (1 <= n <= 8, 1 <= m <= 4, planes <= 16) or no residual source";
-    return false;
-  }
-  std::string source(kJitPrologue);
-  source += "__device__ inline void user_residual(const S *x, const S *d, S *r) {\n";
-  source += residual_body;
-  source += "\n}\n__device__ inline void user_jacobian(const S *x, const S *d, S *J) {\n";
-  source += jacobian_body ? jacobian_body : "";
-  source += "\n}\n";
-  source += kJitSweep;
+bool compileVariant(JitKernel &k, int mode, bool cov_symmetric, JitVariant &out) {
   const std::string defs[] = {
-      std::string("-DMOPT_S=") + (scalar_bytes == 8 ? "double" : "float"),
-      "-DMOPT_N=" + std::to_string(n_params),
-      "-DMOPT_M=" + std::to_string(n_outputs),
-      "-DMOPT_D=" + std::to_string(n_planes),
+      std::string("-DMOPT_S=") + (k.scalar_bytes == 8 ? "double" : "float"),
+      "-DMOPT_N=" + std::to_string(k.n_params),
+      "-DMOPT_M=" + std::to_string(k.n_outputs),
+      "-DMOPT_D=" + std::to_string(k.n_planes),
+      "-DMOPT_A=" + std::to_string(k.n_aux),
+      "-DMOPT_MODE=" + std::to_string(mode),
+      std::string("-DMOPT_COVSYM=") + (cov_symmetric ? "1" : "0"),
       "--offload-arch=gfx950",
       "-O3",
       "-std=c++17",
@@ -159,7 +187,7 @@ bool jitCompile(int scalar_bytes, int n_params, int n_outputs, int n_planes,
   for (const auto &d : defs) opts.push_back(d.c_str());
 
   hiprtcProgram prog = nullptr;
-  if (hiprtcCreateProgram(&prog, source.c_str(), "mopt_jit_model.hip", 0, nullptr, nullptr) !=
+  if (hiprtcCreateProgram(&prog, k.source.c_str(), "mopt_jit_model.hip", 0, nullptr, nullptr) !=
       HIPRTC_SUCCESS) {
     jitError() = "hiprtcCreateProgram failed";
     return false;
@@ -189,22 +217,65 @@ bool jitCompile(int scalar_bytes, int n_params, int n_outputs, int n_planes,
     out.module = nullptr;
     return false;
   }
-  out.has_jacobian = jacobian_body && *jacobian_body;
   return true;
 }
 
-void jitRelease(JitKernel &k) {
-  if (k.module) (void)hipModuleUnload(k.module);
-  k.module = nullptr;
-  k.sweep = nullptr;
+}  // namespace
+
+const char *jitLastError() { return jitError().c_str(); }
+
+bool jitCreate(int scalar_bytes, int n_params, int n_outputs, int n_planes, int n_aux,
+               const char *setup_body, const char *residual_body, const char *jacobian_body,
+               JitKernel &out) {
+  if (!residual_body || n_params < 1 || n_params > kMaxParams || n_outputs < 1 || n_outputs > 4 ||
+      n_planes < 0 || n_planes > 16 || n_aux < 0 || n_aux > 64 || (n_aux > 0 && !setup_body)) {
+    jitError() = "bad model shape (1 <= n <= 8, 1 <= m <= 4, planes <= 16, aux <= 64 with a setup "
+                 "source) or no residual source";
+    return false;
+  }
+  out.scalar_bytes = scalar_bytes;
+  out.n_params = n_params;
+  out.n_outputs = n_outputs;
+  out.n_planes = n_planes;
+  out.n_aux = n_aux;
+  out.has_jacobian = jacobian_body && *jacobian_body;
+  out.source = kJitPrologue;
+  out.source += "__device__ inline void user_setup(const S *x, S *a) {\n";
+  out.source += (n_aux > 0 && setup_body) ? setup_body : "";
+  out.source += "\n}\n__device__ inline void user_residual(const S *x, const S *a, const S *d, S *r) {\n";
+  out.source += residual_body;
+  out.source += "\n}\n__device__ inline void user_jacobian(const S *x, const S *a, const S *d, S *J) {\n";
+  out.source += jacobian_body ? jacobian_body : "";
+  out.source += "\n}\n";
+  out.source += kJitSweep;
+  // Errors in the user's text must surface at construction: build the sweeps that touch each
+  // body now (cost only: setup + residual; supplied Jacobian); the others on first use.
+  if (!jitVariant(out, 0, true)) return false;
+  if (out.has_jacobian && !jitVariant(out, 1, true)) return false;
+  return true;
 }
 
-hipError_t jitLaunch(const JitKernel &k, const void *args, size_t args_bytes, int grid,
+const JitVariant *jitVariant(JitKernel &k, int mode, bool cov_symmetric) {
+  const int key = mode * 2 + (mode != 0 && cov_symmetric ? 1 : 0);
+  JitVariant &v = k.variants[key];
+  if (!v.sweep && !compileVariant(k, mode, mode == 0 || cov_symmetric, v)) return nullptr;
+  return &v;
+}
+
+void jitRelease(JitKernel &k) {
+  for (auto &v : k.variants) {
+    if (v.module) (void)hipModuleUnload(v.module);
+    v.module = nullptr;
+    v.sweep = nullptr;
+  }
+}
+
+hipError_t jitLaunch(const JitVariant &v, const void *args, size_t args_bytes, int grid,
                      hipStream_t stream) {
   size_t size = args_bytes;
   void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<void *>(args),
                     HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-  return hipModuleLaunchKernel(k.sweep, unsigned(grid), 1, 1, kBlockThreads, 1, 1, 0, stream, nullptr,
+  return hipModuleLaunchKernel(v.sweep, unsigned(grid), 1, 1, kBlockThreads, 1, 1, 0, stream, nullptr,
                                config);
 }
 

@@ -3,14 +3,23 @@
 
 #include <hip/hip_runtime.h>
 
+#include <string>
+
 #include "sweep.hpp"
 
 namespace mopt {
 
-struct JitKernel {
+struct JitVariant {
   hipModule_t module = nullptr;
   hipFunction_t sweep = nullptr;
+};
+
+// One user model: its assembled source and the sweeps compiled from it so far.
+struct JitKernel {
+  std::string source;
+  int scalar_bytes = 8, n_params = 0, n_outputs = 0, n_planes = 0, n_aux = 0;
   bool has_jacobian = false;
+  JitVariant variants[6];  // [mode * 2 + cov_symmetric]; mode 0 (cost only) uses slot 0
 };
 
 // Kernel argument block; the device-side declaration in jit_model.cpp has the same members in the
@@ -21,9 +30,7 @@ struct JitArgs {
   long long count;
   long long stride;
   int loss_kind;
-  int numeric;
-  int cost_only;
-  int pad_;
+  int pad_[3];
   S loss_param;
   S x[8];
   S h[8];
@@ -31,10 +38,15 @@ struct JitArgs {
   double *partials;
 };
 
-bool jitCompile(int scalar_bytes, int n_params, int n_outputs, int n_planes,
-                const char *residual_body, const char *jacobian_body, JitKernel &out);
+// Validates the shape, assembles the source and compiles the sweeps that exercise every user body.
+bool jitCreate(int scalar_bytes, int n_params, int n_outputs, int n_planes, int n_aux,
+               const char *setup_body, const char *residual_body, const char *jacobian_body,
+               JitKernel &out);
+// mode: 0 cost only, 1 supplied Jacobian, 2 forward differences.  Compiled on first use;
+// nullptr (and jitLastError) when that fails.
+const JitVariant *jitVariant(JitKernel &k, int mode, bool cov_symmetric);
 void jitRelease(JitKernel &k);
-hipError_t jitLaunch(const JitKernel &k, const void *args, size_t args_bytes, int grid,
+hipError_t jitLaunch(const JitVariant &v, const void *args, size_t args_bytes, int grid,
                      hipStream_t stream);
 const char *jitLastError();
 

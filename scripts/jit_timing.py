@@ -64,5 +64,21 @@ def main():
               (n, "jit oscillation n=3 m=2, numeric", k, n * 24 / (k * 1e-6) / 1e9, wall), flush=True)
 
 
+    # the path's own model written as source (setup + residual + Jacobian), against the built-in sweep
+    import torch
+    from bench import make_shard_on_gpu
+    from tests import datasets as ds
+    from tests.test_gpu_parity import P2P_JIT_SETUP, P2P_JIT_RESIDUAL, P2P_JIT_JACOBIAN
+    for n in args.n:
+        src, tgt = make_shard_on_gpu(torch, n, 0, torch.float64)
+        planes = torch.cat([src.T, tgt.T]).contiguous().cpu().numpy()
+        jit = mo.JitModelCost(6, 3, P2P_JIT_RESIDUAL, P2P_JIT_JACOBIAN, planes=planes, n_aux=12,
+                              setup_body=P2P_JIT_SETUP)
+        for name, mode in (("jit point2point, analytic", 0), ("jit point2point, numeric", 2)):
+            k, wall = timed(jit, ds.X_GENERIC, mode, args.iters)
+            print("n=%9d %-30s kernel %8.2f us  %7.1f GB/s  call %8.2f us" %
+                  (n, name, k, n * 48 / (k * 1e-6) / 1e9, wall), flush=True)
+
+
 if __name__ == "__main__":
     main()

@@ -605,6 +605,64 @@ def test_jit_models_match_builtin_models_and_numpy(hip_lib, oracle):
     assert "not_declared" in str(err.value)
 
 
+P2P_JIT_SETUP = """
+    const S wx = x[3], wy = x[4], wz = x[5];
+    const S th = sqrt(wx * wx + wy * wy + wz * wz);
+    S R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (th > 10 * (sizeof(S) == 8 ? S(2.220446049250313e-16) : S(1.1920929e-7))) {   // so3.cpp:47
+      const S kx = wx / th, ky = wy / th, kz = wz / th, sn = sin(th), cs = 1 - cos(th);
+      const S K[9] = {0, -kz, ky, kz, 0, -kx, -ky, kx, 0};
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+          S kk = 0;
+          for (int k = 0; k < 3; ++k) kk += K[i * 3 + k] * K[k * 3 + j];
+          R[i * 3 + j] += sn * K[i * 3 + j] + cs * kk;
+        }
+    }
+    for (int i = 0; i < 9; ++i) a[i] = R[i];
+    a[9] = x[0]; a[10] = x[1]; a[11] = x[2];
+"""
+P2P_JIT_RESIDUAL = """
+    for (int i = 0; i < 3; ++i)
+      r[i] = ((a[3 * i] * d[0] + a[3 * i + 1] * d[1]) + a[3 * i + 2] * d[2]) + a[9 + i] - d[3 + i];
+"""
+P2P_JIT_JACOBIAN = """
+    for (int k = 0; k < 18; ++k) J[k] = 0;
+    J[0] = 1; J[7] = 1; J[14] = 1;
+    J[4] = d[2];   J[5] = -d[1];
+    J[9] = -d[2];  J[11] = d[0];
+    J[15] = d[1];  J[16] = -d[0];
+"""
+
+
+def test_jit_model_with_setup_reproduces_point2point(hip_lib, oracle):
+    """The path's own model written by a user: setup(x) builds [R | t] once per parameter vector
+    (and per forward-difference vector) as tst/point2point.cpp:31 does, residual and Jacobian are
+    tst/point2point.cpp:36-49 and the row-major [I | -skew(p)].  Must agree with the CPU restatement
+    and with the hand-written kernels, all Jacobian modes, loss and covariance."""
+    src, tgt = ds.synthetic_pair(30_011, seed=91, noise=0.02)
+    planes = np.concatenate([src.T, tgt.T])
+    jit = hip_lib.JitModelCost(6, 3, P2P_JIT_RESIDUAL, P2P_JIT_JACOBIAN, planes=planes, n_aux=12,
+                               setup_body=P2P_JIT_SETUP)
+    builtin = hip_lib.Point2PointCost(src, tgt)
+    cov = np.array([[2.0, 0.1, 0.0], [0.1, 1.0, 0.3], [0.0, 0.3, 0.5]])
+    for x in (ds.X_ZERO, ds.X_GENERIC, np.array([1.0, -2.0, 0.5, 1.2, -0.9, 2.0])):
+        for cv, lk, lp in ((None, 0, 0.0), (cov, 1, 50.0)):
+            for c in (jit, builtin):
+                c.set_covariance(cv)
+                c.set_loss(lk, lp)
+            for jac_mode in (0, 2):
+                want = oracle_ref(oracle, src, tgt, x, jac_mode, cov=cv, loss_kind=lk, loss_param=lp)
+                tol = fd_tolerance(x) if jac_mode == 2 else REL
+                got = jit.linearize(x, jac_mode)
+                check(got, want, tol=tol)
+                check(got, builtin.linearize(x, jac_mode), tol=tol)
+            w = oracle.p2p_cost(src, tgt, x)
+            assert abs(jit.compute_cost(x) - w) <= REL * w
+    with pytest.raises(hip_lib.MoptError):   # aux values without a setup body
+        hip_lib.JitModelCost(6, 3, P2P_JIT_RESIDUAL, planes=planes, n_aux=12)
+
+
 def test_set_data_replaces_correspondences(hip_lib, oracle):
     """mopt_point2point_set_data: new correspondences (smaller, equal and larger count) in an
     existing cost; the kept linearization must not leak across the change."""
