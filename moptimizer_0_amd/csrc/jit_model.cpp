@@ -77,14 +77,23 @@ extern "C" __global__ __launch_bounds__(kBlock) void mopt_jit_sweep(const JitArg
   double acc[NACC];
 #pragma unroll
   for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
-  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < A.count;
-       i += (long long)gridDim.x * kBlock) {
+  const long long step = (long long)gridDim.x * kBlock;
+  long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+  S d[D > 0 ? D : 1], d_next[D > 0 ? D : 1];
+  if (i < A.count) {
+#pragma unroll
+    for (int p = 0; p < D; ++p) d_next[p] = A.data[p * A.stride + i];
+  }
+  for (; i < A.count; i += step) {
+#pragma unroll
+    for (int p = 0; p < D; ++p) d[p] = d_next[p];
+    // the next element's data are requested before this one's arithmetic starts
+    const long long ahead = i + step < A.count ? i + step : i;
+#pragma unroll
+    for (int p = 0; p < D; ++p) d_next[p] = A.data[p * A.stride + ahead];
     // the per-x values stay in LDS: without this the compiler keeps all (N + 1) * AUX of them in
     // registers across the loop
     asm volatile("" ::: "memory");
-    S d[D > 0 ? D : 1];
-#pragma unroll
-    for (int p = 0; p < D; ++p) d[p] = A.data[p * A.stride + i];
     S r[M];
     user_residual(A.x, aux, d, r);
     S rr = 0;
