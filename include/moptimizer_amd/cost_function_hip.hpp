@@ -67,6 +67,11 @@ class DeviceModel : public IBaseModel<Scalar> {
   }
   // creates the mopt_cost for this model on `device`
   virtual mopt_cost *createDeviceCost(int device, int num_residuals) const = 0;
+  // creates the sharded form over several devices of this node; models whose data
+  // do not shard by index range keep the default
+  virtual mopt_group *createDeviceGroup(const std::vector<int> &, int) const {
+    throw Exception("this device model has no multi-device form");
+  }
   virtual int numOutputs() const = 0;
   virtual int numParameters() const { return 6; }
   // The cost hands its device handle to the model so that model->update(x) can act on it.
@@ -92,6 +97,15 @@ class Point2PointDeviceModel : public DeviceModel<Scalar> {
                                          num_residuals, MOPT_INPUT_HOST),
                  "mopt_point2point_create");
     return h;
+  }
+  mopt_group *createDeviceGroup(const std::vector<int> &devices, int num_residuals) const override {
+    if (num_residuals < 0 || std::size_t(num_residuals) > count_)
+      throw Exception("Point2PointDeviceModel: num_residuals exceeds the cloud size");
+    mopt_group *g = nullptr;
+    throwOnError(mopt_group_point2point_create(&g, devices.data(), int(devices.size()),
+                                               int(sizeof(Scalar)), src_, tgt_, num_residuals),
+                 "mopt_group_point2point_create");
+    return g;
   }
   int numOutputs() const override { return 3; }
 
@@ -299,47 +313,74 @@ class CostFunctionHip : public CostFunctionBase<Scalar> {
     this->covariance_->resize(num_outputs_, num_outputs_);
     this->covariance_->setIdentity();
   }
+  // The same cost sharded over several GPUs of the node (contiguous index ranges, one RCCL
+  // all-reduce of n*n + n + 1 doubles per sweep); the single-process LM loop sees one cost.
+  CostFunctionHip(ModelPtr model, int num_parameters, int num_outputs, int num_residuals,
+                  const std::vector<int> &devices)
+      : Base(model, num_residuals), num_parameters_(num_parameters), num_outputs_(num_outputs) {
+    auto *dm = dynamic_cast<DeviceModel<Scalar> *>(model.get());
+    if (!dm) throw Exception("CostFunctionHip needs a device model");
+    if (num_parameters != dm->numParameters() || num_outputs != dm->numOutputs())
+      throw Exception("CostFunctionHip: (num_parameters, num_outputs) do not match the device model");
+    if (devices.empty()) throw Exception("CostFunctionHip: empty device list");
+    group_ = dm->createDeviceGroup(devices, num_residuals);
+    this->covariance_->resize(num_outputs_, num_outputs_);
+    this->covariance_->setIdentity();
+  }
   ~CostFunctionHip() override {
     if (handle_) mopt_cost_destroy(handle_);
+    if (group_) mopt_group_destroy(group_);
   }
 
   Scalar computeCost(const Scalar *x) override {
     Scalar sum = 0;
-    throwOnError(mopt_cost_compute(handle_, x, &sum), "mopt_cost_compute");
+    if (group_)
+      throwOnError(mopt_group_compute(group_, x, &sum), "mopt_group_compute");
+    else
+      throwOnError(mopt_cost_compute(handle_, x, &sum), "mopt_cost_compute");
     return sum;
   }
 
   Scalar linearize(const Scalar *x, Scalar *hessian, Scalar *b) override {
     pushState();
     Scalar sum = 0;
-    throwOnError(mopt_cost_linearize(handle_, JacobianMode, x, hessian, b, &sum),
-                 "mopt_cost_linearize");
+    if (group_)
+      throwOnError(mopt_group_linearize(group_, JacobianMode, x, hessian, b, &sum),
+                   "mopt_group_linearize");
+    else
+      throwOnError(mopt_cost_linearize(handle_, JacobianMode, x, hessian, b, &sum),
+                   "mopt_cost_linearize");
     return sum;
   }
 
   mopt_cost *handle() const { return handle_; }
+  mopt_group *group() const { return group_; }
 
  protected:
   // setLossFunction / setCovariance are non-virtual setters on the base (cost_function.h:37-40),
   // so the current loss and covariance are forwarded at the start of every sweep.
   void pushState() {
-    throwOnError(mopt_cost_set_covariance(handle_, this->covariance_->data()),
-                 "mopt_cost_set_covariance");
+    throwOnError(group_ ? mopt_group_set_covariance(group_, this->covariance_->data())
+                        : mopt_cost_set_covariance(handle_, this->covariance_->data()),
+                 "set_covariance");
     auto *gm = dynamic_cast<loss::GemmanMCClure<Scalar> *>(this->loss_function_.get());
+    int kind = MOPT_LOSS_NONE;
+    double parameter = 0.0;
     if (gm) {
-      throwOnError(
-          mopt_cost_set_loss(handle_, MOPT_LOSS_GEMAN_MCCLURE, gemanMcClureThreshold(gm, 0)),
-          "mopt_cost_set_loss");
-    } else if (dynamic_cast<loss::NoLoss<Scalar> *>(this->loss_function_.get())) {
-      throwOnError(mopt_cost_set_loss(handle_, MOPT_LOSS_NONE, 0.0), "mopt_cost_set_loss");
-    } else {
+      kind = MOPT_LOSS_GEMAN_MCCLURE;
+      parameter = gemanMcClureThreshold(gm, 0);
+    } else if (!dynamic_cast<loss::NoLoss<Scalar> *>(this->loss_function_.get())) {
       throw Exception("CostFunctionHip: only NoLoss and GemmanMCClure have device kernels");
     }
+    throwOnError(group_ ? mopt_group_set_loss(group_, kind, parameter)
+                        : mopt_cost_set_loss(handle_, kind, parameter),
+                 "set_loss");
   }
 
   int num_parameters_;
   int num_outputs_;
   mopt_cost *handle_ = nullptr;
+  mopt_group *group_ = nullptr;
 };
 
 // Drop-in for CostFunctionAnalyticalDynamic: model-supplied, API-conformant row-major Jacobian.
@@ -369,6 +410,9 @@ class CostFunctionAnalytical : public CostFunctionHip<Scalar, MOPT_JAC_ANALYTIC>
   CostFunctionAnalytical(ModelPtr model, int num_residuals, int device = 0)
       : CostFunctionHip<Scalar, MOPT_JAC_ANALYTIC>(model, model_parameter_dim, model_output_dim,
                                                    num_residuals, device) {}
+  CostFunctionAnalytical(ModelPtr model, int num_residuals, const std::vector<int> &devices)
+      : CostFunctionHip<Scalar, MOPT_JAC_ANALYTIC>(model, model_parameter_dim, model_output_dim,
+                                                   num_residuals, devices) {}
 };
 
 template <class Scalar = double, int model_parameter_dim = 1, int model_output_dim = 1>
@@ -378,6 +422,9 @@ class CostFunctionNumerical : public CostFunctionHip<Scalar, MOPT_JAC_NUMERIC> {
   CostFunctionNumerical(ModelPtr model, int num_residuals, int device = 0)
       : CostFunctionHip<Scalar, MOPT_JAC_NUMERIC>(model, model_parameter_dim, model_output_dim,
                                                   num_residuals, device) {}
+  CostFunctionNumerical(ModelPtr model, int num_residuals, const std::vector<int> &devices)
+      : CostFunctionHip<Scalar, MOPT_JAC_NUMERIC>(model, model_parameter_dim, model_output_dim,
+                                                  num_residuals, devices) {}
 };
 
 }  // namespace hip

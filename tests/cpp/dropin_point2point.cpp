@@ -187,6 +187,33 @@ int main(int argc, char **argv) {
       expectTrue(std::fabs(sa - sc) <= 1e-7 * sa, "sum analytic == sum numeric (1e-7 rel)", sa, sc);
     }
 
+    // ---- the cost sharded over a device list (here the one GPU three times: shards combined by
+    // the group's host path; on a multi-GPU node the same constructor runs one RCCL all-reduce) --
+    {
+      const std::vector<int> devices = {0, 0, 0};
+      mh::CostFunctionNumericalDynamic<Scalar> sharded(gpu_model, 6, 3, n, devices);
+      mh::CostFunctionNumericalDynamic<Scalar> single(gpu_model, 6, 3, n);
+      sharded.setLossFunction(std::make_shared<moptimizer::loss::GemmanMCClure<Scalar>>(1000.0));
+      single.setLossFunction(std::make_shared<moptimizer::loss::GemmanMCClure<Scalar>>(1000.0));
+      Scalar Hs[36], H1[36], bs[6], b1[6];
+      double x1[6] = {0.5, -0.3, 0.2, 0.1, -0.2, 0.3};
+      const Scalar ss = sharded.linearize(x1, Hs, bs), s1 = single.linearize(x1, H1, b1);
+      expectTrue(std::fabs(ss - s1) <= 1e-12 * s1, "sharded cost sum == single-device sum", ss, s1);
+      expectTrue(relErr(Hs, H1, 36) <= 1e-12, "sharded H == single-device H", relErr(Hs, H1, 36), 1e-12);
+      expectTrue(relErr(bs, b1, 6) <= 1e-12, "sharded b == single-device b", relErr(bs, b1, 6), 1e-12);
+      expectTrue(std::fabs(sharded.computeCost(x1) - single.computeCost(x1)) <= 1e-12 * s1,
+                 "sharded computeCost == single-device", sharded.computeCost(x1), single.computeCost(x1));
+      moptimizer::LevenbergMarquadtDynamic<Scalar> lm(6);
+      lm.setMaximumIterations(50);
+      mh::CostFunctionNumerical<Scalar, 6, 3> sharded_static(gpu_model, n, devices);
+      lm.addCost(&sharded_static);
+      double xs[6] = {0};
+      lm.minimize(xs);
+      double e = 0;
+      for (int i = 0; i < 6; ++i) e = std::max(e, std::fabs(xs[i] - truth[i]));
+      expectTrue(e < 1e-6, "LM over the sharded cost reaches the fixture pose", e, 1e-6);
+    }
+
     // ---- ICP: correspondences unknown, re-searched by model->update(x) inside the LM loop ----
     {
       // target = the cloud moved by a small pose, in reversed order (index alignment destroyed)
