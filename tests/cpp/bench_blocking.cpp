@@ -39,7 +39,7 @@ int main(int argc, char **argv) {
                 std::chrono::duration<double, std::milli>(Clock::now() - t0).count());
     mopt_cost_set_speculation(cost.handle(), 0);  // time real sweeps
     double x[6] = {0.5, -0.3, 0.2, 0.1, -0.2, 0.3}, H[36], b[6];
-    for (int warm = 0; warm < 600; ++warm) cost.linearize(x, H, b);  // past the runtime's one-time stall
+    for (int warm = 0; warm < 50; ++warm) cost.linearize(x, H, b);  // code objects loaded, clocks up
     const int reps = 300;
     t0 = Clock::now();
     for (int k = 0; k < reps; ++k) {
