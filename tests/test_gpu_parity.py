@@ -823,6 +823,85 @@ def test_parallel_cost_test_of_the_reference(hip_lib, oracle):
     assert abs(moved.compute_cost(x) - 14.0e6) <= 1e-12 * 14.0e6
 
 
+def test_jit_accelerometer_model_of_the_reference(hip_lib):
+    """include/moptimizer/models/accelerometer.h — the one model the reference library itself ships —
+    written for the GPU: setup(x) = Exp(x) (3 parameters), residual = measurement - R g with
+    g = (0, 0, 9.81) (accelerometer.h:17-32), here over a batch of measurements instead of one.
+    Forward differences against a numpy statement of linearization.h:65-124; the supplied Jacobian
+    is the exact skew(R g) J_l(x) (the header's own f_df is an experiment whose test only prints,
+    tst/differentiation.cpp:163-188) and must agree with the forward differences; LM recovers the
+    orientation that generated the measurements."""
+    rng = np.random.default_rng(33)
+
+    def exp_so3(w):
+        th = np.linalg.norm(w)
+        if th <= 10 * EPS:
+            return np.eye(3)
+        k = w / th
+        K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
+
+    g = np.array([0.0, 0.0, 9.81])
+    x_true = np.array([0.3, -0.2, 0.1])
+    count = 4001
+    meas = (exp_so3(x_true) @ g)[None, :] + rng.normal(0, 0.05, (count, 3))
+    planes = np.ascontiguousarray(meas.T)
+
+    def residual(x, d):
+        return d.T - (exp_so3(x) @ g)[None, :]
+
+    setup = """
+        const S th = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+        S R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        if (th > 10 * S(2.220446049250313e-16)) {
+          const S kx = x[0] / th, ky = x[1] / th, kz = x[2] / th, sn = sin(th), cs = 1 - cos(th);
+          const S K[9] = {0, -kz, ky, kz, 0, -kx, -ky, kx, 0};
+          for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+              S kk = 0;
+              for (int k = 0; k < 3; ++k) kk += K[i * 3 + k] * K[k * 3 + j];
+              R[i * 3 + j] += sn * K[i * 3 + j] + cs * kk;
+            }
+        }
+        a[0] = R[2] * S(9.81); a[1] = R[5] * S(9.81); a[2] = R[8] * S(9.81);    // R g
+        // left Jacobian of SO(3): I + (1 - cos)/th^2 [x]x + (th - sin)/th^3 [x]x^2
+        S Jl[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        if (th > S(1e-6)) {
+          const S X[9] = {0, -x[2], x[1], x[2], 0, -x[0], -x[1], x[0], 0};
+          const S c1 = (1 - cos(th)) / (th * th), c2 = (th - sin(th)) / (th * th * th);
+          for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+              S xx = 0;
+              for (int k = 0; k < 3; ++k) xx += X[i * 3 + k] * X[k * 3 + j];
+              Jl[i * 3 + j] += c1 * X[i * 3 + j] + c2 * xx;
+            }
+        }
+        const S G[9] = {0, -a[2], a[1], a[2], 0, -a[0], -a[1], a[0], 0};           // skew(R g)
+        for (int i = 0; i < 3; ++i)
+          for (int j = 0; j < 3; ++j) {
+            S v = 0;
+            for (int k = 0; k < 3; ++k) v += G[i * 3 + k] * Jl[k * 3 + j];
+            a[3 + i * 3 + j] = v;                                                 // d r / d x, row-major
+          }
+    """
+    c = hip_lib.JitModelCost(3, 3, "for (int i = 0; i < 3; ++i) r[i] = d[i] - a[i];",
+                             "for (int k = 0; k < 9; ++k) J[k] = a[3 + k];", planes=planes, n_aux=12,
+                             setup_body=setup)
+    for x in (np.array([0.1, 0.0, 0.0]), np.array([0.25, -0.15, 0.4]), x_true):
+        want = numpy_linearize(residual, planes, x)
+        check(c.linearize(x, 2), want, tol=fd_tolerance(x))
+        Ha, ba, sa = c.linearize(x, 0)
+        assert rel_err(Ha, want[0]) < 1e-5 and rel_err(ba, want[1]) < 1e-5 and abs(sa - want[2]) <= REL * want[2]
+    # Gauss-Newton on the GPU cost recovers the generating orientation about the two axes gravity
+    # observes; the rotation about g itself is unobservable (H is rank 2 there), so compare R g
+    x = np.array([0.05, 0.05, 0.0])
+    for _ in range(15):
+        H, b, _ = c.linearize(x, 0)
+        x = x - np.linalg.lstsq(H, b, rcond=1e-10)[0]
+    mean = meas.mean(0)   # R g lives on the sphere of radius 9.81: the minimiser is the mean's direction
+    assert np.abs(exp_so3(x) @ g - 9.81 * mean / np.linalg.norm(mean)).max() < 1e-6
+
+
 def test_randomized_configurations_against_oracle(hip_lib, oracle):
     """Seeded sweep over the configuration space of the path: size (incl. exact tile multiples and
     one past), pose (zero components, rotations up to ~3 rad, sub-epsilon rotation), Jacobian
