@@ -275,9 +275,9 @@ def main():
         torch.cuda.synchronize()
 
     # Untimed settling before the W warm-up steps: a GPU that has just been handed its data is not
-    # yet in its steady state (measured at 10 M: 84 us per step and 76 us per sweep after 20
-    # steps, 82 / 73-74 us after 500), and the metric is the steady-state rate of an LM loop that
-    # runs thousands of sweeps.  The count is the same on every rank (each step holds a collective).
+    # yet in its steady state (measured at 10 M, same box: 87.0 us per step timed after 70 steps,
+    # 85.8 after 150 ms of sweeps, 84.9 after 1 s), and the metric is the steady-state rate of an LM
+    # loop that runs thousands of sweeps.  The count is the same on every rank (each step holds a collective).
     per_rank = args.total_n // world if args.total_n else args.n
     est_step_s = 20e-6 + per_rank * BYTES_PER_CORRESPONDENCE[scalar_bytes] / 6.0e12
     for k in range(min(5000, max(50, int(args.settle_ms * 1e-3 / est_step_s)))):
