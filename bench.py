@@ -57,7 +57,7 @@ def parse_args():
                     help="bracket every N-th sweep launch of the timed region with HIP events "
                          "(a recorded pair costs the host ~5 us; 1 = every launch; 0 = choose so "
                          "that about 25 launches are timed, at most every 8th)")
-    ap.add_argument("--settle-ms", type=float, default=150.0,
+    ap.add_argument("--settle-ms", type=float, default=500.0,
                     help="untimed sweeps before the warm-up steps, about this many milliseconds")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
@@ -280,7 +280,7 @@ def main():
     # loop that runs thousands of sweeps.  The count is the same on every rank (each step holds a collective).
     per_rank = args.total_n // world if args.total_n else args.n
     est_step_s = 20e-6 + per_rank * BYTES_PER_CORRESPONDENCE[scalar_bytes] / 6.0e12
-    for k in range(min(5000, max(50, int(args.settle_ms * 1e-3 / est_step_s)))):
+    for k in range(min(20000, max(50, int(args.settle_ms * 1e-3 / est_step_s)))):
         step(k)
     for k in range(args.warmup):
         step(k)
