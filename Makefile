@@ -23,8 +23,9 @@ all: $(LIB)
 $(OBJDIR) $(LIBDIR):
 	mkdir -p $@
 
+# leading scalar kernel arguments preloaded into SGPRs at wave launch (gfx940+)
 $(OBJDIR)/sweep_kernels.o: $(CSRC)/sweep_kernels.hip $(PUBLIC_HEADERS) | $(OBJDIR)
-	$(HIPCC) $(HIPFLAGS) $(INCLUDES) -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) $(INCLUDES) -mllvm -amdgpu-kernarg-preload-count=4 -c $< -o $@
 
 $(OBJDIR)/%.o: $(CSRC)/%.cpp $(PUBLIC_HEADERS) | $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) $(INCLUDES) -x hip -c $< -o $@

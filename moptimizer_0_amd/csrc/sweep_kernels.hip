@@ -297,8 +297,12 @@ __global__ __launch_bounds__(kBlockThreads) void p2pLinearizeLiteralKernel(
 //   sum_i w_i J_i^T S J_i  and  sum_i w_i J_i^T S r_i
 // are linear in the 22 moments  sum w, sum w p, sum w p p^T, sum w r, sum w p r^T.  The sweep
 // accumulates those (plus sum r^T r); finalizeMomentsKernel contracts them with the basis.
+// `tiles` / `num_tiles` repeat the first members of A as leading scalar arguments: gfx950 can
+// preload those into SGPRs at wave launch (-amdgpu-kernarg-preload-count), so the first tile's
+// loads go out without waiting for a kernel-argument fetch.
 template <typename S, bool STREAMING>
-__global__ __launch_bounds__(kBlockThreads) void p2pMomentsKernel(const P2PSweepArgs<S> A) {
+__global__ __launch_bounds__(kBlockThreads) void p2pMomentsKernel(const S *tiles, int num_tiles,
+                                                                  const P2PSweepArgs<S> A) {
   constexpr int V = TileShape<S>::kVec;
   double acc[kAccMoments];
 #pragma unroll
@@ -309,7 +313,7 @@ __global__ __launch_bounds__(kBlockThreads) void p2pMomentsKernel(const P2PSweep
   // then promoted once — 23 conversions + fp64 adds per tile instead of 92, which otherwise makes
   // the fp32 sweep VALU-bound.
   using Local = typename std::conditional<sizeof(S) == 8, double, S>::type;
-  sweepTiles<S, STREAMING>(A.tiles, A.num_tiles, [&](const Pack<S>(&cur)[6], long long first) {
+  sweepTiles<S, STREAMING>(tiles, num_tiles, [&](const Pack<S>(&cur)[6], long long first) {
     Local loc[kAccMoments];
     if constexpr (sizeof(S) == 4) {
 #pragma unroll
@@ -364,10 +368,11 @@ __global__ __launch_bounds__(kBlockThreads) void p2pMomentsKernel(const P2PSweep
 
 // ---- point-to-point, cost only (linearization.h:36-63) ----------------------------------------
 template <typename S, bool STREAMING>
-__global__ __launch_bounds__(kBlockThreads) void p2pCostKernel(const P2PSweepArgs<S> A) {
+__global__ __launch_bounds__(kBlockThreads) void p2pCostKernel(const S *tiles, int num_tiles,
+                                                               const P2PSweepArgs<S> A) {
   constexpr int V = TileShape<S>::kVec;
   double acc[1] = {0.0};
-  sweepTiles<S, STREAMING>(A.tiles, A.num_tiles, [&](const Pack<S>(&cur)[6], long long first) {
+  sweepTiles<S, STREAMING>(tiles, num_tiles, [&](const Pack<S>(&cur)[6], long long first) {
 #pragma unroll
     for (int e = 0; e < V; ++e) {
       const S p[3] = {cur[0].v[e], cur[1].v[e], cur[2].v[e]};
@@ -927,8 +932,13 @@ template hipError_t launchP2PLinearizeLiteral<double>(const P2PSweepArgs<double>
 
 template <typename S>
 hipError_t launchP2PMoments(const P2PSweepArgs<S> &args, int grid, const LaunchSite &site) {
-  return site.streaming ? launchSweep(p2pMomentsKernel<S, true>, grid, site, args)
-                        : launchSweep(p2pMomentsKernel<S, false>, grid, site, args);
+  if (site.streaming)
+    hipLaunchKernelGGL((p2pMomentsKernel<S, true>), dim3(grid), dim3(kBlockThreads), 0, site.stream,
+                       args.tiles, args.num_tiles, args);
+  else
+    hipLaunchKernelGGL((p2pMomentsKernel<S, false>), dim3(grid), dim3(kBlockThreads), 0, site.stream,
+                       args.tiles, args.num_tiles, args);
+  return hipGetLastError();
 }
 template hipError_t launchP2PMoments<float>(const P2PSweepArgs<float> &, int, const LaunchSite &);
 template hipError_t launchP2PMoments<double>(const P2PSweepArgs<double> &, int,
@@ -936,8 +946,13 @@ template hipError_t launchP2PMoments<double>(const P2PSweepArgs<double> &, int,
 
 template <typename S>
 hipError_t launchP2PCost(const P2PSweepArgs<S> &args, int grid, const LaunchSite &site) {
-  return site.streaming ? launchSweep(p2pCostKernel<S, true>, grid, site, args)
-                        : launchSweep(p2pCostKernel<S, false>, grid, site, args);
+  if (site.streaming)
+    hipLaunchKernelGGL((p2pCostKernel<S, true>), dim3(grid), dim3(kBlockThreads), 0, site.stream,
+                       args.tiles, args.num_tiles, args);
+  else
+    hipLaunchKernelGGL((p2pCostKernel<S, false>), dim3(grid), dim3(kBlockThreads), 0, site.stream,
+                       args.tiles, args.num_tiles, args);
+  return hipGetLastError();
 }
 template hipError_t launchP2PCost<float>(const P2PSweepArgs<float> &, int, const LaunchSite &);
 template hipError_t launchP2PCost<double>(const P2PSweepArgs<double> &, int, const LaunchSite &);
