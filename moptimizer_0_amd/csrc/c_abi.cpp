@@ -54,15 +54,17 @@ int resolvePendingEvents(mopt_cost *c) {
   return MOPT_OK;
 }
 
-// Brackets the dominant kernel of a sweep with a pair of HIP events recorded on the launch stream
-// when profiling is on.  (Timestamping the dispatch itself through hipExtLaunchKernelGGL agrees
-// with rocprofv3 to 0.2 us but costs the host 10 us per call; the recorded pair reads ~1 us
-// longer than the kernel and costs 6 us.)
+// Times the dominant kernel of a sweep with a pair of HIP events on the launch stream when
+// profiling samples this launch.  The moments / cost sweeps have their dispatch timestamped into
+// the events (hipExtLaunchKernelGGL: agrees with rocprofv3's kernel trace to 0.2 us, costs the
+// host ~10 us, which is why launches are sampled); the other sweeps get a recorded pair around
+// the launch (reads 1-3 us longer than the kernel, costs ~6 us).
 struct SweepTimer {
   mopt_cost *c;
   mopt::LaunchSite site;
   hipEvent_t start = nullptr, stop_ev = nullptr;
-  SweepTimer(mopt_cost *cost, hipStream_t stream) : c(cost) {
+  bool dispatch_stamped = false;
+  SweepTimer(mopt_cost *cost, hipStream_t stream, bool stamp_dispatch = false) : c(cost) {
     site.stream = stream;
     // Streaming (non-temporal) loads once the tiles exceed the 32 MiB of aggregate L2: measured
     // faster both beyond the 256 MiB Infinity Cache (10 M points: 82 -> 77 us) and inside it
@@ -81,13 +83,19 @@ struct SweepTimer {
         e = nullptr;
       }
     }
-    if (ev[0] && ev[1] && hipEventRecord(ev[0], stream) == hipSuccess) {
+    if (!ev[0] || !ev[1]) return;
+    if (stamp_dispatch) {
+      start = site.time_start = ev[0];
+      stop_ev = site.time_stop = ev[1];
+      dispatch_stamped = true;
+    } else if (hipEventRecord(ev[0], stream) == hipSuccess) {
       start = ev[0];
       stop_ev = ev[1];
     }
   }
   void stop() {
-    if (start && stop_ev && hipEventRecord(stop_ev, site.stream) == hipSuccess)
+    if (!start || !stop_ev) return;
+    if (dispatch_stamped || hipEventRecord(stop_ev, site.stream) == hipSuccess)
       c->pending_events.emplace_back(start, stop_ev);
   }
 };
@@ -202,7 +210,7 @@ int p2pLinearizeAsync(mopt_cost *c, int jac_mode, const S *x, double *d_result, 
     mopt::AffineBasis basis;
     fillBasis<S>(c, jac_mode, args, basis);
     const int grid = gridFor(c, envInt("MOPT_BLOCKS_PER_CU", 1));
-    SweepTimer timer(c, s);
+    SweepTimer timer(c, s, true);
     MOPT_HIP_TRY(mopt::launchP2PMoments<S>(args, grid, timer.site));
     timer.stop();
     MOPT_HIP_TRY(mopt::launchFinalizeMoments(c->d_partials, grid, basis, d_result, pub, s));
@@ -224,7 +232,7 @@ int p2pCostAsync(mopt_cost *c, const S *x, double *d_sum, hipStream_t s,
   mopt::P2PSweepArgs<S> args;
   fillP2PArgs<S>(c, x, false, args);
   const int grid = gridFor(c, envInt("MOPT_BLOCKS_PER_CU", 1));
-  SweepTimer timer(c, s);
+  SweepTimer timer(c, s, true);
   MOPT_HIP_TRY(mopt::launchP2PCost<S>(args, grid, timer.site));
   timer.stop();
   MOPT_HIP_TRY(mopt::launchFinalizeCost(c->d_partials, grid, d_sum, pub, s));

@@ -112,6 +112,9 @@ struct IcpMatchArgs {
 struct LaunchSite {
   hipStream_t stream = nullptr;
   bool streaming = false;  // non-temporal loads: data set larger than the Infinity Cache
+  // when set, the sweep kernel's own dispatch is timestamped into these events (hipExtLaunch):
+  // exactly the kernel's duration, as a kernel trace reports it
+  hipEvent_t time_start = nullptr, time_stop = nullptr;
 };
 
 // Optional hand-over of a finalize kernel's 43 (or 1) results straight into mapped host memory:

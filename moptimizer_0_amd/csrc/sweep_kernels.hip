@@ -20,6 +20,8 @@
 //     H (column-major) | b | sum_sq; no atomics anywhere.
 #include "sweep.hpp"
 
+#include <hip/hip_ext.h>
+
 #include <type_traits>
 
 namespace mopt {
@@ -897,6 +899,18 @@ hipError_t launchSweep(Kernel kernel, int grid, const LaunchSite &site, const Ar
   return hipGetLastError();
 }
 
+// moments / cost sweeps: (tiles, num_tiles, args) signature; optionally timestamped dispatch
+template <typename Kernel, typename S>
+hipError_t launchTiled(Kernel kernel, int grid, const LaunchSite &site, const P2PSweepArgs<S> &args) {
+  if (site.time_start && site.time_stop)
+    hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(kBlockThreads), 0, site.stream, site.time_start,
+                          site.time_stop, 0, args.tiles, args.num_tiles, args);
+  else
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlockThreads), 0, site.stream, args.tiles,
+                       args.num_tiles, args);
+  return hipGetLastError();
+}
+
 template <typename S, int JAC>
 hipError_t launchLiteralCov(const P2PSweepArgs<S> &args, int cov_mode, int grid,
                             const LaunchSite &site) {
@@ -932,13 +946,8 @@ template hipError_t launchP2PLinearizeLiteral<double>(const P2PSweepArgs<double>
 
 template <typename S>
 hipError_t launchP2PMoments(const P2PSweepArgs<S> &args, int grid, const LaunchSite &site) {
-  if (site.streaming)
-    hipLaunchKernelGGL((p2pMomentsKernel<S, true>), dim3(grid), dim3(kBlockThreads), 0, site.stream,
-                       args.tiles, args.num_tiles, args);
-  else
-    hipLaunchKernelGGL((p2pMomentsKernel<S, false>), dim3(grid), dim3(kBlockThreads), 0, site.stream,
-                       args.tiles, args.num_tiles, args);
-  return hipGetLastError();
+  return site.streaming ? launchTiled(p2pMomentsKernel<S, true>, grid, site, args)
+                        : launchTiled(p2pMomentsKernel<S, false>, grid, site, args);
 }
 template hipError_t launchP2PMoments<float>(const P2PSweepArgs<float> &, int, const LaunchSite &);
 template hipError_t launchP2PMoments<double>(const P2PSweepArgs<double> &, int,
@@ -946,13 +955,8 @@ template hipError_t launchP2PMoments<double>(const P2PSweepArgs<double> &, int,
 
 template <typename S>
 hipError_t launchP2PCost(const P2PSweepArgs<S> &args, int grid, const LaunchSite &site) {
-  if (site.streaming)
-    hipLaunchKernelGGL((p2pCostKernel<S, true>), dim3(grid), dim3(kBlockThreads), 0, site.stream,
-                       args.tiles, args.num_tiles, args);
-  else
-    hipLaunchKernelGGL((p2pCostKernel<S, false>), dim3(grid), dim3(kBlockThreads), 0, site.stream,
-                       args.tiles, args.num_tiles, args);
-  return hipGetLastError();
+  return site.streaming ? launchTiled(p2pCostKernel<S, true>, grid, site, args)
+                        : launchTiled(p2pCostKernel<S, false>, grid, site, args);
 }
 template hipError_t launchP2PCost<float>(const P2PSweepArgs<float> &, int, const LaunchSite &);
 template hipError_t launchP2PCost<double>(const P2PSweepArgs<double> &, int, const LaunchSite &);
