@@ -14,6 +14,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def built_tree():
+    """The tests exercise built artefacts (the HIP library, the oracle, the C++ programs), which are
+    kept out of the git history: build whatever is missing once per session, as
+    __graft_entry__.build() does.  hipcc cross-compiles for gfx950 without a GPU."""
+    lib = os.path.join(ROOT, "moptimizer_0_amd", "lib", "libmoptimizer_hip.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-C", ROOT, "-j4", "all"], stdout=subprocess.DEVNULL)
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_build", "liboracle.so")):
+        subprocess.check_call(["make", "-C", ROOT, "oracle"], stdout=subprocess.DEVNULL)
+    if not os.path.exists(os.path.join(ROOT, "tests", "cpp", "_build", "dropin_models")):
+        subprocess.check_call(["make", "-C", ROOT, "cpptests"], stdout=subprocess.DEVNULL)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from tests import oracle_binding
