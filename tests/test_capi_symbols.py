@@ -34,6 +34,19 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), "libmoptimizer_hip.so does not export %s" % name
 
 
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: the header compiles as C99 with pedantic warnings as errors, and
+    as C++17."""
+    import subprocess
+    src = tmp_path / "use.c"
+    src.write_text('#include "moptimizer_hip.h"\nint main(void) { return mopt_version() != 0 ? 0 : 1; }\n')
+    inc = os.path.join(ds.ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc,
+                           "-fsyntax-only", str(src)])
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", inc, "-x", "c++",
+                           "-fsyntax-only", str(src)])
+
+
 def test_every_cited_reference_interface_is_in_the_header():
     text = open(HEADER).read()
     for cite in ("include/moptimizer/cost_function.h:50", "include/moptimizer/cost_function.h:49",
