@@ -4,6 +4,8 @@ Bar (BASELINE.json north_star): J^T J and J^T r within 1e-6 relative, norm-wise
 (max|dH| / max|H|), same for the cost; fp32 instantiations are judged against the fp64 oracle
 with the looser bound written at the test.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -53,6 +55,33 @@ def check(got, want, tol=REL):
 @pytest.fixture(scope="module")
 def cloud_1k():
     return ds.synthetic_pair(1000, seed=42, noise=0.01)
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_p2p_1k_matches_committed_golden_vectors(hip_lib, variant):
+    """The HIP path against tests/golden/p2p_1k_golden.npz alone (no oracle library in the loop):
+    24 point2point configurations (3 Jacobian modes x 2 poses x 2 losses x 2 covariances), the
+    reference's five camera correspondences, and the LM end point on the 1 k cloud."""
+    from tests.golden import make_p2p_golden as mk
+    g = np.load(os.path.join(ds.GOLDEN, "p2p_1k_golden.npz"))
+    src, tgt = ds.synthetic_pair(1000, seed=42, noise=0.01)
+    cost = hip_lib.Point2PointCost(src, tgt)
+    cost.set_kernel_variant(variant)
+    mode_of = {"analytic": 0, "analytic_tst": 1, "numeric": 2}
+    for m, xn, ln, cn in mk.cases():
+        lk, lp = mk.LOSSES[ln]
+        cost.set_loss(lk, lp)
+        cost.set_covariance(mk.COVS[cn])
+        key = "%s/%s/%s/%s" % (m, xn, ln, cn)
+        x = mk.XS[xn]
+        check(cost.linearize(x, mode_of[m]), (g[key + "/H"], g[key + "/b"], float(g[key + "/cost"])),
+              tol=fd_tolerance(x) if m == "numeric" else REL)
+    if variant == 2:
+        cam = hip_lib.ReprojectionCost(mk.CAMERA_PTS, mk.CAMERA_PIX)
+        for xn, xv in (("zero", np.zeros(6)), ("bad", np.array([0.5, 0.5, 0.5, 0.2, 0.5, 0.5]))):
+            H, b, s = cam.linearize(xv, 2)
+            check((H, b, s), (g["camera/%s/H" % xn], g["camera/%s/b" % xn], float(g["camera/%s/cost" % xn])),
+                  tol=fd_tolerance(xv))
 
 
 @pytest.mark.parametrize("jac_mode", [0, 1, 2])
