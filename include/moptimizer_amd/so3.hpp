@@ -14,8 +14,32 @@
 #include <cmath>
 #include <limits>
 
+// The rotation must come out bit-identical wherever this header is compiled (the library's host
+// code, a caller's own translation unit, the test oracle's independent matrix-form statement):
+// forward differences divide R(x + h e_j) - R(x) by h ~ 1e-8, so a 1-ulp difference made by one
+// compiler fusing a multiply-add that another does not would move a whole Jacobian column by
+// eps / h (measured: 16 % of the entries differed by an ulp between -O3 -march=x86-64-v3 and a
+// baseline build before this).  Every operation below is therefore rounded on its own.
+#if defined(__clang__)
+#define MOPT_SO3_EXACT
+#define MOPT_SO3_EXACT_BODY _Pragma("clang fp contract(off)")
+#elif defined(__GNUC__)
+#define MOPT_SO3_EXACT __attribute__((optimize("fp-contract=off")))
+#define MOPT_SO3_EXACT_BODY
+#else
+#define MOPT_SO3_EXACT
+#define MOPT_SO3_EXACT_BODY
+#endif
+
 namespace moptimizer {
 namespace so3 {
+
+// sin and cos of one angle through glibc's sincos: GCC turns the reference's
+// `std::sin(t) ... std::cos(t)` (src/so3.cpp:51-52) into that call, clang keeps two calls, and the
+// two libm entry points differ by an ulp for about one argument in two thousand — which forward
+// differences then amplify by 1 / h.  One explicit call makes every build agree.
+inline void sinCos(double t, double *s, double *c) { ::sincos(t, s, c); }
+inline void sinCos(float t, float *s, float *c) { ::sincosf(t, s, c); }
 
 // Row-major 3x4 [R | t]; what the kernels consume.
 template <typename Scalar>
@@ -26,12 +50,14 @@ struct Rigid3 {
 };
 
 template <typename Scalar>
-inline void expSO3(const Scalar *w, Scalar R[9] /* row-major */) {
+MOPT_SO3_EXACT inline void expSO3(const Scalar *w, Scalar R[9] /* row-major */) {
+  MOPT_SO3_EXACT_BODY
   const Scalar theta = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
   if (theta > Scalar(10) * std::numeric_limits<Scalar>::epsilon()) {
     const Scalar ax = w[0] / theta, ay = w[1] / theta, az = w[2] / theta;
-    const Scalar s = std::sin(theta);
-    const Scalar c1 = Scalar(1) - std::cos(theta);
+    Scalar s, c;
+    sinCos(theta, &s, &c);
+    const Scalar c1 = Scalar(1) - c;
     // K = [[0,-az,ay],[az,0,-ax],[-ay,ax,0]],  K^2 = a a^T - |a|^2 I (|a|^2 kept explicit so
     // that rounding in the normalisation is carried the same way a matrix product would).
     const Scalar xx = ax * ax, yy = ay * ay, zz = az * az;

@@ -97,6 +97,15 @@ enum mopt_kernel_variant {
 };
 
 MOPT_API int mopt_device_count(int *count);
+
+/* x = (tx, ty, tz, wx, wy, wz) -> 4x4 column-major [ Exp(w) t ; 0 1 ]: exactly the transform the
+ * sweeps of this library derive from x on the host, once per parameter vector, as the reference's
+ * model->setup(x) does (so3::convert6DOFParameterToMatrix + so3::Exp, src/so3.cpp:7-19,43-57).
+ * When T_plus_out / h_out are given, also the six forward-difference points of
+ * linearization.h:78-92: h_j = sqrt(eps) |x_j| (sqrt(eps) when zero), T_plus_out[16 j ..] the
+ * transform at x + h_j e_j.  Needs no device.  scalar_bytes 4 or 8 selects the type of all arrays. */
+MOPT_API int mopt_se3_from_params(int scalar_bytes, const void *x, void *T_out /* 16 */,
+                                  void *T_plus_out /* 6 * 16 or NULL */, void *h_out /* 6 or NULL */);
 MOPT_API const char *mopt_last_error(void);
 MOPT_API const char *mopt_version(void);
 

@@ -45,6 +45,8 @@ def load():
     c_void_pp = ctypes.POINTER(ctypes.c_void_p)
     sigs = {
         "mopt_device_count": [ctypes.POINTER(ctypes.c_int)],
+        "mopt_se3_from_params": [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                 ctypes.c_void_p],
         "mopt_point2point_create": [c_void_pp, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                     ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint],
         "mopt_point2point_set_data": [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
@@ -129,6 +131,21 @@ def device_count():
     n = ctypes.c_int(0)
     check(load().mopt_device_count(ctypes.byref(n)))
     return n.value
+
+
+def se3_from_params(x, with_steps=False, dtype=np.float64):
+    """The transform(s) the library derives from x on the host (no device needed): 4x4 matrix, and
+    with_steps also the six forward-difference transforms and steps."""
+    x = np.ascontiguousarray(x, dtype=dtype)
+    T = np.zeros(16, dtype=dtype)
+    if not with_steps:
+        check(load().mopt_se3_from_params(x.itemsize, _ptr(x), _ptr(T), None, None))
+        return T.reshape(4, 4, order="F")
+    Tp = np.zeros(96, dtype=dtype)
+    h = np.zeros(6, dtype=dtype)
+    check(load().mopt_se3_from_params(x.itemsize, _ptr(x), _ptr(T), _ptr(Tp), _ptr(h)))
+    return (T.reshape(4, 4, order="F"),
+            [Tp[16 * j:16 * j + 16].reshape(4, 4, order="F") for j in range(6)], h)
 
 
 def _dtype_of(scalar_bytes):

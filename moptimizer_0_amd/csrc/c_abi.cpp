@@ -120,6 +120,7 @@ void defaultReprojConstants(double K[12], double C[16]) {
 // or sqrt(eps) when that is zero; x_plus_j = x + h_j e_j.
 template <typename S>
 void forwardSteps(const S *x, S h[kNumParams], S x_plus[kNumParams][kNumParams]) {
+  MOPT_SO3_EXACT_BODY  // x + h is a rounded product added to x, never a fused multiply-add
   const S min_step = std::sqrt(std::numeric_limits<S>::epsilon());
   for (int j = 0; j < kNumParams; ++j) {
     h[j] = min_step * std::fabs(x[j]);
@@ -661,6 +662,20 @@ int stageInputs(const void *ha, size_t bytes_a, const void *hb, size_t bytes_b, 
 
 }  // namespace
 
+namespace {
+template <typename S>
+void se3FromParams(const S *x, S *T, S *T_plus, S *h_out) {
+  moptimizer::so3::convert6DOFParameterToMatrix<S>(x, T);
+  if (!T_plus && !h_out) return;
+  S h[kNumParams], xp[kNumParams][kNumParams];
+  forwardSteps<S>(x, h, xp);
+  for (int j = 0; j < kNumParams; ++j) {
+    if (h_out) h_out[j] = h[j];
+    if (T_plus) moptimizer::so3::convert6DOFParameterToMatrix<S>(xp[j], T_plus + 16 * j);
+  }
+}
+}  // namespace
+
 extern "C" {
 
 const char *mopt_last_error(void) { return g_last_error.c_str(); }
@@ -671,6 +686,20 @@ int mopt_device_count(int *count) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
   *count = n;
+  return MOPT_OK;
+}
+
+int mopt_se3_from_params(int scalar_bytes, const void *x, void *T_out, void *T_plus_out,
+                         void *h_out) {
+  if (!x || !T_out) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (scalar_bytes == 8)
+    se3FromParams<double>(static_cast<const double *>(x), static_cast<double *>(T_out),
+                          static_cast<double *>(T_plus_out), static_cast<double *>(h_out));
+  else if (scalar_bytes == 4)
+    se3FromParams<float>(static_cast<const float *>(x), static_cast<float *>(T_out),
+                         static_cast<float *>(T_plus_out), static_cast<float *>(h_out));
+  else
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "scalar_bytes must be 4 or 8");
   return MOPT_OK;
 }
 

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "moptimizer_amd/host_api.hpp"
+#include "so3_ref.hpp"
 
 namespace oracle {
 
@@ -94,9 +95,7 @@ class CostComputation {
     for (int j = 0; j < n_; ++j) {
       // :85 — unqualified abs(); with Eigen's headers in scope it resolves to the
       // floating-point overload on the reference's platform, hence fabs.
-      h[j] = min_step_size * std::fabs(x[j]);
-      if (h[j] == 0.0) h[j] = min_step_size;  // :87
-      x_plus[j][j] += h[j];                   // :89
+      forwardStep<Scalar>(x[j], min_step_size, &h[j], &x_plus[j][j]);  // :85-89 (so3_ref.hpp)
       models_plus[j] = model->clone();        // :91
       models_plus[j]->setup(x_plus[j].data());
     }

@@ -321,9 +321,7 @@ int oracle_se3_from_x(const double *x, double *T16, double *T16_plus /* 6*16 or 
     for (int j = 0; j < 6; ++j) {
       double xp[6];
       for (int k = 0; k < 6; ++k) xp[k] = x[k];
-      h[j] = min_step * std::fabs(x[j]);
-      if (h[j] == 0.0) h[j] = min_step;
-      xp[j] += h[j];
+      oracle::forwardStep<double>(x[j], min_step, &h[j], &xp[j]);
       oracle::so3::convert6DOFParameterToMatrix<double>(xp, T16_plus + 16 * j);
     }
   }

@@ -10,7 +10,34 @@
 #include <cmath>
 #include <limits>
 
+// Rounded operation by operation whatever the optimisation flags (the oracle library is built
+// -march=x86-64-v3, where GCC would otherwise fuse multiply-adds): forward differences amplify a
+// 1-ulp difference in R by 1 / h ~ 1e8, and tests/test_so3_bitwise.py requires this statement and
+// the product's closed form to agree bit for bit.
+#if defined(__clang__)
+#define ORACLE_SO3_EXACT
+#define ORACLE_SO3_EXACT_BODY _Pragma("clang fp contract(off)")
+#elif defined(__GNUC__)
+#define ORACLE_SO3_EXACT __attribute__((optimize("fp-contract=off")))
+#define ORACLE_SO3_EXACT_BODY
+#else
+#define ORACLE_SO3_EXACT
+#define ORACLE_SO3_EXACT_BODY
+#endif
+
 namespace oracle {
+
+// linearization.h:85-89 — the forward-difference step and the perturbed parameter, each operation
+// rounded on its own (x + h must not become fma(min_step, |x|, x)).
+template <typename Scalar>
+ORACLE_SO3_EXACT inline void forwardStep(Scalar xj, Scalar min_step, Scalar *h, Scalar *x_plus) {
+  ORACLE_SO3_EXACT_BODY
+  Scalar step = min_step * std::fabs(xj);  // :85
+  if (step == Scalar(0)) step = min_step;  // :87
+  *h = step;
+  *x_plus = xj + step;                     // :89
+}
+
 namespace so3 {
 
 // 3x3, indexable as M[r][c]
@@ -30,15 +57,21 @@ inline Mat3<Scalar> skew(const Scalar a[3]) {
 }
 
 template <typename Scalar>
-inline Mat3<Scalar> Exp(const Scalar delta[3]) {
+ORACLE_SO3_EXACT inline Mat3<Scalar> Exp(const Scalar delta[3]) {
+  ORACLE_SO3_EXACT_BODY
   Mat3<Scalar> R;
   const Scalar delta_norm =
       std::sqrt(delta[0] * delta[0] + delta[1] * delta[1] + delta[2] * delta[2]);
   if (delta_norm > Scalar(10.0) * std::numeric_limits<Scalar>::epsilon()) {  // :47
     const Scalar axis[3] = {delta[0] / delta_norm, delta[1] / delta_norm, delta[2] / delta_norm};
     const Mat3<Scalar> K = skew<Scalar>(axis);
-    const Scalar s = std::sin(delta_norm);
-    const Scalar c1 = Scalar(1.0) - std::cos(delta_norm);
+    // std::sin(delta_norm), std::cos(delta_norm) (:51-52): GCC, the reference's compiler, merges
+    // the pair into one sincos call; written out so that the result does not depend on whether
+    // this translation unit's compiler does (the two libm entry points differ by an ulp for
+    // about one argument in two thousand).
+    Scalar s, c;
+    if constexpr (sizeof(Scalar) == 8) ::sincos(delta_norm, &s, &c); else ::sincosf(delta_norm, &s, &c);
+    const Scalar c1 = Scalar(1.0) - c;
     for (int i = 0; i < 3; ++i) {
       for (int j = 0; j < 3; ++j) {
         // :51-52.  Association as Eigen 3.4.0 (what ubuntu-22.04's libeigen3-dev, the CI's
