@@ -216,7 +216,12 @@ MOPT_API int mopt_cost_compute(mopt_cost *cost, const void *x, void *sum_sq);
  * linearization sweep (in the mode of the most recent mopt_cost_linearize) and keeps H | b | sum_sq;
  * a following mopt_cost_linearize with bit-identical x, mode, loss and covariance returns them
  * without touching HBM — one sweep per accepted LM iteration instead of two.  Values equal those of
- * the un-speculated calls up to the summation order of sum_sq (1e-15 relative). */
+ * the un-speculated calls up to the summation order of sum_sq (1e-15 relative).
+ * That trade is free for the point2point moments sweep over fixed correspondences.  For the other
+ * sweeps (forward differences of the reprojection / scalar / user models, literal evaluation, ICP
+ * costs whose update(x) re-matches before the kept result can be used) the library keeps
+ * speculating only while it pays: once more kept results have gone unused than used,
+ * mopt_cost_compute goes back to the cost-only sweep. */
 MOPT_API int mopt_cost_set_speculation(mopt_cost *cost, int enabled);
 /* sweeps launched and calls answered from the kept result since creation */
 MOPT_API int mopt_cost_stats(const mopt_cost *cost, int64_t *sweeps, int64_t *cache_hits);
@@ -226,7 +231,11 @@ MOPT_API int mopt_cost_stats(const mopt_cost *cost, int64_t *sweeps, int64_t *ca
 /* Enqueue on `hip_stream` and return at once.  hip_stream is a hipStream_t passed as a pointer;
  * NULL is HIP's null (legacy default) stream, as everywhere in HIP — mopt_cost_stream gives the
  * cost's own stream when that is wanted.  d_result: device double[n*n + n + 1].  d_sum_sq: device
- * double[1].  The caller orders later work after the sweep by stream order or a synchronisation. */
+ * double[1].  The caller orders later work after the sweep by stream order or a synchronisation.
+ * Sweeps of ONE cost must be stream-ordered with respect to each other (a cost owns one set of
+ * partial-sum buffers): enqueue them on one stream, or order the streams with events.  The library
+ * records an event behind a sweep enqueued on a caller's stream, and mopt_cost_destroy /
+ * mopt_point2point_set_data wait for it before the cost's device buffers are reused. */
 MOPT_API int mopt_cost_linearize_async(mopt_cost *cost, int jacobian_mode, const void *x,
                                        double *d_result, void *hip_stream);
 MOPT_API int mopt_cost_compute_async(mopt_cost *cost, const void *x, double *d_sum_sq,

@@ -451,7 +451,7 @@ class Point2PointGroup:
         H = np.zeros((6, 6), dtype=dt, order="F")
         b = np.zeros(6, dtype=dt)
         s = np.zeros(1, dtype=dt)
-        fn = load().mopt_cost_linearize
+        fn = load().mopt_group_linearize
         args = (self._h, int(jac_mode), _ptr(x), _ptr(H), _ptr(b), _ptr(s))
 
         def call():

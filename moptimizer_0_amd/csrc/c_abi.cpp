@@ -32,6 +32,12 @@ namespace {
 inline int resultCount(const mopt_cost *c) { return c->n_params * c->n_params + c->n_params + 1; }
 inline int costOffset(const mopt_cost *c) { return c->n_params * c->n_params + c->n_params; }
 
+// MOPT_BLOCKS_PER_CU (tuning override of the workgroups launched per CU) is read once per process.
+int blocksPerCu(int fallback) {
+  static const int forced = envInt("MOPT_BLOCKS_PER_CU", 0);
+  return forced > 0 ? forced : fallback;
+}
+
 int gridFor(const mopt_cost *c, int blocks_per_cu) {
   long long g = (long long)c->num_cus * blocks_per_cu;
   if (g > c->num_tiles) g = c->num_tiles;
@@ -40,18 +46,28 @@ int gridFor(const mopt_cost *c, int blocks_per_cu) {
   return int(g);
 }
 
+// Every pair leaves pending_events exactly once, whatever fails: a pair whose timing cannot be read
+// is dropped from the statistics and its events destroyed (not recycled: they may still be pending).
 int resolvePendingEvents(mopt_cost *c) {
+  int rc = MOPT_OK;
   for (auto &pr : c->pending_events) {
-    MOPT_HIP_TRY(hipEventSynchronize(pr.second));
     float ms = 0.f;
-    MOPT_HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
-    c->sweep_ms_total += double(ms);
-    c->sweep_launches += 1;
-    c->free_events.push_back(pr.first);
-    c->free_events.push_back(pr.second);
+    hipError_t e = rc == MOPT_OK ? hipEventSynchronize(pr.second) : hipErrorUnknown;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, pr.first, pr.second);
+    if (e == hipSuccess) {
+      c->sweep_ms_total += double(ms);
+      c->sweep_launches += 1;
+      c->free_events.push_back(pr.first);
+      c->free_events.push_back(pr.second);
+    } else {
+      if (rc == MOPT_OK)
+        rc = fail(MOPT_ERR_HIP, std::string("sweep timing events: ") + hipGetErrorString(e));
+      (void)hipEventDestroy(pr.first);
+      (void)hipEventDestroy(pr.second);
+    }
   }
   c->pending_events.clear();
-  return MOPT_OK;
+  return rc;
 }
 
 // Times the dominant kernel of a sweep with a pair of HIP events on the launch stream when
@@ -83,7 +99,11 @@ struct SweepTimer {
         e = nullptr;
       }
     }
-    if (!ev[0] || !ev[1]) return;
+    if (!ev[0] || !ev[1]) {  // keep the one that was obtained
+      for (auto e : ev)
+        if (e) cost->free_events.push_back(e);
+      return;
+    }
     if (stamp_dispatch) {
       start = site.time_start = ev[0];
       stop_ev = site.time_stop = ev[1];
@@ -91,6 +111,9 @@ struct SweepTimer {
     } else if (hipEventRecord(ev[0], stream) == hipSuccess) {
       start = ev[0];
       stop_ev = ev[1];
+    } else {
+      cost->free_events.push_back(ev[0]);
+      cost->free_events.push_back(ev[1]);
     }
   }
   void stop() {
@@ -210,13 +233,13 @@ int p2pLinearizeAsync(mopt_cost *c, int jac_mode, const S *x, double *d_result, 
   if (moments) {
     mopt::AffineBasis basis;
     fillBasis<S>(c, jac_mode, args, basis);
-    const int grid = gridFor(c, envInt("MOPT_BLOCKS_PER_CU", 1));
+    const int grid = gridFor(c, blocksPerCu(1));
     SweepTimer timer(c, s, true);
     MOPT_HIP_TRY(mopt::launchP2PMoments<S>(args, grid, timer.site));
     timer.stop();
     MOPT_HIP_TRY(mopt::launchFinalizeMoments(c->d_partials, grid, basis, d_result, pub, s));
   } else {
-    const int grid = gridFor(c, envInt("MOPT_BLOCKS_PER_CU", 2));
+    const int grid = gridFor(c, blocksPerCu(2));
     const int nacc = c->cov_mode == mopt::kCovGeneral ? mopt::kAccFull : mopt::kAccSym;
     SweepTimer timer(c, s);
     MOPT_HIP_TRY(mopt::launchP2PLinearizeLiteral<S>(args, jac_mode, c->cov_mode, grid, timer.site));
@@ -232,7 +255,7 @@ int p2pCostAsync(mopt_cost *c, const S *x, double *d_sum, hipStream_t s,
                  const mopt::HostPublish &pub) {
   mopt::P2PSweepArgs<S> args;
   fillP2PArgs<S>(c, x, false, args);
-  const int grid = gridFor(c, envInt("MOPT_BLOCKS_PER_CU", 1));
+  const int grid = gridFor(c, blocksPerCu(1));
   SweepTimer timer(c, s, true);
   MOPT_HIP_TRY(mopt::launchP2PCost<S>(args, grid, timer.site));
   timer.stop();
@@ -296,7 +319,7 @@ int reprojLinearizeAsync(mopt_cost *c, int jac_mode, const double *x, double *d_
                 "the reprojection model has no analytic Jacobian (BaseModel, numeric only)");
   mopt::ReprojSweepArgs args;
   fillReprojArgs(c, x, true, args);
-  const int grid = gridFor(c, envInt("MOPT_BLOCKS_PER_CU", 2));
+  const int grid = gridFor(c, blocksPerCu(2));
   const int nacc = c->cov_mode == mopt::kCovGeneral ? mopt::kAccFull : mopt::kAccSym;
   SweepTimer timer(c, s);
   MOPT_HIP_TRY(mopt::launchReprojLinearize(args, c->cov_mode, grid, timer.site));
@@ -310,7 +333,7 @@ int reprojCostAsync(mopt_cost *c, const double *x, double *d_sum, hipStream_t s,
                     const mopt::HostPublish &pub) {
   mopt::ReprojSweepArgs args;
   fillReprojArgs(c, x, false, args);
-  const int grid = gridFor(c, envInt("MOPT_BLOCKS_PER_CU", 2));
+  const int grid = gridFor(c, blocksPerCu(2));
   SweepTimer timer(c, s);
   MOPT_HIP_TRY(mopt::launchReprojCost(args, grid, timer.site));
   timer.stop();
@@ -586,10 +609,22 @@ int commonCreate(mopt_cost *c, int device) {
   return MOPT_OK;
 }
 
+hipError_t quiesceCost(mopt_cost *c) {
+  hipError_t first = hipSuccess;
+  if (c->stream) first = hipStreamSynchronize(c->stream);
+  if (c->foreign_pending && c->foreign_done) {
+    const hipError_t e = hipEventSynchronize(c->foreign_done);
+    if (first == hipSuccess) first = e;
+    c->foreign_pending = false;
+  }
+  return first;
+}
+
 void destroyCost(mopt_cost *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  (void)quiesceCost(c);
+  if (c->foreign_done) (void)hipEventDestroy(c->foreign_done);
   for (auto &pr : c->pending_events) {
     (void)hipEventDestroy(pr.first);
     (void)hipEventDestroy(pr.second);
@@ -749,9 +784,9 @@ int mopt_point2point_set_data(mopt_cost *c, const void *src_xyz, const void *tgt
   if (tiles > std::numeric_limits<int>::max())
     return fail(MOPT_ERR_INVALID_ARGUMENT, "count too large");
   const size_t tile_bytes = size_t(tile_points) * 6 * c->scalar_bytes;
-  MOPT_HIP_TRY(hipStreamSynchronize(c->stream));
+  MOPT_HIP_TRY(quiesceCost(c));
   if (tiles > c->capacity_tiles) {
-    deviceRelease(c->d_tiles);  // the stream was synchronised above
+    deviceRelease(c->d_tiles);  // nothing enqueued for this cost is still running
     c->d_tiles = nullptr;
     c->capacity_tiles = 0;
     MOPT_HIP_TRY(deviceAlloc(&c->d_tiles, tile_bytes * size_t(tiles)));
@@ -968,19 +1003,36 @@ int mopt_cost_info(const mopt_cost *c, int64_t *count, int *n, int *m, int *scal
   return MOPT_OK;
 }
 
+namespace {
+// A sweep went onto a stream this cost does not own: leave a marker behind it, so that
+// destroy / set_data can wait for it before the cost's buffers go back to the pool.
+int markForeignStream(mopt_cost *c, hipStream_t s) {
+  if (s == c->stream) return MOPT_OK;
+  if (!c->foreign_done)
+    MOPT_HIP_TRY(hipEventCreateWithFlags(&c->foreign_done, hipEventDisableTiming));
+  MOPT_HIP_TRY(hipEventRecord(c->foreign_done, s));
+  c->foreign_pending = true;
+  return MOPT_OK;
+}
+}  // namespace
+
 int mopt_cost_linearize_async(mopt_cost *c, int jacobian_mode, const void *x, double *d_result,
                               void *hip_stream) {
   if (!c || !x || !d_result) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
   MOPT_HIP_TRY(hipSetDevice(c->device));
   // hip_stream is the hipStream_t itself; NULL is HIP's null (legacy default) stream, which is
   // also what torch's default stream is
-  return linearizeAsyncImpl(c, jacobian_mode, x, d_result, static_cast<hipStream_t>(hip_stream));
+  const hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const int rc = linearizeAsyncImpl(c, jacobian_mode, x, d_result, s);
+  return rc != MOPT_OK ? rc : markForeignStream(c, s);
 }
 
 int mopt_cost_compute_async(mopt_cost *c, const void *x, double *d_sum_sq, void *hip_stream) {
   if (!c || !x || !d_sum_sq) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
   MOPT_HIP_TRY(hipSetDevice(c->device));
-  return costAsyncImpl(c, x, d_sum_sq, static_cast<hipStream_t>(hip_stream));
+  const hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const int rc = costAsyncImpl(c, x, d_sum_sq, s);
+  return rc != MOPT_OK ? rc : markForeignStream(c, s);
 }
 
 namespace {
@@ -988,6 +1040,20 @@ bool cacheMatches(const mopt_cost *c, const void *x, int mode_or_any) {
   return c->cache.valid && c->cache.version == c->state_version &&
          (mode_or_any < 0 || c->cache.mode == mode_or_any) &&
          std::memcmp(c->cache.x, x, size_t(c->n_params) * c->scalar_bytes) == 0;
+}
+// Where the linearization sweep is as cheap as the cost sweep, speculation always pays.
+bool speculationIsFree(const mopt_cost *c) {
+  return c->model == kModelPoint2Point && c->variant != MOPT_KERNEL_LITERAL && !c->matcher;
+}
+// A kept result is about to be replaced or ignored without having answered a linearize.
+void noteKeptResultUnused(mopt_cost *c) {
+  if (c->spec_kept_unused) {
+    c->spec_kept_unused = false;
+    c->spec_unused += 1;
+  }
+}
+bool speculationPays(const mopt_cost *c) {
+  return speculationIsFree(c) || c->spec_unused < 2 || c->spec_unused <= c->spec_used;
 }
 void cacheStore(mopt_cost *c, const void *x, int mode) {
   c->cache.valid = true;
@@ -1005,10 +1071,15 @@ int mopt_cost_linearize(mopt_cost *c, int jacobian_mode, const void *x, void *he
     return fail(MOPT_ERR_INVALID_ARGUMENT, "unknown jacobian_mode");
   if (c->speculate && cacheMatches(c, x, jacobian_mode)) {
     c->stat_cache_hits += 1;
+    if (c->spec_kept_unused) {
+      c->spec_kept_unused = false;
+      c->spec_used += 1;
+    }
     c->last_jac_mode = jacobian_mode;
     storeResult(c, c->cache.result, hessian, b, sum_sq);
     return MOPT_OK;
   }
+  noteKeptResultUnused(c);
   MOPT_HIP_TRY(hipSetDevice(c->device));
   const int rc = blockingSweep(c, false, jacobian_mode, x);
   if (rc != MOPT_OK) return rc;
@@ -1026,11 +1097,13 @@ int mopt_cost_compute(mopt_cost *c, const void *x, void *sum_sq) {
     return MOPT_OK;
   }
   MOPT_HIP_TRY(hipSetDevice(c->device));
-  if (c->speculate && c->last_jac_mode >= 0) {
+  noteKeptResultUnused(c);
+  if (c->speculate && c->last_jac_mode >= 0 && speculationPays(c)) {
     // the linearization sweep also yields sum r^T r; keep all of it for the linearize that follows
     const int rc = blockingSweep(c, false, c->last_jac_mode, x);
     if (rc != MOPT_OK) return rc;
     cacheStore(c, x, c->last_jac_mode);
+    c->spec_kept_unused = true;
   } else {
     const int rc = blockingSweep(c, true, 0, x);
     if (rc != MOPT_OK) return rc;
@@ -1043,6 +1116,8 @@ int mopt_cost_set_speculation(mopt_cost *c, int enabled) {
   if (!c) return fail(MOPT_ERR_INVALID_ARGUMENT, "cost is NULL");
   c->speculate = enabled != 0;
   c->cache.valid = false;
+  c->spec_kept_unused = false;
+  c->spec_unused = c->spec_used = 0;
   return MOPT_OK;
 }
 

@@ -50,7 +50,8 @@ inline int envInt(const char *name, int fallback) {
 
 }  // namespace mopt_detail
 
-// Uniform grid over the target cloud of an ICP cost (built once on the host, resident in HBM).
+// Uniform grid over the target cloud of an ICP cost (built once, on the GPU: icp_grid.hip;
+// resident in HBM).
 struct IcpMatcher {
   void *d_sorted = nullptr;      // [num_targets][4] scalars grouped by cell
   int *d_cell_start = nullptr;   // [cells + 1]
@@ -110,6 +111,13 @@ struct mopt_cost {
   // linearization sweep (same HBM traffic as the cost sweep) and keeps its H | b | sum_sq, so the
   // following linearize at the same x costs no sweep at all.
   bool speculate = true;
+  // Speculation is free only where the linearization sweep costs what the cost sweep costs (the
+  // point2point moments sweep over fixed correspondences).  Elsewhere (forward differences of the
+  // reprojection / scalar / user models: n + 1 residual evaluations per element; ICP costs, whose
+  // update(x) invalidates the kept result before it can be used) it is kept only while it pays:
+  // once more kept results have gone unused than used, computeCost goes back to cost-only sweeps.
+  bool spec_kept_unused = false;  // a result kept by mopt_cost_compute that nobody has asked for yet
+  int spec_unused = 0, spec_used = 0;
   int last_jac_mode = -1;
   unsigned long long state_version = 0;  // bumped when loss / covariance / variant change
   struct {
@@ -121,6 +129,11 @@ struct mopt_cost {
   } cache;
   long long stat_sweeps = 0;
   long long stat_cache_hits = 0;
+
+  // Sweeps enqueued on a caller's stream (the *_async entry points): the buffers of this cost must
+  // not be recycled before that work has finished, and only an event on that stream can tell.
+  hipEvent_t foreign_done = nullptr;
+  bool foreign_pending = false;
 
   int profiling = 0;  // 0 off, N > 0: bracket every N-th sweep launch with events
   long long profiling_tick = 0;
@@ -148,6 +161,8 @@ hipError_t deviceAlloc(void **out, size_t bytes);
 void deviceRelease(void *p);
 
 int commonCreate(mopt_cost *c, int device);  // device, stream, partial / result buffers
+// wait for everything enqueued for this cost, on its own stream and on callers' streams
+hipError_t quiesceCost(mopt_cost *c);
 void destroyCost(mopt_cost *c);
 // enqueue one linearization / cost sweep + its finalize on `s`; results to d_result (+ optional
 // hand-over to mapped host memory)

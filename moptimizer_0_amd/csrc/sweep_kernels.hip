@@ -12,8 +12,9 @@
 //     staging of inputs — every lane issues 16-byte loads straight to VGPRs, six per tile, all
 //     six landing in one contiguous 24 KiB tile (layout in sweep.hpp), with the next tile's loads
 //     issued before the current tile's arithmetic so each wave keeps 2 x 96 B per lane in flight.
-//   * 64-wide wavefronts: per-thread register accumulators -> wave reduction with shuffles ->
-//     4 waves combined through LDS -> one partial row per workgroup in HBM.
+//   * 64-wide wavefronts: per-thread register accumulators -> one LDS transpose per workgroup
+//     (every lane stores each value once, 32 x 8 threads add them up, three xor-shuffles finish;
+//     blockReduceStore) -> one partial row per workgroup in HBM.
 //   * A fixed grid (workgroups per CU x CUs) strides over tiles, so the summation tree — and
 //     therefore the result — is deterministic for a given device and count.
 //   * A second tiny kernel adds the workgroup partials in a fixed order and writes

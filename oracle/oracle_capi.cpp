@@ -12,7 +12,7 @@
 #include <vector>
 
 #include "cpu_costs.hpp"
-#include "moptimizer_amd/levenberg_marquadt.hpp"
+#include "moptimizer_caller/levenberg_marquadt.hpp"
 #include "test_models.hpp"
 
 namespace {

@@ -26,7 +26,7 @@
 #include <vector>
 
 #include "cpu_costs.hpp"
-#include "moptimizer_amd/levenberg_marquadt.hpp"
+#include "moptimizer_caller/levenberg_marquadt.hpp"
 #include "test_models.hpp"
 
 #include "curve_data.inc"

@@ -7,10 +7,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import moptimizer_0_amd as mo
-from bench import make_shard_on_gpu, prewarm_runtime
+from bench import make_shard_on_gpu, quiesce_python_gc
 from tests import datasets as ds
 torch.cuda.set_device(0)
-prewarm_runtime(mo)
+quiesce_python_gc()
 for n in (1_000_000, 10_000_000):
     src, tgt = make_shard_on_gpu(torch, n, 0, torch.float64)
     torch.cuda.synchronize()

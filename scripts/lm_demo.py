@@ -34,10 +34,10 @@ def main():
     args = ap.parse_args()
     import torch
     import moptimizer_0_amd as mo
-    from bench import make_shard_on_gpu, prewarm_runtime
+    from bench import make_shard_on_gpu, quiesce_python_gc
     from tests import datasets as ds, oracle_binding as ob
     torch.cuda.set_device(0)
-    prewarm_runtime(mo)
+    quiesce_python_gc()
     src, tgt = make_shard_on_gpu(torch, args.n, 0, torch.float64)
     torch.cuda.synchronize()
     for spec in (False, True):

@@ -39,11 +39,11 @@ def main():
     args = ap.parse_args()
     import torch
     import moptimizer_0_amd as mo
-    from bench import make_shard_on_gpu, prewarm_runtime
+    from bench import make_shard_on_gpu, quiesce_python_gc
     from tests import datasets as ds
 
     torch.cuda.set_device(0)
-    prewarm_runtime(mo)
+    quiesce_python_gc()
     rows = []
     for dtype, tdt, ndt, bpp in (("f64", torch.float64, np.float64, 48), ("f32", torch.float32, np.float32, 24)):
         x = ds.X_GENERIC.astype(ndt)

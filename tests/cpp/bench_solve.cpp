@@ -12,7 +12,7 @@
 #include <vector>
 
 #include "moptimizer_amd/cost_function_hip.hpp"
-#include "moptimizer_amd/levenberg_marquadt.hpp"
+#include "moptimizer_caller/levenberg_marquadt.hpp"
 #include "moptimizer_amd/so3.hpp"
 
 #include "cpu_costs.hpp"

@@ -10,7 +10,7 @@
 #include <vector>
 
 #include "moptimizer_amd/cost_function_hip.hpp"
-#include "moptimizer_amd/levenberg_marquadt.hpp"
+#include "moptimizer_caller/levenberg_marquadt.hpp"
 
 #include "curve_data.inc"
 

@@ -19,7 +19,7 @@
 #include "cpu_costs.hpp"     // oracle (test infrastructure)
 #include "test_models.hpp"   // oracle (test infrastructure)
 #include "moptimizer_amd/cost_function_hip.hpp"
-#include "moptimizer_amd/levenberg_marquadt.hpp"
+#include "moptimizer_caller/levenberg_marquadt.hpp"
 #include "moptimizer_amd/so3.hpp"
 
 using Scalar = double;

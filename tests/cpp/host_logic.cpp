@@ -11,7 +11,7 @@
 #include <sstream>
 #include <stdexcept>
 
-#include "moptimizer_amd/levenberg_marquadt.hpp"
+#include "moptimizer_caller/levenberg_marquadt.hpp"
 #include "moptimizer_amd/so3.hpp"
 
 using moptimizer::LevenbergMarquadtDynamic;

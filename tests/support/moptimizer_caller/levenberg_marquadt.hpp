@@ -1,3 +1,5 @@
+// TEST SUPPORT — not part of the product (libmoptimizer_hip.so and include/ do not use it).
+//
 // The caller of the linearization path: Levenberg-Marquardt over a list of cost functions.
 //
 // Not accelerated and not part of the GPU work; it is restated (without Eigen) only so that
@@ -23,6 +25,7 @@
 #include <vector>
 
 #include "moptimizer_amd/dense.hpp"
+#include "moptimizer_caller/ldlt.hpp"
 #include "moptimizer_amd/host_api.hpp"
 
 namespace duna {
