@@ -34,10 +34,10 @@ $(OBJDIR)/icp_grid.o: $(CSRC)/icp_grid.hip $(PUBLIC_HEADERS) | $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) $(INCLUDES) -c $< -o $@
 
 OBJS = $(OBJDIR)/sweep_kernels.o $(OBJDIR)/icp_grid.o $(OBJDIR)/c_abi.o $(OBJDIR)/icp.o \
-       $(OBJDIR)/group.o $(OBJDIR)/jit_model.o $(OBJDIR)/device_pool.o
+       $(OBJDIR)/group.o $(OBJDIR)/jit_model.o $(OBJDIR)/device_pool.o $(OBJDIR)/combine.o
 
 $(LIB): $(OBJS) | $(LIBDIR)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -L$(ROCM)/lib -lrccl -lhiprtc \
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -L$(ROCM)/lib -lrccl -lhiprtc -lpthread -lrt \
 	    -Wl,-rpath,$(ROCM)/lib -Wl,--no-undefined
 
 oracle:

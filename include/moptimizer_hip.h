@@ -61,7 +61,8 @@ enum mopt_status {
   MOPT_ERR_HIP = 2,
   MOPT_ERR_NO_DEVICE = 3,
   MOPT_ERR_RCCL = 4,
-  MOPT_ERR_UNSUPPORTED = 5
+  MOPT_ERR_UNSUPPORTED = 5,
+  MOPT_ERR_PEER_TIMEOUT = 6 /* a rank of a sharded cost did not deliver its sums in time */
 };
 
 /* How the per-residual Jacobian is obtained. */
@@ -256,6 +257,60 @@ MOPT_API int mopt_cost_synchronize(mopt_cost *cost);
 #define MOPT_COMM_ID_BYTES 128
 MOPT_API int mopt_comm_unique_id(void *id_out, int id_bytes);
 MOPT_API int mopt_cost_comm_init_rank(mopt_cost *cost, const void *id, int rank, int num_ranks);
+
+/* ---- latency-optimised shard combine (replaces the all-reduce launch) -----------------------
+ *
+ * The message of the all-reduce is 344 bytes, so its cost is launches and hops, not bandwidth
+ * (an ncclAllReduce adds a kernel launch behind the finalize kernel, and a publish kernel behind
+ * that).  Two fused forms; in both the finalize kernel of the sweep itself hands the sums over and
+ * every rank adds the num_ranks contributions in rank order (bit-identical totals on every rank):
+ *
+ *   MOPT_COMBINE_HOST  the finalize kernel of every rank publishes its sums (write-through stores
+ *                      + sequence word) into its slot of one block of pinned host memory shared by
+ *                      all ranks (POSIX shared memory registered with HIP); each rank's host
+ *                      thread waits for the num_ranks sequence words and adds the slots.  One hop
+ *                      (GPU -> host memory), no collective launch, no device-side wait.  Results
+ *                      exist on the host only: for the blocking calls.
+ *   MOPT_COMBINE_PEER  every rank owns a slot block in uncached device memory which all ranks
+ *                      open (hipIpcMemHandle between processes: xGMI stores); the finalize kernel
+ *                      pushes its sums into its slot of every rank's block, waits (bounded) for the
+ *                      other ranks' sequence words in its own block, adds, and publishes.  The sums
+ *                      of all ranks are then also in this rank's HBM: for the *_async calls and
+ *                      mopt_lm_minimize, where the next step is taken on the device.
+ *   MOPT_COMBINE_RCCL  ncclAllReduce on the cost's stream (mopt_cost_comm_init_rank), kept for
+ *                      comparison.
+ *
+ * Attach (any subset), then pick with mopt_cost_set_combine; the last attached transport is
+ * selected by default.  All of this is collective: every rank makes the same calls in the same
+ * order, and the caller puts a barrier of its own between attaching and the first sweep, and
+ * before destroying (a rank must not push into memory a peer has already released).
+ *
+ *   mopt_cost_hostcomm_attach   shm_name: a name unique to this job and cost ("/mopt-<pid>-<k>",
+ *                               same on every rank); created by whoever comes first, unlinked by
+ *                               mopt_hostcomm_unlink (any one rank, after the barrier) or at
+ *                               destroy
+ *   mopt_cost_peer_export       allocates this rank's slot block and returns its IPC handle
+ *                               (MOPT_PEER_HANDLE_BYTES); the caller gathers the handles of all
+ *                               ranks, in rank order, by any means
+ *   mopt_cost_peer_attach       opens them (handles: num_ranks * MOPT_PEER_HANDLE_BYTES)
+ *
+ * A peer that never arrives ends the device-side wait after MOPT_PEER_TIMEOUT_MS (default 5000)
+ * and the call returns MOPT_ERR_PEER_TIMEOUT; the host-side wait is bounded the same way. */
+enum mopt_combine_mode {
+  MOPT_COMBINE_NONE = 0, /* this rank's own sums (also: detach for a comparison run) */
+  MOPT_COMBINE_RCCL = 1,
+  MOPT_COMBINE_HOST = 2,
+  MOPT_COMBINE_PEER = 3
+};
+#define MOPT_PEER_HANDLE_BYTES 64
+MOPT_API int mopt_cost_hostcomm_attach(mopt_cost *cost, const char *shm_name, int rank,
+                                       int num_ranks);
+MOPT_API int mopt_hostcomm_unlink(const char *shm_name);
+MOPT_API int mopt_cost_peer_export(mopt_cost *cost, int num_ranks, void *handle_out);
+MOPT_API int mopt_cost_peer_attach(mopt_cost *cost, const void *handles, int rank, int num_ranks);
+MOPT_API int mopt_cost_set_combine(mopt_cost *cost, int combine_mode);
+MOPT_API int mopt_cost_get_combine(const mopt_cost *cost, int *combine_mode, int *rank,
+                                   int *num_ranks);
 
 /* ---- measurement -------------------------------------------------------------------------- */
 

@@ -7,6 +7,10 @@ shard a cost over one-process-per-GPU ranks with torch.distributed (RCCL).
 """
 from . import _capi as capi  # noqa: F401
 from ._capi import (  # noqa: F401
+    COMBINE_HOST,
+    COMBINE_NONE,
+    COMBINE_PEER,
+    COMBINE_RCCL,
     JAC_ANALYTIC,
     JAC_ANALYTIC_TST_LAYOUT,
     JAC_NUMERIC,

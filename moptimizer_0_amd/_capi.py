@@ -17,6 +17,10 @@ JAC_ANALYTIC, JAC_ANALYTIC_TST_LAYOUT, JAC_NUMERIC = 0, 1, 2
 LOSS_NONE, LOSS_GEMAN_MCCLURE = 0, 1
 INPUT_HOST, INPUT_DEVICE = 0, 1
 KERNEL_AUTO, KERNEL_LITERAL, KERNEL_MOMENTS = 0, 1, 2
+COMBINE_NONE, COMBINE_RCCL, COMBINE_HOST, COMBINE_PEER = 0, 1, 2, 3
+COMBINE_NAMES = {COMBINE_NONE: "none", COMBINE_RCCL: "rccl", COMBINE_HOST: "host", COMBINE_PEER: "peer"}
+PEER_HANDLE_BYTES = 64
+ERR_PEER_TIMEOUT = 6
 RESULT_DOUBLES = 43
 
 _lib = None
@@ -86,6 +90,13 @@ def load():
                             ctypes.POINTER(ctypes.c_int64)],
         "mopt_comm_unique_id": [ctypes.c_void_p, ctypes.c_int],
         "mopt_cost_comm_init_rank": [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int],
+        "mopt_cost_hostcomm_attach": [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int],
+        "mopt_hostcomm_unlink": [ctypes.c_char_p],
+        "mopt_cost_peer_export": [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p],
+        "mopt_cost_peer_attach": [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int],
+        "mopt_cost_set_combine": [ctypes.c_void_p, ctypes.c_int],
+        "mopt_cost_get_combine": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int),
+                                  ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)],
         "mopt_cost_set_profiling": [ctypes.c_void_p, ctypes.c_int],
         "mopt_cost_profile": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
                               ctypes.POINTER(ctypes.c_int64)],
@@ -118,6 +129,10 @@ def check(rc):
 
 
 COMM_ID_BYTES = 128
+
+
+def hostcomm_unlink(shm_name):
+    check(load().mopt_hostcomm_unlink(shm_name.encode()))
 
 
 def comm_unique_id():
@@ -251,6 +266,34 @@ class _CostBase:
         linearize / compute_cost return the sums over all ranks."""
         buf = ctypes.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
         check(load().mopt_cost_comm_init_rank(self._h, buf, int(rank), int(num_ranks)))
+
+    # -- shard combine without a collective launch (include/moptimizer_hip.h) ---------------
+    def hostcomm_attach(self, shm_name, rank, num_ranks):
+        """MOPT_COMBINE_HOST: every rank's finalize kernel publishes into one shared host block."""
+        check(load().mopt_cost_hostcomm_attach(self._h, shm_name.encode(), int(rank),
+                                               int(num_ranks)))
+
+    def peer_export(self, num_ranks):
+        """Allocate this rank's device slot block; returns its IPC handle (bytes)."""
+        buf = ctypes.create_string_buffer(PEER_HANDLE_BYTES)
+        check(load().mopt_cost_peer_export(self._h, int(num_ranks), buf))
+        return buf.raw
+
+    def peer_attach(self, handles, rank, num_ranks):
+        """MOPT_COMBINE_PEER: open the slot blocks of all ranks (handles in rank order)."""
+        blob = b"".join(bytes(h) for h in handles)
+        assert len(blob) == PEER_HANDLE_BYTES * num_ranks
+        buf = ctypes.create_string_buffer(blob, len(blob))
+        check(load().mopt_cost_peer_attach(self._h, buf, int(rank), int(num_ranks)))
+
+    def set_combine(self, mode):
+        check(load().mopt_cost_set_combine(self._h, int(mode)))
+
+    def get_combine(self):
+        mode, rank, n = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        check(load().mopt_cost_get_combine(self._h, ctypes.byref(mode), ctypes.byref(rank),
+                                           ctypes.byref(n)))
+        return mode.value, rank.value, n.value
 
     def synchronize(self):
         check(load().mopt_cost_synchronize(self._h))

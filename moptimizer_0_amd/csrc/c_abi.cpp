@@ -237,7 +237,7 @@ int p2pLinearizeAsync(mopt_cost *c, int jac_mode, const S *x, double *d_result, 
     SweepTimer timer(c, s, true);
     MOPT_HIP_TRY(mopt::launchP2PMoments<S>(args, grid, timer.site));
     timer.stop();
-    MOPT_HIP_TRY(mopt::launchFinalizeMoments(c->d_partials, grid, basis, d_result, pub, s));
+    MOPT_HIP_TRY(mopt::launchFinalizeMoments(c->d_partials, grid, basis, d_result, pub, s, c->launch_peers));
   } else {
     const int grid = gridFor(c, blocksPerCu(2));
     const int nacc = c->cov_mode == mopt::kCovGeneral ? mopt::kAccFull : mopt::kAccSym;
@@ -245,7 +245,7 @@ int p2pLinearizeAsync(mopt_cost *c, int jac_mode, const S *x, double *d_result, 
     MOPT_HIP_TRY(mopt::launchP2PLinearizeLiteral<S>(args, jac_mode, c->cov_mode, grid, timer.site));
     timer.stop();
     MOPT_HIP_TRY(
-        mopt::launchFinalizeDense(c->d_partials, grid, nacc, kNumParams, d_result, pub, s));
+        mopt::launchFinalizeDense(c->d_partials, grid, nacc, kNumParams, d_result, pub, s, c->launch_peers));
   }
   return MOPT_OK;
 }
@@ -259,7 +259,7 @@ int p2pCostAsync(mopt_cost *c, const S *x, double *d_sum, hipStream_t s,
   SweepTimer timer(c, s, true);
   MOPT_HIP_TRY(mopt::launchP2PCost<S>(args, grid, timer.site));
   timer.stop();
-  MOPT_HIP_TRY(mopt::launchFinalizeCost(c->d_partials, grid, d_sum, pub, s));
+  MOPT_HIP_TRY(mopt::launchFinalizeCost(c->d_partials, grid, d_sum, pub, s, c->launch_peers));
   return MOPT_OK;
 }
 
@@ -325,7 +325,7 @@ int reprojLinearizeAsync(mopt_cost *c, int jac_mode, const double *x, double *d_
   MOPT_HIP_TRY(mopt::launchReprojLinearize(args, c->cov_mode, grid, timer.site));
   timer.stop();
   MOPT_HIP_TRY(
-      mopt::launchFinalizeDense(c->d_partials, grid, nacc, kNumParams, d_result, pub, s));
+      mopt::launchFinalizeDense(c->d_partials, grid, nacc, kNumParams, d_result, pub, s, c->launch_peers));
   return MOPT_OK;
 }
 
@@ -337,7 +337,7 @@ int reprojCostAsync(mopt_cost *c, const double *x, double *d_sum, hipStream_t s,
   SweepTimer timer(c, s);
   MOPT_HIP_TRY(mopt::launchReprojCost(args, grid, timer.site));
   timer.stop();
-  MOPT_HIP_TRY(mopt::launchFinalizeCost(c->d_partials, grid, d_sum, pub, s));
+  MOPT_HIP_TRY(mopt::launchFinalizeCost(c->d_partials, grid, d_sum, pub, s, c->launch_peers));
   return MOPT_OK;
 }
 
@@ -383,10 +383,10 @@ int scalarSweepAsync(mopt_cost *c, bool cost_only, int jac_mode, const S *x, dou
                                           grid, s));
   timer.stop();
   if (cost_only) {
-    MOPT_HIP_TRY(mopt::launchFinalizeCost(c->d_partials, grid, d_out, pub, s));
+    MOPT_HIP_TRY(mopt::launchFinalizeCost(c->d_partials, grid, d_out, pub, s, c->launch_peers));
   } else {
     const int nacc = c->cov_mode == mopt::kCovGeneral ? n * n + n + 1 : n * (n + 1) / 2 + n + 1;
-    MOPT_HIP_TRY(mopt::launchFinalizeDense(c->d_partials, grid, nacc, n, d_out, pub, s));
+    MOPT_HIP_TRY(mopt::launchFinalizeDense(c->d_partials, grid, nacc, n, d_out, pub, s, c->launch_peers));
   }
   return MOPT_OK;
 }
@@ -430,10 +430,10 @@ int jitSweepAsync(mopt_cost *c, bool cost_only, int jac_mode, const S *x, double
   MOPT_HIP_TRY(mopt::jitLaunch(*variant, &args, sizeof args, grid, s));
   timer.stop();
   if (cost_only) {
-    MOPT_HIP_TRY(mopt::launchFinalizeCost(c->d_partials, grid, d_out, pub, s));
+    MOPT_HIP_TRY(mopt::launchFinalizeCost(c->d_partials, grid, d_out, pub, s, c->launch_peers));
   } else {
     const int nacc = cov_symmetric ? n * (n + 1) / 2 + n + 1 : n * n + n + 1;
-    MOPT_HIP_TRY(mopt::launchFinalizeDense(c->d_partials, grid, nacc, n, d_out, pub, s));
+    MOPT_HIP_TRY(mopt::launchFinalizeDense(c->d_partials, grid, nacc, n, d_out, pub, s, c->launch_peers));
   }
   return MOPT_OK;
 }
@@ -517,30 +517,124 @@ mopt::HostPublish nextPublish(mopt_cost *c, int offset) {
   return pub;
 }
 
-// One blocking sweep on the cost's own stream: kernels (+ all-reduce over the attached
-// communicator) and the published result in c->h_result[offset .. offset + count).
+// The host side of MOPT_COMBINE_HOST: wait until every rank's finalize kernel has published
+// sweep `sequence` into its slot of the shared block, then add the slots in rank order.
+int waitAndSumHostSlots(mopt_cost *c, unsigned long long sequence, int offset, int count) {
+  const ShardCombine &sc = c->combine;
+  const auto started = std::chrono::steady_clock::now();
+  const auto limit = std::chrono::milliseconds(envInt("MOPT_PEER_TIMEOUT_MS", 5000));
+  unsigned long long spins = 0;
+  for (int k = 0; k < sc.num_ranks; ++k) {
+    const double *slot = sc.host_block + mopt::slotIndex(sequence, sc.num_ranks, k);
+    const unsigned long long *flag =
+        reinterpret_cast<const unsigned long long *>(slot + mopt::kSlotFlag);
+    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) < sequence) {
+      if ((++spins & 0x3fff) == 0) {
+        const hipError_t q = hipStreamQuery(c->stream);
+        if (q != hipSuccess && q != hipErrorNotReady)
+          return fail(MOPT_ERR_HIP, std::string("sweep failed: ") + hipGetErrorString(q));
+        if (std::chrono::steady_clock::now() - started > limit)
+          return fail(MOPT_ERR_PEER_TIMEOUT, "rank " + std::to_string(k) +
+                                                 " did not publish its sums (MOPT_PEER_TIMEOUT_MS)");
+      }
+      __builtin_ia32_pause();
+    }
+  }
+  double *out = c->h_result + offset;
+  for (int q = 0; q < count; ++q) out[q] = 0.0;
+  for (int k = 0; k < sc.num_ranks; ++k) {
+    const double *slot = sc.host_block + mopt::slotIndex(sequence, sc.num_ranks, k) + offset;
+    for (int q = 0; q < count; ++q) out[q] += slot[q];
+  }
+  return MOPT_OK;
+}
+
+mopt::PeerCombine nextPeerCombine(mopt_cost *c, int offset) {
+  ShardCombine &sc = c->combine;
+  mopt::PeerCombine pc;
+  for (int k = 0; k < sc.num_ranks; ++k) pc.blocks[k] = sc.peer_blocks[k];
+  pc.rank = sc.rank;
+  pc.num_ranks = sc.num_ranks;
+  pc.offset = offset;
+  pc.sequence = ++sc.sequence;
+  pc.timeout_ticks = sc.peer_timeout_ticks;
+  return pc;
+}
+
+// One blocking sweep on the cost's own stream: kernels, the sum over the ranks of a sharded cost
+// (combine mode), and the published result in c->h_result[offset .. offset + count).
 int blockingSweep(mopt_cost *c, bool cost_only, int jac_mode, const void *x) {
   const int offset = cost_only ? costOffset(c) : 0;
   const int count = cost_only ? 1 : resultCount(c);
-  mopt::HostPublish pub = nextPublish(c, offset);
   c->stat_sweeps += 1;
-  int rc;
-  if (c->comm) {  // also for a 1-rank communicator: same code path as N ranks
-    rc = cost_only ? costAsyncImpl(c, x, c->d_result + offset, c->stream)
-                   : linearizeAsyncImpl(c, jac_mode, x, c->d_result, c->stream);
-    if (rc != MOPT_OK) return rc;
-    MOPT_NCCL_TRY(ncclAllReduce(c->d_result + offset, c->d_result + offset, count, ncclDouble,
-                                ncclSum, c->comm, c->stream));
-    MOPT_HIP_TRY(mopt::launchPublish(c->d_result + offset, count, pub, c->stream));
-  } else {
-    rc = cost_only ? costAsyncImpl(c, x, c->d_result + offset, c->stream, pub)
-                   : linearizeAsyncImpl(c, jac_mode, x, c->d_result, c->stream, pub);
-    if (rc != MOPT_OK) return rc;
+  auto launch = [&](const mopt::HostPublish &pub) {
+    return cost_only ? costAsyncImpl(c, x, c->d_result + offset, c->stream, pub)
+                     : linearizeAsyncImpl(c, jac_mode, x, c->d_result, c->stream, pub);
+  };
+  switch (c->combine.mode) {
+    case MOPT_COMBINE_RCCL: {  // also for a 1-rank communicator: same code path as N ranks
+      int rc = launch(mopt::HostPublish());
+      if (rc != MOPT_OK) return rc;
+      MOPT_NCCL_TRY(ncclAllReduce(c->d_result + offset, c->d_result + offset, count, ncclDouble,
+                                  ncclSum, c->comm, c->stream));
+      mopt::HostPublish pub = nextPublish(c, offset);
+      MOPT_HIP_TRY(mopt::launchPublish(c->d_result + offset, count, pub, c->stream));
+      return waitPublished(c, pub.sequence);
+    }
+    case MOPT_COMBINE_HOST: {
+      ShardCombine &sc = c->combine;
+      const unsigned long long seq = ++sc.sequence;
+      double *slot = sc.host_block_dev + mopt::slotIndex(seq, sc.num_ranks, sc.rank);
+      mopt::HostPublish pub;
+      pub.host_result = slot + offset;
+      pub.host_flag = reinterpret_cast<unsigned long long *>(slot + mopt::kSlotFlag);
+      pub.sequence = seq;
+      int rc = launch(pub);
+      if (rc != MOPT_OK) return rc;
+      return waitAndSumHostSlots(c, seq, offset, count);
+    }
+    case MOPT_COMBINE_PEER: {
+      const mopt::PeerCombine pc = nextPeerCombine(c, offset);
+      mopt::HostPublish pub = nextPublish(c, offset);
+      pub.host_status = c->h_flag_dev + 1;
+      c->launch_peers = &pc;
+      int rc = launch(pub);
+      c->launch_peers = nullptr;
+      if (rc != MOPT_OK) return rc;
+      rc = waitPublished(c, pub.sequence);
+      if (rc != MOPT_OK) return rc;
+      if (__atomic_load_n(c->h_flag + 1, __ATOMIC_ACQUIRE) == mopt::kStatusPeerTimeout)
+        return fail(MOPT_ERR_PEER_TIMEOUT,
+                    "a rank did not deliver its sums to this device in time (MOPT_PEER_TIMEOUT_MS)");
+      return MOPT_OK;
+    }
+    default: {
+      mopt::HostPublish pub = nextPublish(c, offset);
+      int rc = launch(pub);
+      if (rc != MOPT_OK) return rc;
+      return waitPublished(c, pub.sequence);
+    }
   }
-  return waitPublished(c, pub.sequence);
 }
 
 }  // namespace
+
+namespace mopt_detail {
+// For the single-process device group (group.cpp): a shard's sweep + finalize published into its
+// own mapped host memory, launched by one thread and awaited by another.
+int launchPublishedSweep(mopt_cost *c, bool cost_only, int jac_mode, const void *x,
+                         unsigned long long *sequence_out) {
+  const int offset = cost_only ? costOffset(c) : 0;
+  const mopt::HostPublish pub = nextPublish(c, offset);
+  c->stat_sweeps += 1;
+  *sequence_out = pub.sequence;
+  return cost_only ? costAsyncImpl(c, x, c->d_result + offset, c->stream, pub)
+                   : linearizeAsyncImpl(c, jac_mode, x, c->d_result, c->stream, pub);
+}
+int waitPublishedSweep(mopt_cost *c, unsigned long long sequence) {
+  return waitPublished(c, sequence);
+}
+}  // namespace mopt_detail
 
 namespace mopt_detail {
 namespace {
@@ -631,6 +725,8 @@ void destroyCost(mopt_cost *c) {
   }
   for (auto e : c->free_events) (void)hipEventDestroy(e);
   if (c->comm) ncclCommDestroy(c->comm);
+  c->comm = nullptr;
+  releaseCombine(c);
   if (c->matcher) {
     deviceRelease(c->matcher->d_sorted);
     deviceRelease(c->matcher->d_cell_start);
@@ -1023,7 +1119,13 @@ int mopt_cost_linearize_async(mopt_cost *c, int jacobian_mode, const void *x, do
   // hip_stream is the hipStream_t itself; NULL is HIP's null (legacy default) stream, which is
   // also what torch's default stream is
   const hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  mopt::PeerCombine pc;
+  if (c->combine.mode == MOPT_COMBINE_PEER) {  // the sums of all ranks end up in d_result
+    pc = nextPeerCombine(c, 0);
+    c->launch_peers = &pc;
+  }
   const int rc = linearizeAsyncImpl(c, jacobian_mode, x, d_result, s);
+  c->launch_peers = nullptr;
   return rc != MOPT_OK ? rc : markForeignStream(c, s);
 }
 
@@ -1031,7 +1133,13 @@ int mopt_cost_compute_async(mopt_cost *c, const void *x, double *d_sum_sq, void 
   if (!c || !x || !d_sum_sq) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
   MOPT_HIP_TRY(hipSetDevice(c->device));
   const hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  mopt::PeerCombine pc;
+  if (c->combine.mode == MOPT_COMBINE_PEER) {
+    pc = nextPeerCombine(c, costOffset(c));
+    c->launch_peers = &pc;
+  }
   const int rc = costAsyncImpl(c, x, d_sum_sq, s);
+  c->launch_peers = nullptr;
   return rc != MOPT_OK ? rc : markForeignStream(c, s);
 }
 
@@ -1146,8 +1254,16 @@ int mopt_cost_comm_init_rank(mopt_cost *c, const void *id, int rank, int num_ran
   MOPT_HIP_TRY(hipSetDevice(c->device));
   ncclUniqueId uid;
   std::memcpy(&uid, id, sizeof uid);
+  const ShardCombine &sc = c->combine;
+  if ((sc.host_block || sc.peer_attached) && (sc.rank != rank || sc.num_ranks != num_ranks))
+    return fail(MOPT_ERR_INVALID_ARGUMENT,
+                "rank / num_ranks differ from the transport already attached to this cost");
   MOPT_NCCL_TRY(ncclCommInitRank(&c->comm, num_ranks, uid, rank));
   c->comm_size = num_ranks;
+  c->combine.rank = rank;
+  c->combine.num_ranks = num_ranks;
+  c->combine.mode = MOPT_COMBINE_RCCL;
+  c->cache.valid = false;
   return MOPT_OK;
 }
 

@@ -1,0 +1,218 @@
+// Shard combine without a collective launch (include/moptimizer_hip.h, "latency-optimised shard
+// combine"; slot geometry in sweep.hpp).  This file owns the memory the ranks share:
+//   MOPT_COMBINE_HOST  one slot block in POSIX shared memory, registered with HIP in every rank;
+//   MOPT_COMBINE_PEER  one slot block per rank in uncached device memory, exported / opened as
+//                      hipIpcMemHandle (xGMI stores between the GPUs of a node).
+// The pushes and waits themselves are in the finalize kernels (sweep_kernels.hip: publishToHost,
+// peerCombine) and in blockingSweep (c_abi.cpp).
+#include "cost_state.hpp"
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cerrno>
+#include <cstring>
+
+using namespace mopt_detail;
+
+static_assert(sizeof(hipIpcMemHandle_t) == MOPT_PEER_HANDLE_BYTES,
+              "MOPT_PEER_HANDLE_BYTES must be the size of a hipIpcMemHandle_t");
+
+namespace {
+
+constexpr int kMaxHostRanks = 64;
+
+int checkRanks(const mopt_cost *c, int rank, int num_ranks, int limit) {
+  if (num_ranks < 1 || num_ranks > limit || rank < 0 || rank >= num_ranks)
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "bad rank / num_ranks for this transport");
+  const ShardCombine &sc = c->combine;
+  const bool attached = sc.host_block || sc.peer_attached || c->comm;
+  if (attached && (sc.rank != rank || sc.num_ranks != num_ranks))
+    return fail(MOPT_ERR_INVALID_ARGUMENT,
+                "rank / num_ranks differ from the transport already attached to this cost");
+  return MOPT_OK;
+}
+
+unsigned long long peerTimeoutTicks(int device) {
+  int khz = 0;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) != hipSuccess || khz <= 0)
+    khz = 100000;  // gfx9: 100 MHz
+  return (unsigned long long)khz * (unsigned long long)envInt("MOPT_PEER_TIMEOUT_MS", 5000);
+}
+
+}  // namespace
+
+namespace mopt_detail {
+
+void releaseCombine(mopt_cost *c) {
+  ShardCombine &sc = c->combine;
+  for (int k = 0; k < mopt::kMaxPeers; ++k) {
+    if (sc.peer_opened[k] && sc.peer_blocks[k]) (void)hipIpcCloseMemHandle(sc.peer_blocks[k]);
+    sc.peer_opened[k] = false;
+    sc.peer_blocks[k] = nullptr;
+  }
+  if (sc.peer_own) (void)hipFree(sc.peer_own);
+  sc.peer_own = nullptr;
+  sc.peer_attached = false;
+  if (sc.host_registered) (void)hipHostUnregister(sc.host_block);
+  sc.host_registered = false;
+  if (sc.host_block) (void)munmap(sc.host_block, sc.host_bytes);
+  sc.host_block = sc.host_block_dev = nullptr;
+  if (sc.shm_fd >= 0) (void)close(sc.shm_fd);
+  sc.shm_fd = -1;
+  if (!sc.shm_name.empty()) (void)shm_unlink(sc.shm_name.c_str());  // ENOENT: a peer was first
+  sc.shm_name.clear();
+  sc.mode = c->comm ? MOPT_COMBINE_RCCL : MOPT_COMBINE_NONE;
+}
+
+}  // namespace mopt_detail
+
+extern "C" {
+
+int mopt_cost_hostcomm_attach(mopt_cost *c, const char *shm_name, int rank, int num_ranks) {
+  if (!c || !shm_name || shm_name[0] != '/')
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "cost is NULL or shm_name does not start with '/'");
+  int rc = checkRanks(c, rank, num_ranks, kMaxHostRanks);
+  if (rc != MOPT_OK) return rc;
+  ShardCombine &sc = c->combine;
+  if (sc.host_block) return fail(MOPT_ERR_INVALID_ARGUMENT, "a host slot block is already attached");
+  MOPT_HIP_TRY(hipSetDevice(c->device));
+  const size_t page = size_t(sysconf(_SC_PAGESIZE));
+  const size_t bytes =
+      (mopt::slotBlockDoubles(num_ranks) * sizeof(double) + page - 1) / page * page;
+  // A fresh object reads as zeros and sequence numbers start at 1, so nobody has to initialise it
+  // (and nobody may: a rank that attaches late must not wipe what an early one has published).
+  const int fd = shm_open(shm_name, O_CREAT | O_RDWR, 0600);
+  if (fd < 0) return fail(MOPT_ERR_HIP, std::string("shm_open: ") + std::strerror(errno));
+  if (ftruncate(fd, off_t(bytes)) != 0) {
+    const std::string why = std::strerror(errno);
+    close(fd);
+    return fail(MOPT_ERR_HIP, "ftruncate: " + why);
+  }
+  void *base = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  if (base == MAP_FAILED) {
+    const std::string why = std::strerror(errno);
+    close(fd);
+    return fail(MOPT_ERR_HIP, "mmap: " + why);
+  }
+  sc.shm_fd = fd;
+  sc.host_block = static_cast<double *>(base);
+  sc.host_bytes = bytes;
+  sc.shm_name = shm_name;
+  hipError_t e = hipHostRegister(base, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+  if (e == hipSuccess) {
+    sc.host_registered = true;
+    e = hipHostGetDevicePointer(reinterpret_cast<void **>(&sc.host_block_dev), base, 0);
+  }
+  if (e != hipSuccess) {
+    const std::string why = hipGetErrorString(e);
+    releaseCombine(c);
+    return fail(MOPT_ERR_HIP, "registering the shared slot block with HIP: " + why);
+  }
+  sc.rank = rank;
+  sc.num_ranks = num_ranks;
+  sc.mode = MOPT_COMBINE_HOST;
+  c->cache.valid = false;
+  return MOPT_OK;
+}
+
+int mopt_hostcomm_unlink(const char *shm_name) {
+  if (!shm_name) return fail(MOPT_ERR_INVALID_ARGUMENT, "shm_name is NULL");
+  if (shm_unlink(shm_name) != 0 && errno != ENOENT)
+    return fail(MOPT_ERR_HIP, std::string("shm_unlink: ") + std::strerror(errno));
+  return MOPT_OK;
+}
+
+int mopt_cost_peer_export(mopt_cost *c, int num_ranks, void *handle_out) {
+  if (!c || !handle_out) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (num_ranks < 1 || num_ranks > mopt::kMaxPeers)
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "the device-side combine spans at most 8 ranks (one node)");
+  ShardCombine &sc = c->combine;
+  if (sc.peer_own) return fail(MOPT_ERR_INVALID_ARGUMENT, "a peer slot block was already exported");
+  MOPT_HIP_TRY(hipSetDevice(c->device));
+  const size_t bytes = mopt::slotBlockDoubles(num_ranks) * sizeof(double);
+  // Uncached (MTYPE UC) memory: stores arriving over xGMI go to HBM, not through this device's
+  // L2, so the polling finalize kernel must not find the line in a cache either.
+  void *p = nullptr;
+  hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
+  }
+  if (e != hipSuccess)
+    return fail(MOPT_ERR_HIP, std::string("uncached slot block: ") + hipGetErrorString(e));
+  sc.peer_own = static_cast<double *>(p);
+  e = hipMemset(p, 0, bytes);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  hipIpcMemHandle_t handle;
+  if (e == hipSuccess) e = hipIpcGetMemHandle(&handle, p);
+  if (e != hipSuccess) {
+    (void)hipFree(p);
+    sc.peer_own = nullptr;
+    return fail(MOPT_ERR_HIP, std::string("exporting the slot block (hipIpcGetMemHandle): ") +
+                                  hipGetErrorString(e));
+  }
+  std::memcpy(handle_out, &handle, sizeof handle);
+  return MOPT_OK;
+}
+
+int mopt_cost_peer_attach(mopt_cost *c, const void *handles, int rank, int num_ranks) {
+  if (!c || !handles) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
+  int rc = checkRanks(c, rank, num_ranks, mopt::kMaxPeers);
+  if (rc != MOPT_OK) return rc;
+  ShardCombine &sc = c->combine;
+  if (!sc.peer_own) return fail(MOPT_ERR_INVALID_ARGUMENT, "call mopt_cost_peer_export first");
+  if (sc.peer_attached) return fail(MOPT_ERR_INVALID_ARGUMENT, "peers are already attached");
+  MOPT_HIP_TRY(hipSetDevice(c->device));
+  const char *bytes = static_cast<const char *>(handles);
+  for (int k = 0; k < num_ranks; ++k) {
+    if (k == rank) {
+      sc.peer_blocks[k] = sc.peer_own;
+      continue;
+    }
+    hipIpcMemHandle_t handle;
+    std::memcpy(&handle, bytes + size_t(k) * sizeof handle, sizeof handle);
+    void *p = nullptr;
+    const hipError_t e = hipIpcOpenMemHandle(&p, handle, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      for (int q = 0; q < k; ++q) {
+        if (sc.peer_opened[q]) (void)hipIpcCloseMemHandle(sc.peer_blocks[q]);
+        sc.peer_opened[q] = false;
+        sc.peer_blocks[q] = nullptr;
+      }
+      return fail(MOPT_ERR_HIP, "opening the slot block of rank " + std::to_string(k) +
+                                    " (hipIpcOpenMemHandle): " + hipGetErrorString(e));
+    }
+    sc.peer_blocks[k] = static_cast<double *>(p);
+    sc.peer_opened[k] = true;
+  }
+  sc.peer_timeout_ticks = peerTimeoutTicks(c->device);
+  sc.peer_attached = true;
+  sc.rank = rank;
+  sc.num_ranks = num_ranks;
+  sc.mode = MOPT_COMBINE_PEER;
+  c->cache.valid = false;
+  return MOPT_OK;
+}
+
+int mopt_cost_set_combine(mopt_cost *c, int mode) {
+  if (!c) return fail(MOPT_ERR_INVALID_ARGUMENT, "cost is NULL");
+  const bool ok = mode == MOPT_COMBINE_NONE || (mode == MOPT_COMBINE_RCCL && c->comm) ||
+                  ((mode == MOPT_COMBINE_HOST || mode == MOPT_COMBINE_PEER) && c->combine.has(mode));
+  if (!ok) return fail(MOPT_ERR_INVALID_ARGUMENT, "that combine transport is not attached to this cost");
+  if (c->combine.mode != mode) c->cache.valid = false;
+  c->combine.mode = mode;
+  return MOPT_OK;
+}
+
+int mopt_cost_get_combine(const mopt_cost *c, int *mode, int *rank, int *num_ranks) {
+  if (!c) return fail(MOPT_ERR_INVALID_ARGUMENT, "cost is NULL");
+  if (mode) *mode = c->combine.mode;
+  if (rank) *rank = c->combine.rank;
+  if (num_ranks) *num_ranks = c->combine.num_ranks;
+  return MOPT_OK;
+}
+
+}  // extern "C"

@@ -66,6 +66,31 @@ struct IcpMatcher {
   std::vector<long long> order;
 };
 
+// How the sums of a sharded cost are added over the ranks (MOPT_COMBINE_* of the header).
+struct ShardCombine {
+  int mode = MOPT_COMBINE_NONE;  // the transport blocking sweeps use now
+  int rank = 0, num_ranks = 1;
+  unsigned long long sequence = 0;  // collective sweeps so far; in step on every rank
+  // MOPT_COMBINE_HOST: slot block in POSIX shared memory, registered with HIP so that the
+  // finalize kernel of every rank publishes straight into it
+  std::string shm_name;
+  int shm_fd = -1;
+  double *host_block = nullptr;      // host address
+  double *host_block_dev = nullptr;  // the same memory as this device addresses it
+  size_t host_bytes = 0;
+  bool host_registered = false;
+  // MOPT_COMBINE_PEER: uncached device memory, one block per rank, opened over IPC
+  double *peer_own = nullptr;
+  double *peer_blocks[mopt::kMaxPeers] = {nullptr};
+  bool peer_opened[mopt::kMaxPeers] = {false};
+  bool peer_attached = false;
+  unsigned long long peer_timeout_ticks = 0;
+  bool has(int m) const {
+    return m == MOPT_COMBINE_HOST ? host_block != nullptr
+                                  : (m == MOPT_COMBINE_PEER ? peer_attached : false);
+  }
+};
+
 struct mopt_cost {
   int device = 0;
   int scalar_bytes = 8;
@@ -92,6 +117,9 @@ struct mopt_cost {
   hipStream_t stream = nullptr;
   ncclComm_t comm = nullptr;  // multi-process shard group (one rank per GPU), optional
   int comm_size = 1;
+  ShardCombine combine;  // latency-optimised alternatives to the RCCL all-reduce (combine.cpp)
+  // set around the launches of one sweep: the finalize kernel then also adds over the ranks
+  const mopt::PeerCombine *launch_peers = nullptr;
 
   double cov[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // row-major, stride 3 (m <= 3), as double
   double cov_m[16] = {1};                        // row-major m x m compact (scalar models, m <= 4)
@@ -163,6 +191,7 @@ void deviceRelease(void *p);
 int commonCreate(mopt_cost *c, int device);  // device, stream, partial / result buffers
 // wait for everything enqueued for this cost, on its own stream and on callers' streams
 hipError_t quiesceCost(mopt_cost *c);
+void releaseCombine(mopt_cost *c);  // combine.cpp: unmaps / closes whatever was attached
 void destroyCost(mopt_cost *c);
 // enqueue one linearization / cost sweep + its finalize on `s`; results to d_result (+ optional
 // hand-over to mapped host memory)

@@ -124,6 +124,41 @@ struct HostPublish {
   double *host_result = nullptr;           // mapped, fine-grained host memory (device pointer)
   unsigned long long *host_flag = nullptr;
   unsigned long long sequence = 0;
+  unsigned long long *host_status = nullptr;  // optional: receives kStatus* before the flag
+};
+
+// ---- shard combine without a collective launch ----------------------------------------------
+// A sweep over sharded correspondences ends in n*n + n + 1 sums per rank that must be added over
+// the ranks (the host accumulation of levenberg_marquadt_dyn.cpp:57-59, across shards).  The
+// message is 344 bytes, so what matters is latency, not bandwidth: instead of a collective launch
+// behind the finalize kernel, every rank owns a block of *slots* — one per (parity, rank) — in
+// memory all ranks can store to (uncached device memory opened over IPC / peer access for the
+// device-side form, shared pinned host memory for the host-side form), and the finalize kernel
+// itself pushes its sums into its slot of every rank's block, write-through, followed by the
+// sequence number of the sweep.  Slots alternate with the parity of the sequence number: a rank
+// can only be one sweep ahead of the slowest reader (it needs that reader's flag of the sweep in
+// between), so a slot is never overwritten while someone may still read it.
+constexpr int kMaxPeers = 8;                    // one node: 8 GPUs
+constexpr int kSlotData = 96;                   // >= n*n + n + 1 for n <= 8
+constexpr int kSlotFlag = kSlotData;            // sequence word (as unsigned long long)
+constexpr int kSlotStatus = kSlotData + 1;      // 0 ok, kStatusPeerTimeout
+constexpr int kSlotDoubles = kSlotData + 16;    // 896 B: flag and status on their own 128-B line
+constexpr unsigned long long kStatusPeerTimeout = 1;
+__host__ __device__ inline size_t slotBlockDoubles(int num_ranks) { return size_t(2) * num_ranks * kSlotDoubles; }
+__host__ __device__ inline size_t slotIndex(unsigned long long sequence, int num_ranks, int rank) {
+  return (size_t(sequence & 1) * num_ranks + rank) * kSlotDoubles;
+}
+
+// Device-side combine, run by the (single-workgroup) finalize kernel: push this rank's sums into
+// slot (parity, rank) of every rank's block, then wait for the other ranks' flags in the own block
+// and add the G slots in rank order — every rank forms bit-identical totals.  num_ranks == 0: off.
+struct PeerCombine {
+  double *blocks[kMaxPeers] = {nullptr};  // [k]: rank k's slot block as THIS device addresses it
+  int rank = 0;
+  int num_ranks = 0;
+  int offset = 0;  // first value of this sweep inside a slot (0: H | b | sum_sq; n*n + n: cost only)
+  unsigned long long sequence = 0;
+  unsigned long long timeout_ticks = 0;  // of the 100 MHz wall clock; the wait is always bounded
 };
 
 // ---- launches (all asynchronous on `stream`) ------------------------------------------------
@@ -149,12 +184,16 @@ hipError_t launchReprojLinearize(const ReprojSweepArgs &args, int cov_mode, int 
 hipError_t launchReprojCost(const ReprojSweepArgs &args, int grid, const LaunchSite &site);
 
 // partials[grid][nacc] -> result[n*n + n + 1] (H column-major | b | sum_sq)
+// `peers` (optional): add the sums over the ranks inside the same kernel (PeerCombine above)
 hipError_t launchFinalizeDense(const double *partials, int grid, int nacc, int n, double *result,
-                               const HostPublish &pub, hipStream_t stream);
+                               const HostPublish &pub, hipStream_t stream,
+                               const PeerCombine *peers = nullptr);
 hipError_t launchFinalizeMoments(const double *partials, int grid, const AffineBasis &basis,
-                                 double *result, const HostPublish &pub, hipStream_t stream);
+                                 double *result, const HostPublish &pub, hipStream_t stream,
+                                 const PeerCombine *peers = nullptr);
 hipError_t launchFinalizeCost(const double *partials, int grid, double *result,
-                              const HostPublish &pub, hipStream_t stream);
+                              const HostPublish &pub, hipStream_t stream,
+                              const PeerCombine *peers = nullptr);
 // Small parametric models: one launch computes the workgroup partial rows of the linearization
 // (or of the cost when cost_only); finish with launchFinalizeDense(n) / launchFinalizeCost.
 template <typename S>

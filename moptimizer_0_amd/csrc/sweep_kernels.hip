@@ -704,13 +704,72 @@ __device__ __forceinline__ void storeSystem(double *p, double v) {
 // `v`.  Payload goes out write-through, every storing wave drains it (s_waitcnt vmcnt(0)), the
 // workgroup meets at a barrier, then one lane stores the sequence word — the payload is complete
 // before the flag is issued (cdna_hip_programming.md Guideline 16, form R1, at system scope).
-__device__ __forceinline__ void publishToHost(const HostPublish &pub, int count, double v) {
+__device__ __forceinline__ void publishToHost(const HostPublish &pub, int count, double v,
+                                              unsigned long long status = 0) {
   if (pub.host_flag == nullptr) return;
   if (int(threadIdx.x) < count && pub.host_result) storeSystem(pub.host_result + threadIdx.x, v);
+  if (threadIdx.x == 0 && pub.host_status)
+    __hip_atomic_store(pub.host_status, status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0)
     __hip_atomic_store(pub.host_flag, pub.sequence, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__device__ __forceinline__ double loadSystem(const double *p) {
+  return __longlong_as_double(static_cast<long long>(
+      __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                        __HIP_MEMORY_SCOPE_SYSTEM)));
+}
+
+// Sum of `v` over the ranks (sweep.hpp, PeerCombine), by the single finalize workgroup; threads
+// k < count hold value k.  Same producer form as publishToHost (write-through payload, every
+// storing wave drained, barrier, then the sequence word), here into every rank's slot block;
+// the consumer side polls the G flags of the own block with system-scope loads from one lane
+// each, sleeps between polls, gives up after timeout_ticks (the wait must end on every path: a
+// peer that never arrives turns into kStatusPeerTimeout and NaN sums, not into a hung GPU), and
+// then adds the G slots in rank order.
+__device__ __forceinline__ double peerCombine(const PeerCombine &pc, int count, double v,
+                                              unsigned long long *status) {
+  *status = 0;
+  if (pc.num_ranks <= 0) return v;
+  __shared__ double *peer_block[kMaxPeers];
+  __shared__ int timed_out;
+  const int tid = threadIdx.x;
+  const int G = pc.num_ranks;
+  if (tid < kMaxPeers) peer_block[tid] = pc.blocks[tid < G ? tid : 0];
+  if (tid == 0) timed_out = 0;
+  __syncthreads();
+  const size_t mine = slotIndex(pc.sequence, G, pc.rank);
+  if (tid < count)
+    for (int p = 0; p < G; ++p) storeSystem(peer_block[p] + mine + pc.offset + tid, v);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  double *own = peer_block[pc.rank];
+  if (tid < G) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(peer_block[tid] + mine + kSlotFlag),
+                       pc.sequence, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long *flag = reinterpret_cast<const unsigned long long *>(
+        own + slotIndex(pc.sequence, G, tid) + kSlotFlag);
+    const unsigned long long started = wall_clock64();
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < pc.sequence) {
+      if (wall_clock64() - started > pc.timeout_ticks) {
+        timed_out = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(4);
+    }
+  }
+  __syncthreads();
+  double total = 0.0;
+  if (tid < count)
+    for (int k = 0; k < G; ++k)
+      total += loadSystem(own + slotIndex(pc.sequence, G, k) + pc.offset + tid);
+  if (timed_out) {
+    *status = kStatusPeerTimeout;
+    total = __builtin_nan("");
+  }
+  return total;
 }
 
 __device__ __forceinline__ void columnTotals(const double *partials, int grid, int nacc,
@@ -748,7 +807,8 @@ __device__ __forceinline__ void columnTotals(const double *partials, int grid, i
 __global__ __launch_bounds__(kFinalThreads) void finalizeDenseKernel(const double *partials,
                                                                       int grid, int nacc, int n,
                                                                       double *result,
-                                                                      const HostPublish pub) {
+                                                                      const HostPublish pub,
+                                                                      const PeerCombine pc) {
   __shared__ double scratch[kFinalThreads];
   __shared__ double total[kMaxAccumulators];
   columnTotals(partials, grid, nacc, scratch, total);
@@ -769,9 +829,11 @@ __global__ __launch_bounds__(kFinalThreads) void finalizeDenseKernel(const doubl
     } else {
       v = total[nh + (k - n * n)];  // b (n) then sum_sq
     }
-    result[k] = v;
   }
-  publishToHost(pub, count, v);
+  unsigned long long status;
+  v = peerCombine(pc, count, v, &status);
+  if (k < count) result[k] = v;
+  publishToHost(pub, count, v, status);
 }
 
 // Moments -> H, b.  With p_0 = 1:  W(a,b) = sum w p_a p_b,  V(a,c) = sum w p_a r_c  and
@@ -781,7 +843,8 @@ __global__ __launch_bounds__(kFinalThreads) void finalizeMomentsKernel(const dou
                                                                         int grid,
                                                                         const AffineBasis B,
                                                                         double *result,
-                                                                        const HostPublish pub) {
+                                                                        const HostPublish pub,
+                                                                        const PeerCombine pc) {
   __shared__ double scratch[kFinalThreads];
   __shared__ double total[kMaxAccumulators];
   __shared__ double terms[36 * 16 + 6 * 4];
@@ -834,14 +897,17 @@ __global__ __launch_bounds__(kFinalThreads) void finalizeMomentsKernel(const dou
     } else {
       v = total[22];
     }
-    result[t] = v;
   }
-  publishToHost(pub, kResultDoubles, v);
+  unsigned long long status;
+  v = peerCombine(pc, kResultDoubles, v, &status);
+  if (t < kResultDoubles) result[t] = v;
+  publishToHost(pub, kResultDoubles, v, status);
 }
 
 __global__ __launch_bounds__(kFinalThreads) void finalizeCostKernel(const double *partials,
                                                                      int grid, double *result,
-                                                                     const HostPublish pub) {
+                                                                     const HostPublish pub,
+                                                                     const PeerCombine pc) {
   __shared__ double lds[kFinalThreads / 64];
   double s = 0.0;
   for (int row = threadIdx.x; row < grid; row += kFinalThreads) s += partials[row];
@@ -852,11 +918,13 @@ __global__ __launch_bounds__(kFinalThreads) void finalizeCostKernel(const double
     double v = 0.0;
 #pragma unroll
     for (int k = 0; k < kFinalThreads / 64; ++k) v += lds[k];
-    result[0] = v;
     lds[0] = v;
   }
   __syncthreads();
-  publishToHost(pub, 1, lds[0]);
+  unsigned long long status;
+  const double v = peerCombine(pc, 1, lds[0], &status);
+  if (threadIdx.x == 0) result[0] = v;
+  publishToHost(pub, 1, v, status);
 }
 
 __global__ void publishKernel(const double *values, int count, const HostPublish pub) {
@@ -979,25 +1047,28 @@ hipError_t launchReprojCost(const ReprojSweepArgs &args, int grid, const LaunchS
 }
 
 hipError_t launchFinalizeDense(const double *partials, int grid, int nacc, int n, double *result,
-                               const HostPublish &pub, hipStream_t stream) {
+                               const HostPublish &pub, hipStream_t stream,
+                               const PeerCombine *peers) {
   if (n < 1 || n > kMaxParams || (nacc != n * (n + 1) / 2 + n + 1 && nacc != n * n + n + 1))
     return hipErrorInvalidValue;
   hipLaunchKernelGGL(finalizeDenseKernel, dim3(1), dim3(kFinalThreads), 0, stream, partials, grid,
-                     nacc, n, result, pub);
+                     nacc, n, result, pub, peers ? *peers : PeerCombine());
   return hipGetLastError();
 }
 
 hipError_t launchFinalizeMoments(const double *partials, int grid, const AffineBasis &basis,
-                                 double *result, const HostPublish &pub, hipStream_t stream) {
+                                 double *result, const HostPublish &pub, hipStream_t stream,
+                                 const PeerCombine *peers) {
   hipLaunchKernelGGL(finalizeMomentsKernel, dim3(1), dim3(kFinalThreads), 0, stream, partials,
-                     grid, basis, result, pub);
+                     grid, basis, result, pub, peers ? *peers : PeerCombine());
   return hipGetLastError();
 }
 
 hipError_t launchFinalizeCost(const double *partials, int grid, double *result,
-                              const HostPublish &pub, hipStream_t stream) {
+                              const HostPublish &pub, hipStream_t stream,
+                              const PeerCombine *peers) {
   hipLaunchKernelGGL(finalizeCostKernel, dim3(1), dim3(kFinalThreads), 0, stream, partials, grid,
-                     result, pub);
+                     result, pub, peers ? *peers : PeerCombine());
   return hipGetLastError();
 }
 

@@ -75,3 +75,58 @@ def gpu_point2point_sweep(cost, jac_mode_default=None):
 
     dev = torch.device("cuda", torch.cuda.current_device())
     return ShardedSweep(lin, cst, device=dev)
+
+
+def _all_agree(ok, group=None):
+    """True only if every rank says ok (MIN all-reduce; on the device with RCCL, on the host with
+    gloo)."""
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return int(t.item()) == 1
+
+
+def attach_combines(cost, rank, world, want=("host", "peer", "rccl"), group=None, log=None):
+    """Attach the shard-combine transports of include/moptimizer_hip.h to this rank's cost, using
+    torch.distributed only as the side channel (a name, IPC handles, an RCCL id).  A transport
+    counts only if EVERY rank attached it.  Returns the list of usable transports, in `want` order;
+    collective: every rank calls it with the same arguments.  RCCL cannot span ranks that share a
+    GPU, so it is only tried with the "nccl" backend (one rank per GPU)."""
+    from . import _capi as capi
+    import os
+    usable = []
+    for name in want:
+        ok, err = True, None
+        try:
+            if name == "host":
+                tag = [("/mopt-%d-%x" % (os.getpid(), int.from_bytes(os.urandom(4), "little")))
+                       if rank == 0 else None]
+                dist.broadcast_object_list(tag, src=0, group=group)
+                cost.hostcomm_attach(tag[0], rank, world)
+            elif name == "peer":
+                mine, err = None, None
+                try:
+                    mine = cost.peer_export(world)
+                except Exception as e:  # still take part in the gather below
+                    err = e
+                handles = [None] * world
+                dist.all_gather_object(handles, mine, group=group)
+                if err is not None or any(h is None for h in handles):
+                    raise err or RuntimeError("a rank could not export its slot block")
+                cost.peer_attach(handles, rank, world)
+            elif name == "rccl":
+                if dist.get_backend(group) != "nccl":
+                    raise RuntimeError("ranks share GPUs (rehearsal backend): RCCL not attempted")
+                ids = [capi.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0, group=group)
+                cost.comm_init_rank(ids[0], rank, world)
+            else:
+                raise ValueError(name)
+        except Exception as e:
+            ok, err = False, e
+        if _all_agree(ok, group):
+            usable.append(name)
+        elif log is not None:
+            log("rank %d: combine transport %r unavailable (%s)" % (rank, name, err or "on a peer"))
+    dist.barrier(group=group)  # nobody sweeps before everybody has attached
+    return usable

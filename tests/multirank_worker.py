@@ -1,0 +1,90 @@
+"""One rank of the multi-process shard-combine tests (tests/test_gpu_multirank.py starts two or
+more of these as fresh processes).  Ranks may share a GPU: the host and peer combines work between
+processes on one device (same-device IPC); RCCL is only attempted when every rank has a GPU of its
+own.  Writes what it computed to <out>/rank<k>.npz for the parent to compare."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, world, out = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), sys.argv[1]
+    n_total = int(sys.argv[2])
+    import torch
+    import torch.distributed as dist
+
+    import moptimizer_0_amd as mo
+    from moptimizer_0_amd.sharded import attach_combines, shard_range
+    from tests import datasets as ds
+
+    ndev = torch.cuda.device_count()
+    own_gpu = ndev >= world
+    device = rank if own_gpu else 0
+    torch.cuda.set_device(device)
+    dist.init_process_group("gloo")
+    src, tgt = ds.synthetic_pair(n_total, seed=11, noise=0.02)
+    lo, hi = shard_range(n_total, rank, world)
+    cost = mo.Point2PointCost(src[lo:hi], tgt[lo:hi], device=device)
+    cost.set_loss(mo.LOSS_GEMAN_MCCLURE, 50.0)
+    want = ("host", "peer", "rccl") if own_gpu else ("host", "peer")
+    notes = []
+    usable = attach_combines(cost, rank, world, want=want, log=notes.append)
+    res = {"usable": np.array(usable), "notes": np.array(notes)}
+    modes = {"host": mo.COMBINE_HOST, "peer": mo.COMBINE_PEER, "rccl": mo.COMBINE_RCCL}
+    xs = [ds.X_ZERO, ds.X_GENERIC, ds.X_GENERIC * 0.3]
+    for name in usable:
+        cost.set_combine(modes[name])
+        cost.set_speculation(False)
+        for jm in (mo.JAC_ANALYTIC, mo.JAC_NUMERIC):
+            for xi, x in enumerate(xs):
+                H, b, s = cost.linearize(x, jm)
+                c = cost.compute_cost(x)
+                res["%s_H_%d_%d" % (name, jm, xi)] = H
+                res["%s_b_%d_%d" % (name, jm, xi)] = b
+                res["%s_s_%d_%d" % (name, jm, xi)] = np.array([s, c])
+        # the LM pattern with speculation: computeCost(x) then linearize(x) answered from the kept
+        # result, on every rank alike (the kept result holds the sums of ALL ranks)
+        cost.set_speculation(True)
+        x = ds.X_GENERIC * 0.7
+        cost.linearize(x * 0.5, mo.JAC_NUMERIC)
+        sweeps0, hits0 = cost.stats()
+        c = cost.compute_cost(x)
+        H, b, s = cost.linearize(x, mo.JAC_NUMERIC)
+        sweeps1, hits1 = cost.stats()
+        res[name + "_spec"] = np.array([sweeps1 - sweeps0, hits1 - hits0, c, s])
+        res[name + "_spec_H"] = H
+        # many sweeps back to back: slot parity / sequence bookkeeping
+        acc = 0.0
+        cost.set_speculation(False)
+        for k in range(200):
+            acc += cost.compute_cost(ds.X_GENERIC * (0.01 * k))
+        res[name + "_chain"] = np.array([acc])
+    dist.barrier()
+    if rank == 0:
+        # what the sums must be: the same shards, in one process, added on the host in shard order
+        group = mo.Point2PointGroup(src, tgt, [0] * world)
+        group.set_loss(mo.LOSS_GEMAN_MCCLURE, 50.0)
+        for jm in (mo.JAC_ANALYTIC, mo.JAC_NUMERIC):
+            for xi, x in enumerate(xs):
+                H, b, s = group.linearize(x, jm)
+                c = group.compute_cost(x)
+                res["group_H_%d_%d" % (jm, xi)] = H
+                res["group_b_%d_%d" % (jm, xi)] = b
+                res["group_s_%d_%d" % (jm, xi)] = np.array([s, c])
+        acc = 0.0
+        for k in range(200):
+            acc += group.compute_cost(ds.X_GENERIC * (0.01 * k))
+        res["group_chain"] = np.array([acc])
+        group.close()
+    np.savez(os.path.join(out, "rank%d.npz" % rank), **res)
+    dist.barrier()  # nobody releases its slot blocks while a peer may still push into them
+    cost.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

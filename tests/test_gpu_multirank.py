@@ -1,0 +1,108 @@
+"""The library's own multi-rank paths with MORE THAN ONE RANK: fresh processes, one shard each,
+the 43 sums added over the ranks by the fused combines of include/moptimizer_hip.h
+(MOPT_COMBINE_HOST: shared pinned host slots; MOPT_COMBINE_PEER: HBM slots opened over IPC) and,
+when every rank has a GPU of its own, by the RCCL all-reduce.  Replaces the host accumulation of
+levenberg_marquadt_dyn.cpp:57-59 across shards.  On a one-GPU box the ranks share the device (the
+host and peer combines work there; RCCL refuses, and is skipped)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import datasets as ds
+
+pytestmark = pytest.mark.gpu
+
+
+def run_ranks(tmp_path, world, n_total, extra_env=None, timeout=420):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen(
+            [sys.executable, os.path.join(ds.ROOT, "tests", "multirank_worker.py"), str(tmp_path),
+             str(n_total)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out.decode())
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, outs[r][-3000:])
+    return [np.load(os.path.join(tmp_path, "rank%d.npz" % r)) for r in range(world)]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_combine_through_the_library(hip_lib, tmp_path, world):
+    res = run_ranks(tmp_path, world, 200_003)
+    usable = list(res[0]["usable"])
+    assert "host" in usable and "peer" in usable, (usable, list(res[0]["notes"]))
+    for r in range(1, world):
+        assert list(res[r]["usable"]) == usable
+    for name in usable:
+        for jm in (0, 2):
+            for xi in range(3):
+                for part in "Hbs":
+                    key = "%s_%s_%d_%d" % (name, part, jm, xi)
+                    want = res[0]["group_%s_%d_%d" % (part, jm, xi)]
+                    for r in range(world):
+                        # bit-equal: same shards, same kernels, same order of the G additions
+                        assert res[r][key].tobytes() == want.tobytes(), (key, r)
+        for r in range(world):
+            sweeps, hits, c, s = res[r][name + "_spec"]
+            assert (sweeps, hits) == (1, 1), (name, r, sweeps, hits)  # one sweep answered both calls
+            assert c == s
+            assert res[r][name + "_spec_H"].tobytes() == res[0][name + "_spec_H"].tobytes()
+            assert res[r][name + "_chain"].tobytes() == res[0]["group_chain"].tobytes()
+
+
+def test_sharded_sums_match_the_unsharded_cost(hip_lib, tmp_path, oracle):
+    """Shard-invariance against the oracle on the whole data set (1e-6 bar; the sums differ from a
+    single-cost sweep only by fp64 reassociation)."""
+    from tests import oracle_binding as ob
+    n = 200_003
+    res = run_ranks(tmp_path, 2, n)
+    src, tgt = ds.synthetic_pair(n, seed=11, noise=0.02)
+    xs = [ds.X_ZERO, ds.X_GENERIC, ds.X_GENERIC * 0.3]
+    for xi, x in enumerate(xs):
+        Hr, br, sr = oracle.p2p_linearize(src, tgt, x, cost_class=ob.ANALYTIC_DYN,
+                                          layout=ob.LAYOUT_ROW_MAJOR, loss_kind=1, loss_param=50.0)
+        for name in ("host", "peer"):
+            H = res[1]["%s_H_0_%d" % (name, xi)]
+            b = res[1]["%s_b_0_%d" % (name, xi)]
+            s = res[1]["%s_s_0_%d" % (name, xi)]
+            assert np.abs(H - Hr).max() <= 1e-6 * np.abs(Hr).max()
+            assert np.abs(b - br).max() <= 1e-6 * np.abs(br).max()
+            assert abs(s[0] - sr) <= 1e-6 * sr and abs(s[1] - sr) <= 1e-6 * sr
+
+
+def test_bench_launches_its_own_ranks(hip_lib):
+    """`python bench.py --gpus 2` without a launcher (as the driver calls it), rehearsed on however
+    many GPUs this box has: one JSON line, n_gpus = 2, a fused combine selected."""
+    import json
+    env = dict(os.environ)
+    import torch
+    if torch.cuda.device_count() < 2:
+        env["MOPT_BENCH_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(ds.ROOT, "bench.py"), "--gpus", "2",
+                          "--steps", "20", "--warmup", "3", "--n", "300000", "--settle-ms", "5"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["collective"] in ("host", "peer")
+    assert line["check"]["H00"] == 600000.0  # both shards were summed
+    assert set(line["ms_per_step_by_collective"]) >= {"none", "host", "peer"}
+    assert line["config4_strong"]["total_correspondences"] == 10_000_000
