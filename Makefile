@@ -33,8 +33,11 @@ $(OBJDIR)/%.o: $(CSRC)/%.cpp $(PUBLIC_HEADERS) | $(OBJDIR)
 $(OBJDIR)/icp_grid.o: $(CSRC)/icp_grid.hip $(PUBLIC_HEADERS) | $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) $(INCLUDES) -c $< -o $@
 
+$(OBJDIR)/lm_kernels.o: $(CSRC)/lm_kernels.hip $(PUBLIC_HEADERS) | $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) $(INCLUDES) -c $< -o $@
+
 OBJS = $(OBJDIR)/sweep_kernels.o $(OBJDIR)/icp_grid.o $(OBJDIR)/c_abi.o $(OBJDIR)/icp.o \
-       $(OBJDIR)/group.o $(OBJDIR)/jit_model.o $(OBJDIR)/device_pool.o $(OBJDIR)/combine.o
+       $(OBJDIR)/group.o $(OBJDIR)/jit_model.o $(OBJDIR)/device_pool.o $(OBJDIR)/combine.o $(OBJDIR)/lm.o $(OBJDIR)/lm_kernels.o
 
 $(LIB): $(OBJS) | $(LIBDIR)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -L$(ROCM)/lib -lrccl -lhiprtc -lpthread -lrt \

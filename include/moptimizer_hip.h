@@ -312,6 +312,49 @@ MOPT_API int mopt_cost_set_combine(mopt_cost *cost, int combine_mode);
 MOPT_API int mopt_cost_get_combine(const mopt_cost *cost, int *combine_mode, int *rank,
                                    int *num_ranks);
 
+/* ---- device-resident Levenberg-Marquardt ----------------------------------------------------
+ *
+ * An additive entry point next to the boundary above (which stays what the reference's LM loop
+ * calls): the whole of LevenbergMarquadtDynamic<Scalar>::minimize
+ * (src/levenberg_marquadt_dyn.cpp:34-119) with the iteration taken on the device.  Behind every
+ * sweep a one-workgroup kernel adds the costs' H | b | sum_sq (:48-60), solves
+ * (H + lambda diag H) delta = -b by pivoted LDL^T (:78-80), forms the trial point (:83), evaluates
+ * the gain ratio and the accept / reject / stop logic (:86-115) and writes the transforms and
+ * forward-difference constants of the next sweep into HBM; sweeps are queued ahead and read their
+ * constants from there.  The host takes no decision and sees only the final x.  Each point is
+ * evaluated once, with the linearization sweep (it also yields sum r^T r).
+ *
+ * costs / jacobian_modes: the costs of Optimizer::addCost (optimizer.h:58) with the Jacobian mode
+ * of each (the cost class the caller would have used), at most 4, same device / scalar type / n;
+ * point2point, reprojection and the built-in scalar models (not ICP costs, whose update(x) step
+ * is driven from the host, nor run-time compiled models).  x: n scalars, in: x0, out: the result.
+ * For sharded costs select MOPT_COMBINE_PEER first: every rank then runs the identical loop on
+ * bit-identical sums (collective call).
+ * report->status takes the values of moptimizer::OptimizationStatus (types.h:6-12). */
+enum mopt_lm_status {
+  MOPT_LM_CONVERGED = 0,
+  MOPT_LM_MAXIMUM_ITERATIONS_REACHED = 1,
+  MOPT_LM_SMALL_DELTA = 2,
+  MOPT_LM_NUMERIC_ERROR = 3,
+  MOPT_LM_FATAL_ERROR = 4
+};
+typedef struct mopt_lm_options {
+  int max_iterations;    /* Optimizer::setMaximumIterations, default 15 (optimizer.h:19)        */
+  int lm_max_iterations; /* setLevenbergMarquadtIterations, default 3 (levenberg_marquadt_dyn.cpp:9) */
+  int manifold;          /* 0: xi = x0 + delta as the reference (:83)                            */
+  int window;            /* trial points queued ahead of the device; 0 = default (3)             */
+} mopt_lm_options;
+typedef struct mopt_lm_report {
+  int status;     /* mopt_lm_status */
+  int iterations; /* Optimizer::getExecutedIterations */
+  int64_t sweeps; /* points evaluated (one sweep per cost each) */
+  double cost;    /* sum of squares at the returned x */
+  double lambda;  /* final damping */
+} mopt_lm_report;
+MOPT_API int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian_modes,
+                              void *x, const mopt_lm_options *options /* NULL = defaults */,
+                              mopt_lm_report *report /* may be NULL */);
+
 /* ---- measurement -------------------------------------------------------------------------- */
 
 /* With profiling on, sweep kernel launches are bracketed by HIP events recorded on their stream:

@@ -25,6 +25,18 @@ RESULT_DOUBLES = 43
 
 _lib = None
 
+LM_CONVERGED, LM_MAXIMUM_ITERATIONS_REACHED, LM_SMALL_DELTA, LM_NUMERIC_ERROR, LM_FATAL_ERROR = range(5)
+
+
+class LmOptions(ctypes.Structure):
+    _fields_ = [("max_iterations", ctypes.c_int), ("lm_max_iterations", ctypes.c_int),
+                ("manifold", ctypes.c_int), ("window", ctypes.c_int)]
+
+
+class LmReport(ctypes.Structure):
+    _fields_ = [("status", ctypes.c_int), ("iterations", ctypes.c_int), ("sweeps", ctypes.c_int64),
+                ("cost", ctypes.c_double), ("lambda_", ctypes.c_double)]
+
 
 class MoptError(RuntimeError):
     pass
@@ -97,6 +109,9 @@ def load():
         "mopt_cost_set_combine": [ctypes.c_void_p, ctypes.c_int],
         "mopt_cost_get_combine": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int),
                                   ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)],
+        "mopt_lm_minimize": [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int,
+                             ctypes.POINTER(ctypes.c_int), ctypes.c_void_p,
+                             ctypes.POINTER(LmOptions), ctypes.POINTER(LmReport)],
         "mopt_cost_set_profiling": [ctypes.c_void_p, ctypes.c_int],
         "mopt_cost_profile": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
                               ctypes.POINTER(ctypes.c_int64)],
@@ -161,6 +176,22 @@ def se3_from_params(x, with_steps=False, dtype=np.float64):
     check(load().mopt_se3_from_params(x.itemsize, _ptr(x), _ptr(T), _ptr(Tp), _ptr(h)))
     return (T.reshape(4, 4, order="F"),
             [Tp[16 * j:16 * j + 16].reshape(4, 4, order="F") for j in range(6)], h)
+
+
+def lm_minimize(costs, jac_modes, x0, max_iterations=15, lm_max_iterations=3, window=0):
+    """Device-resident LevenbergMarquadtDynamic::minimize over `costs` (mopt_lm_minimize).
+    Returns (x, report dict)."""
+    costs = list(costs)
+    dt = _dtype_of(costs[0].scalar_bytes)
+    x = np.array(x0, dtype=dt).copy()
+    handles = (ctypes.c_void_p * len(costs))(*[c._h for c in costs])
+    modes = (ctypes.c_int * len(costs))(*[int(m) for m in jac_modes])
+    opt = LmOptions(int(max_iterations), int(lm_max_iterations), 0, int(window))
+    rep = LmReport()
+    check(load().mopt_lm_minimize(handles, len(costs), modes, _ptr(x), ctypes.byref(opt),
+                                  ctypes.byref(rep)))
+    return x, dict(status=rep.status, iterations=rep.iterations, sweeps=rep.sweeps, cost=rep.cost,
+                   lambda_=rep.lambda_)
 
 
 def _dtype_of(scalar_bytes):

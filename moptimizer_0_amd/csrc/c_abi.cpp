@@ -620,6 +620,209 @@ int blockingSweep(mopt_cost *c, bool cost_only, int jac_mode, const void *x) {
 }  // namespace
 
 namespace mopt_detail {
+
+// ---- resident sweeps for the device-resident LM (lm.cpp) ---------------------------------------
+namespace {
+template <typename Args>
+int uploadArgs(mopt_cost *c, const Args &host_value, hipStream_t s) {
+  if (!c->d_lm_args) MOPT_HIP_TRY(deviceAlloc(&c->d_lm_args, 2048));  // >= every Args struct
+  static_assert(sizeof(Args) <= 2048, "resident argument block too small");
+  MOPT_HIP_TRY(mopt::launchStoreArgs<Args>(host_value, static_cast<Args *>(c->d_lm_args), s));
+  return MOPT_OK;
+}
+
+template <typename S>
+int residentPrepareP2P(mopt_cost *c, int jac_mode, bool moments, hipStream_t s) {
+  mopt::P2PSweepArgs<S> args;
+  const S zero[kNumParams] = {0, 0, 0, 0, 0, 0};
+  fillP2PArgs<S>(c, zero, false, args);  // data, loss, covariance; the step kernel writes T, 1/h
+  int rc = uploadArgs(c, args, s);
+  if (rc != MOPT_OK) return rc;
+  if (moments) {
+    mopt::AffineBasis basis;
+    // analytic modes: the whole basis is independent of x; forward differences: the step kernel
+    // rewrites J per point and only the covariance stays
+    fillBasis<S>(c, jac_mode == MOPT_JAC_NUMERIC ? MOPT_JAC_ANALYTIC : jac_mode, args, basis);
+    if (!c->d_lm_basis)
+      MOPT_HIP_TRY(deviceAlloc(reinterpret_cast<void **>(&c->d_lm_basis), sizeof(mopt::AffineBasis)));
+    MOPT_HIP_TRY(mopt::launchStoreArgs<mopt::AffineBasis>(basis, c->d_lm_basis, s));
+  }
+  return MOPT_OK;
+}
+
+bool usesMoments(const mopt_cost *c) { return c->variant != MOPT_KERNEL_LITERAL; }
+}  // namespace
+
+int residentPrepare(mopt_cost *c, int jac_mode, hipStream_t s, mopt::LmCostDesc *desc) {
+  if (jac_mode < MOPT_JAC_ANALYTIC || jac_mode > MOPT_JAC_NUMERIC)
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "unknown jacobian_mode");
+  if (c->matcher)
+    return fail(MOPT_ERR_UNSUPPORTED,
+                "mopt_lm_minimize: an ICP cost re-matches on the host side of update(x); drive it "
+                "with the host LM loop");
+  desc->jac_mode = jac_mode;
+  desc->n_out = c->n_out;
+  desc->moments = 0;
+  desc->result = c->d_result;
+  int rc = MOPT_OK;
+  const bool stale =
+      c->lm_uploaded_version != c->state_version || c->lm_uploaded_mode != jac_mode || !c->d_lm_args;
+  switch (c->model) {
+    case kModelPoint2Point: {
+      desc->model = mopt::kLmPoint2Point;
+      desc->moments = usesMoments(c) ? 1 : 0;
+      if (stale)
+        rc = c->scalar_bytes == 8 ? residentPrepareP2P<double>(c, jac_mode, desc->moments, s)
+                                  : residentPrepareP2P<float>(c, jac_mode, desc->moments, s);
+      break;
+    }
+    case kModelReprojection: {
+      if (jac_mode != MOPT_JAC_NUMERIC)
+        return fail(MOPT_ERR_UNSUPPORTED,
+                    "the reprojection model has no analytic Jacobian (BaseModel, numeric only)");
+      desc->model = mopt::kLmReprojection;
+      std::memcpy(desc->camera, c->camera, sizeof desc->camera);
+      std::memcpy(desc->frame, c->frame, sizeof desc->frame);
+      if (stale) {
+        mopt::ReprojSweepArgs args;
+        const double zero[kNumParams] = {0, 0, 0, 0, 0, 0};
+        fillReprojArgs(c, zero, false, args);
+        rc = uploadArgs(c, args, s);
+      }
+      break;
+    }
+    case kModelScalar: {
+      if (jac_mode == MOPT_JAC_ANALYTIC_TST_LAYOUT)
+        return fail(MOPT_ERR_UNSUPPORTED,
+                    "the as-written point2point layout applies to point2point only");
+      if (jac_mode == MOPT_JAC_ANALYTIC && !scalarModelHasJacobian(c->scalar_model))
+        return fail(MOPT_ERR_UNSUPPORTED,
+                    "Non implemented non-jacobian model function `f_df` being used.");
+      desc->model = mopt::kLmScalar;
+      if (stale) {
+        if (c->scalar_bytes == 8) {
+          mopt::ScalarSweepArgs<double> args;
+          const double zero[mopt::kMaxParams] = {0};
+          fillScalarArgs<double>(c, zero, args);
+          rc = uploadArgs(c, args, s);
+        } else {
+          mopt::ScalarSweepArgs<float> args;
+          const float zero[mopt::kMaxParams] = {0};
+          fillScalarArgs<float>(c, zero, args);
+          rc = uploadArgs(c, args, s);
+        }
+      }
+      break;
+    }
+    default:
+      return fail(MOPT_ERR_UNSUPPORTED,
+                  "mopt_lm_minimize: run-time compiled models are driven by the host LM loop");
+  }
+  if (rc != MOPT_OK) return rc;
+  c->lm_uploaded_version = c->state_version;
+  c->lm_uploaded_mode = jac_mode;
+  desc->args = c->d_lm_args;
+  desc->basis = c->d_lm_basis;
+  return MOPT_OK;
+}
+
+int residentSweep(mopt_cost *c, int jac_mode, mopt::LmControl *control, hipStream_t s,
+                  unsigned long long base_sequence) {
+  mopt::PeerCombine pc;
+  const mopt::PeerCombine *peers = nullptr;
+  if (c->combine.mode == MOPT_COMBINE_PEER) {
+    const ShardCombine &sc = c->combine;
+    for (int k = 0; k < sc.num_ranks; ++k) pc.blocks[k] = sc.peer_blocks[k];
+    pc.rank = sc.rank;
+    pc.num_ranks = sc.num_ranks;
+    pc.offset = 0;
+    pc.sequence = base_sequence;  // + control->trial, added on the device
+    pc.timeout_ticks = sc.peer_timeout_ticks;
+    peers = &pc;
+  }
+  const int n = c->n_params;
+  mopt::LaunchSite site;
+  site.stream = s;
+  const size_t bytes = size_t(c->count) * 6 * size_t(c->scalar_bytes);
+  site.streaming = bytes > (size_t(32) << 20);
+  switch (c->model) {
+    case kModelPoint2Point: {
+      if (usesMoments(c)) {
+        const int grid = gridFor(c, blocksPerCu(1));
+        if (c->scalar_bytes == 8)
+          MOPT_HIP_TRY(mopt::launchP2PMomentsResident<double>(
+              static_cast<const double *>(c->d_tiles), c->num_tiles,
+              static_cast<const mopt::P2PSweepArgs<double> *>(c->d_lm_args), control, grid, site));
+        else
+          MOPT_HIP_TRY(mopt::launchP2PMomentsResident<float>(
+              static_cast<const float *>(c->d_tiles), c->num_tiles,
+              static_cast<const mopt::P2PSweepArgs<float> *>(c->d_lm_args), control, grid, site));
+        MOPT_HIP_TRY(mopt::launchFinalizeMomentsResident(c->d_partials, grid, c->d_lm_basis,
+                                                         c->d_result, control, s, peers));
+      } else {
+        const int grid = gridFor(c, blocksPerCu(2));
+        const int nacc = c->cov_mode == mopt::kCovGeneral ? mopt::kAccFull : mopt::kAccSym;
+        if (c->scalar_bytes == 8)
+          MOPT_HIP_TRY(mopt::launchP2PLiteralResident<double>(
+              static_cast<const mopt::P2PSweepArgs<double> *>(c->d_lm_args), control, jac_mode,
+              c->cov_mode, grid, site));
+        else
+          MOPT_HIP_TRY(mopt::launchP2PLiteralResident<float>(
+              static_cast<const mopt::P2PSweepArgs<float> *>(c->d_lm_args), control, jac_mode,
+              c->cov_mode, grid, site));
+        MOPT_HIP_TRY(mopt::launchFinalizeDenseResident(c->d_partials, grid, nacc, kNumParams,
+                                                       c->d_result, control, s, peers));
+      }
+      return MOPT_OK;
+    }
+    case kModelReprojection: {
+      const int grid = gridFor(c, blocksPerCu(2));
+      const int nacc = c->cov_mode == mopt::kCovGeneral ? mopt::kAccFull : mopt::kAccSym;
+      MOPT_HIP_TRY(mopt::launchReprojResident(
+          static_cast<const mopt::ReprojSweepArgs *>(c->d_lm_args), control, c->cov_mode, grid, site));
+      MOPT_HIP_TRY(mopt::launchFinalizeDenseResident(c->d_partials, grid, nacc, kNumParams,
+                                                     c->d_result, control, s, peers));
+      return MOPT_OK;
+    }
+    case kModelScalar: {
+      long long blocks = (c->count + mopt::kBlockThreads - 1) / mopt::kBlockThreads;
+      if (blocks > c->num_cus * 2) blocks = c->num_cus * 2;
+      if (blocks < 1) blocks = 1;
+      const int grid = int(blocks);
+      const int nacc = c->cov_mode == mopt::kCovGeneral ? n * n + n + 1 : n * (n + 1) / 2 + n + 1;
+      if (c->scalar_bytes == 8)
+        MOPT_HIP_TRY(mopt::launchScalarModelResident<double>(
+            static_cast<const mopt::ScalarSweepArgs<double> *>(c->d_lm_args), control,
+            c->scalar_model, jac_mode, c->cov_mode, grid, s));
+      else
+        MOPT_HIP_TRY(mopt::launchScalarModelResident<float>(
+            static_cast<const mopt::ScalarSweepArgs<float> *>(c->d_lm_args), control,
+            c->scalar_model, jac_mode, c->cov_mode, grid, s));
+      MOPT_HIP_TRY(mopt::launchFinalizeDenseResident(c->d_partials, grid, nacc, n, c->d_result,
+                                                     control, s, peers));
+      return MOPT_OK;
+    }
+    default:
+      return fail(MOPT_ERR_UNSUPPORTED, "no resident sweep for this model");
+  }
+}
+
+void releaseResident(mopt_cost *c) {
+  deviceRelease(c->d_lm_args);
+  deviceRelease(c->d_lm_basis);
+  deviceRelease(c->d_lm_control);
+  deviceRelease(c->d_lm_state);
+  c->d_lm_args = nullptr;
+  c->d_lm_basis = nullptr;
+  c->d_lm_control = nullptr;
+  c->d_lm_state = nullptr;
+  if (c->h_lm_report) (void)hipHostFree(c->h_lm_report);
+  c->h_lm_report = c->h_lm_report_dev = nullptr;
+}
+
+}  // namespace mopt_detail
+
+namespace mopt_detail {
 // For the single-process device group (group.cpp): a shard's sweep + finalize published into its
 // own mapped host memory, launched by one thread and awaited by another.
 int launchPublishedSweep(mopt_cost *c, bool cost_only, int jac_mode, const void *x,
@@ -733,6 +936,7 @@ void destroyCost(mopt_cost *c) {
     deviceRelease(c->matcher->d_matched);
   }
   mopt::jitRelease(c->jit);
+  releaseResident(c);
   deviceRelease(c->d_tiles);
   deviceRelease(c->d_partials);
   deviceRelease(c->d_result);

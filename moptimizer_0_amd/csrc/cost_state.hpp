@@ -158,6 +158,18 @@ struct mopt_cost {
   long long stat_sweeps = 0;
   long long stat_cache_hits = 0;
 
+  // Device-resident LM (mopt_lm_minimize, lm.cpp): this cost's sweep constants in HBM, written by
+  // the step kernel per trial point; the static part (data, loss, covariance) is re-uploaded when
+  // (state_version, Jacobian mode) change.  The first cost of a problem also owns the workspace.
+  void *d_lm_args = nullptr;
+  mopt::AffineBasis *d_lm_basis = nullptr;
+  unsigned long long lm_uploaded_version = ~0ull;
+  int lm_uploaded_mode = -1;
+  mopt::LmControl *d_lm_control = nullptr;
+  void *d_lm_state = nullptr;
+  mopt::LmReport *h_lm_report = nullptr;      // mapped host memory
+  mopt::LmReport *h_lm_report_dev = nullptr;  // as the device addresses it
+
   // Sweeps enqueued on a caller's stream (the *_async entry points): the buffers of this cost must
   // not be recycled before that work has finished, and only an event on that stream can tell.
   hipEvent_t foreign_done = nullptr;
@@ -192,6 +204,13 @@ int commonCreate(mopt_cost *c, int device);  // device, stream, partial / result
 // wait for everything enqueued for this cost, on its own stream and on callers' streams
 hipError_t quiesceCost(mopt_cost *c);
 void releaseCombine(mopt_cost *c);  // combine.cpp: unmaps / closes whatever was attached
+// c_abi.cpp, for the device-resident LM (lm.cpp): upload the static part of this cost's sweep
+// constants if it changed and describe the cost to the step kernel; enqueue one resident sweep +
+// finalize on `s` (peer-combine sequence numbers = base_sequence + trials counted on the device)
+int residentPrepare(mopt_cost *c, int jac_mode, hipStream_t s, mopt::LmCostDesc *desc);
+int residentSweep(mopt_cost *c, int jac_mode, mopt::LmControl *control, hipStream_t s,
+                  unsigned long long base_sequence);
+void releaseResident(mopt_cost *c);
 void destroyCost(mopt_cost *c);
 // enqueue one linearization / cost sweep + its finalize on `s`; results to d_result (+ optional
 // hand-over to mapped host memory)

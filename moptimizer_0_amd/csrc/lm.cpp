@@ -1,0 +1,174 @@
+// mopt_lm_minimize: the Levenberg-Marquardt loop of src/levenberg_marquadt_dyn.cpp:34-119 with the
+// iteration resident on the device (step kernel: lm_kernels.hip; resident sweeps:
+// sweep_kernels.hip).  The host only queues launches a few trial points ahead of the device and
+// watches a progress word in mapped memory; it takes no decision and copies nothing per iteration.
+#include "cost_state.hpp"
+
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+using namespace mopt_detail;
+
+namespace {
+
+int ensureWorkspace(mopt_cost *c) {
+  if (!c->d_lm_control)
+    MOPT_HIP_TRY(deviceAlloc(reinterpret_cast<void **>(&c->d_lm_control), sizeof(mopt::LmControl)));
+  if (!c->d_lm_state) MOPT_HIP_TRY(deviceAlloc(&c->d_lm_state, 4096));  // >= LmState<double>
+  if (!c->h_lm_report) {
+    MOPT_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_lm_report), sizeof(mopt::LmReport),
+                               hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(c->h_lm_report, 0, sizeof(mopt::LmReport));
+    MOPT_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->h_lm_report_dev),
+                                         c->h_lm_report, 0));
+  }
+  return MOPT_OK;
+}
+
+// A consistent copy of the report: the progress word is read before and after the payload.
+unsigned long long readReport(const mopt::LmReport *live, mopt::LmReport *out) {
+  for (;;) {
+    const unsigned long long before = __atomic_load_n(&live->flag, __ATOMIC_ACQUIRE);
+    std::memcpy(out, live, sizeof *out);
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    if (__atomic_load_n(&live->flag, __ATOMIC_ACQUIRE) == before) return before;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian_modes, void *x,
+                     const mopt_lm_options *options, mopt_lm_report *report_out) {
+  if (!costs || num_costs < 1 || !jacobian_modes || !x)
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument / no costs");
+  if (num_costs > mopt::kLmMaxCosts)
+    return fail(MOPT_ERR_UNSUPPORTED, "mopt_lm_minimize sums at most 4 costs");
+  mopt_cost *lead = costs[0];
+  for (int k = 0; k < num_costs; ++k) {
+    const mopt_cost *c = costs[k];
+    if (!c) return fail(MOPT_ERR_INVALID_ARGUMENT, "a cost is NULL");
+    if (c->device != lead->device || c->scalar_bytes != lead->scalar_bytes ||
+        c->n_params != lead->n_params)
+      return fail(MOPT_ERR_INVALID_ARGUMENT,
+                  "the costs of one problem share device, scalar type and parameter count");
+    if (c->combine.mode != MOPT_COMBINE_NONE && c->combine.mode != MOPT_COMBINE_PEER)
+      return fail(MOPT_ERR_UNSUPPORTED,
+                  "a sharded cost needs the sums of all ranks on the device: select "
+                  "MOPT_COMBINE_PEER (mopt_cost_set_combine) for mopt_lm_minimize");
+  }
+  mopt_lm_options opt;
+  opt.max_iterations = 15;    // optimizer.h:19
+  opt.lm_max_iterations = 3;  // levenberg_marquadt_dyn.cpp:9
+  opt.manifold = 0;
+  opt.window = 0;
+  if (options) opt = *options;
+  if (opt.max_iterations < 0 || opt.lm_max_iterations < 0)
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "Optimization::max_iterations cannot be less than 0.");
+  if (opt.manifold)
+    return fail(MOPT_ERR_UNSUPPORTED, "the device-resident loop takes the reference's Euclidean step");
+  mopt_lm_report rep;
+  std::memset(&rep, 0, sizeof rep);
+  rep.status = MOPT_LM_MAXIMUM_ITERATIONS_REACHED;
+  if (opt.max_iterations == 0) {  // the reference's loop body never runs
+    if (report_out) *report_out = rep;
+    return MOPT_OK;
+  }
+  MOPT_HIP_TRY(hipSetDevice(lead->device));
+  int rc = ensureWorkspace(lead);
+  if (rc != MOPT_OK) return rc;
+  hipStream_t s = lead->stream;
+
+  mopt::LmProblem problem;
+  problem.num_costs = num_costs;
+  problem.n = lead->n_params;
+  problem.max_iterations = opt.max_iterations;
+  problem.lm_max_iterations = opt.lm_max_iterations;
+  problem.control = lead->d_lm_control;
+  problem.state = lead->d_lm_state;
+  problem.report = lead->h_lm_report_dev;
+  for (int k = 0; k < num_costs; ++k) {
+    rc = residentPrepare(costs[k], jacobian_modes[k], s, &problem.cost[k]);
+    if (rc != MOPT_OK) return rc;
+    costs[k]->cache.valid = false;
+  }
+  unsigned long long base_sequence[mopt::kLmMaxCosts];
+  for (int k = 0; k < num_costs; ++k) base_sequence[k] = costs[k]->combine.sequence + 1;
+
+  mopt::LmReport *live = lead->h_lm_report;
+  __atomic_store_n(&live->flag, 0ull, __ATOMIC_RELEASE);
+  if (lead->scalar_bytes == 8)
+    MOPT_HIP_TRY(mopt::launchLmStep<double>(problem, true, static_cast<const double *>(x), s));
+  else
+    MOPT_HIP_TRY(mopt::launchLmStep<float>(problem, true, static_cast<const float *>(x), s));
+
+  // One sweep per evaluated point: the linearization at x0, then at most lm_max_iterations trial
+  // points per outer iteration.  The host stays `window` points ahead of the device; whatever is
+  // still queued when the step kernel stops finds control->done set and returns at once.
+  const long long max_points =
+      1 + (long long)opt.max_iterations * (opt.lm_max_iterations > 0 ? opt.lm_max_iterations : 1);
+  static const int default_window = envInt("MOPT_LM_WINDOW", 3);
+  const int window = opt.window > 0 ? opt.window : default_window;
+  long long enqueued = 0;
+  mopt::LmReport snap;
+  const auto started = std::chrono::steady_clock::now();
+  unsigned long long spins = 0;
+  for (;;) {
+    const unsigned long long steps = readReport(live, &snap);
+    const long long completed = steps > 0 ? (long long)steps - 1 : 0;  // the init run counts one
+    if (steps > 0 && int(snap.status) != mopt::kLmRunning) break;
+    bool queued = false;
+    while (enqueued < max_points && enqueued - completed < window) {
+      for (int k = 0; k < num_costs; ++k) {
+        rc = residentSweep(costs[k], jacobian_modes[k], problem.control, s, base_sequence[k]);
+        if (rc != MOPT_OK) return rc;
+      }
+      if (lead->scalar_bytes == 8)
+        MOPT_HIP_TRY(mopt::launchLmStep<double>(problem, false, nullptr, s));
+      else
+        MOPT_HIP_TRY(mopt::launchLmStep<float>(problem, false, nullptr, s));
+      ++enqueued;
+      queued = true;
+    }
+    if (queued) continue;
+    if ((++spins & 0x3fff) == 0) {
+      const hipError_t q = hipStreamQuery(s);
+      if (q != hipSuccess && q != hipErrorNotReady)
+        return fail(MOPT_ERR_HIP, std::string("device-resident LM failed: ") + hipGetErrorString(q));
+      if (q == hipSuccess) {
+        const unsigned long long now = readReport(live, &snap);
+        if (now > 0 && int(snap.status) != mopt::kLmRunning) break;
+        if (enqueued >= max_points)
+          return fail(MOPT_ERR_HIP, "device-resident LM drained without reaching a status");
+      }
+      if (std::chrono::steady_clock::now() - started > std::chrono::seconds(120))
+        return fail(MOPT_ERR_HIP, "timed out waiting for the device-resident LM (120 s)");
+    }
+    __builtin_ia32_pause();
+  }
+
+  const long long trials = (long long)snap.trials;
+  for (int k = 0; k < num_costs; ++k) {
+    mopt_cost *c = costs[k];
+    c->stat_sweeps += trials;
+    if (c->combine.mode == MOPT_COMBINE_PEER) c->combine.sequence += (unsigned long long)trials;
+  }
+  if (lead->scalar_bytes == 8)
+    for (int i = 0; i < problem.n; ++i) static_cast<double *>(x)[i] = snap.x[i];
+  else
+    for (int i = 0; i < problem.n; ++i) static_cast<float *>(x)[i] = float(snap.x[i]);
+  rep.status = int(snap.status);
+  rep.iterations = int(snap.iterations);
+  rep.sweeps = trials;
+  rep.cost = snap.cost;
+  rep.lambda = snap.lambda;
+  if (report_out) *report_out = rep;
+  if ((unsigned long long)snap.peer_status == mopt::kStatusPeerTimeout)
+    return fail(MOPT_ERR_PEER_TIMEOUT,
+                "a rank did not deliver its sums to this device in time (MOPT_PEER_TIMEOUT_MS)");
+  return MOPT_OK;
+}
+
+}  // extern "C"

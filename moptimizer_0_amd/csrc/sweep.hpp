@@ -161,6 +161,97 @@ struct PeerCombine {
   unsigned long long timeout_ticks = 0;  // of the 100 MHz wall clock; the wait is always bounded
 };
 
+// ---- device-resident Levenberg-Marquardt (mopt_lm_minimize) ---------------------------------
+// The LM loop of src/levenberg_marquadt_dyn.cpp:34-119 with the iteration taken on the device:
+// after every sweep a one-workgroup step kernel reads the sums, solves the damped 6x6 system,
+// tests the trial point and writes the per-x constants of the NEXT sweep (transforms, forward-
+// difference steps, affine basis) into HBM, from where the "resident" forms of the sweep and
+// finalize kernels read them — so sweeps can be queued ahead of time and the host only sees the
+// final x.  A queued kernel that finds `done` set returns at once.
+constexpr int kLmMaxCosts = 4;
+enum LmModel : int { kLmPoint2Point = 1, kLmReprojection = 2, kLmScalar = 3 };
+// values of moptimizer::OptimizationStatus (include/moptimizer/types.h:6-12)
+enum LmStatus : int {
+  kLmConverged = 0,
+  kLmMaxIterations = 1,
+  kLmSmallDelta = 2,
+  kLmNumericError = 3,
+  kLmFatalError = 4,
+  kLmRunning = -1
+};
+
+struct LmControl {  // device memory; written by the step kernel only
+  int done;         // 0 while iterating; queued sweeps / finalizes return at once when set
+  int trial;        // sweeps evaluated so far = offset of the next peer-combine sequence number
+  int pad[2];
+};
+
+struct LmCostDesc {
+  int model = 0;     // LmModel
+  int jac_mode = 0;  // JacMode
+  int n_out = 0;
+  int moments = 0;   // point2point: the finalize kernel contracts moments with `basis`
+  void *args = nullptr;           // device: P2PSweepArgs<S> / ReprojSweepArgs / ScalarSweepArgs<S>
+  AffineBasis *basis = nullptr;   // device, point2point moments
+  const double *result = nullptr; // device: this cost's H | b | sum_sq (summed over the ranks)
+  double camera[12] = {0};        // reprojection constants (row-major 3x4, 4x4)
+  double frame[16] = {0};
+};
+
+struct LmReport {  // mapped host memory (as doubles so that one layout serves float and double)
+  double x[kMaxParams];
+  double cost;        // sum of squares at the returned x
+  double lambda;
+  double status;      // LmStatus
+  double iterations;  // executed outer iterations (Optimizer::getExecutedIterations)
+  double trials;      // sweeps evaluated
+  double peer_status; // kStatusPeerTimeout when a rank went missing
+  double pad[2];
+  unsigned long long flag;  // progress word: number of step-kernel runs that have completed
+};
+
+struct LmProblem {
+  int num_costs = 0;
+  int n = 0;
+  int max_iterations = 15;    // optimizer.h:19
+  int lm_max_iterations = 3;  // levenberg_marquadt_dyn.cpp:9
+  int manifold = 0;           // 1: x (+) delta composed on SE(3) instead of added (n = 6 only)
+  int pad = 0;
+  LmCostDesc cost[kLmMaxCosts];
+  LmControl *control = nullptr;  // device
+  void *state = nullptr;         // device, LmState<S> (lm_kernels.hip)
+  LmReport *report = nullptr;    // mapped host memory as the device addresses it
+};
+
+// `init`: start a minimisation from x0 (control and state reset, constants of the first sweep
+// written); otherwise: digest the sweep that has just finished and propose the next point.
+template <typename S>
+hipError_t launchLmStep(const LmProblem &problem, bool init, const S *x0, hipStream_t stream);
+template <typename Args>
+hipError_t launchStoreArgs(const Args &value, Args *d_dst, hipStream_t stream);
+
+// Resident forms: per-x constants read from HBM (`d_args`, `d_basis`), early exit on control->done,
+// peer-combine sequence = peers.sequence + control->trial.
+template <typename S>
+hipError_t launchP2PMomentsResident(const S *tiles, int num_tiles, const P2PSweepArgs<S> *d_args,
+                                    const LmControl *control, int grid, const LaunchSite &site);
+template <typename S>
+hipError_t launchP2PLiteralResident(const P2PSweepArgs<S> *d_args, const LmControl *control,
+                                    int jac_mode, int cov_mode, int grid, const LaunchSite &site);
+hipError_t launchReprojResident(const ReprojSweepArgs *d_args, const LmControl *control,
+                                int cov_mode, int grid, const LaunchSite &site);
+template <typename S>
+hipError_t launchScalarModelResident(const ScalarSweepArgs<S> *d_args, const LmControl *control,
+                                     int model, int jac_mode, int cov_mode, int grid,
+                                     hipStream_t stream);
+hipError_t launchFinalizeDenseResident(const double *partials, int grid, int nacc, int n,
+                                       double *result, LmControl *control, hipStream_t stream,
+                                       const PeerCombine *peers);
+hipError_t launchFinalizeMomentsResident(const double *partials, int grid,
+                                         const AffineBasis *d_basis, double *result,
+                                         LmControl *control, hipStream_t stream,
+                                         const PeerCombine *peers);
+
 // ---- launches (all asynchronous on `stream`) ------------------------------------------------
 template <typename S>
 hipError_t launchRelayoutP2P(const S *src_xyz, const S *tgt_xyz, long long count, S *tiles,

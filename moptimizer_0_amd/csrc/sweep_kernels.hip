@@ -274,8 +274,7 @@ __device__ __forceinline__ void p2pPointLiteral(
 }
 
 template <typename S, int JAC, int COV>
-__global__ __launch_bounds__(kBlockThreads) void p2pLinearizeLiteralKernel(
-    const P2PSweepArgs<S> A) {
+__device__ __forceinline__ void p2pLinearizeLiteralBody(const P2PSweepArgs<S> &A) {
   constexpr int NACC = (COV == kCovGeneral) ? kAccFull : kAccSym;
   constexpr int V = TileShape<S>::kVec;
   double acc[NACC];
@@ -294,6 +293,23 @@ __global__ __launch_bounds__(kBlockThreads) void p2pLinearizeLiteralKernel(
   blockReduceStore<NACC>(acc, A.partials + size_t(blockIdx.x) * NACC);
 }
 
+template <typename S, int JAC, int COV>
+__global__ __launch_bounds__(kBlockThreads) void p2pLinearizeLiteralKernel(
+    const P2PSweepArgs<S> A) {
+  p2pLinearizeLiteralBody<S, JAC, COV>(A);
+}
+
+// Resident form (device-resident LM, sweep.hpp): the per-x constants come from HBM, where the
+// step kernel of the previous trial left them; a kernel queued past the end of the minimisation
+// finds control->done set and returns.
+template <typename S, int JAC, int COV>
+__global__ __launch_bounds__(kBlockThreads) void p2pLinearizeLiteralResidentKernel(
+    const P2PSweepArgs<S> *__restrict__ d_args, const LmControl *__restrict__ control) {
+  if (control->done) return;
+  const P2PSweepArgs<S> A = *d_args;
+  p2pLinearizeLiteralBody<S, JAC, COV>(A);
+}
+
 // ---- point-to-point, weighted moments --------------------------------------------------------
 // Every Jacobian this model produces is affine in the source point p (analytic: [I | -skew(p)];
 // forward differences: ((R_j - R) p + (t_j - t)) / h_j), so
@@ -304,8 +320,8 @@ __global__ __launch_bounds__(kBlockThreads) void p2pLinearizeLiteralKernel(
 // preload those into SGPRs at wave launch (-amdgpu-kernarg-preload-count), so the first tile's
 // loads go out without waiting for a kernel-argument fetch.
 template <typename S, bool STREAMING>
-__global__ __launch_bounds__(kBlockThreads) void p2pMomentsKernel(const S *tiles, int num_tiles,
-                                                                  const P2PSweepArgs<S> A) {
+__device__ __forceinline__ void p2pMomentsBody(const S *tiles, int num_tiles,
+                                               const P2PSweepArgs<S> &A) {
   constexpr int V = TileShape<S>::kVec;
   double acc[kAccMoments];
 #pragma unroll
@@ -369,6 +385,21 @@ __global__ __launch_bounds__(kBlockThreads) void p2pMomentsKernel(const S *tiles
   blockReduceStore<kAccMoments>(acc, A.partials + size_t(blockIdx.x) * kAccMoments);
 }
 
+template <typename S, bool STREAMING>
+__global__ __launch_bounds__(kBlockThreads) void p2pMomentsKernel(const S *tiles, int num_tiles,
+                                                                  const P2PSweepArgs<S> A) {
+  p2pMomentsBody<S, STREAMING>(tiles, num_tiles, A);
+}
+
+template <typename S, bool STREAMING>
+__global__ __launch_bounds__(kBlockThreads) void p2pMomentsResidentKernel(
+    const S *tiles, int num_tiles, const P2PSweepArgs<S> *__restrict__ d_args,
+    const LmControl *__restrict__ control) {
+  if (control->done) return;
+  const P2PSweepArgs<S> A = *d_args;
+  p2pMomentsBody<S, STREAMING>(tiles, num_tiles, A);
+}
+
 // ---- point-to-point, cost only (linearization.h:36-63) ----------------------------------------
 template <typename S, bool STREAMING>
 __global__ __launch_bounds__(kBlockThreads) void p2pCostKernel(const S *tiles, int num_tiles,
@@ -408,7 +439,7 @@ __device__ __forceinline__ void reprojResidual(const double (&Mx)[12], const dou
 }
 
 template <int COV, bool COST_ONLY>
-__global__ __launch_bounds__(kBlockThreads) void reprojKernel(const ReprojSweepArgs A) {
+__device__ __forceinline__ void reprojBody(const ReprojSweepArgs &A) {
   constexpr int NACC = COST_ONLY ? 1 : ((COV == kCovGeneral) ? kAccFull : kAccSym);
   double acc[NACC];
 #pragma unroll
@@ -450,6 +481,19 @@ __global__ __launch_bounds__(kBlockThreads) void reprojKernel(const ReprojSweepA
     }
   }
   blockReduceStore<NACC>(acc, A.partials + size_t(blockIdx.x) * NACC);
+}
+
+template <int COV, bool COST_ONLY>
+__global__ __launch_bounds__(kBlockThreads) void reprojKernel(const ReprojSweepArgs A) {
+  reprojBody<COV, COST_ONLY>(A);
+}
+
+template <int COV>
+__global__ __launch_bounds__(kBlockThreads) void reprojResidentKernel(
+    const ReprojSweepArgs *__restrict__ d_args, const LmControl *__restrict__ control) {
+  if (control->done) return;
+  const ReprojSweepArgs A = *d_args;
+  reprojBody<COV, false>(A);
 }
 
 // ---- small parametric models over per-element scalar data ------------------------------------
@@ -505,7 +549,7 @@ struct Powell {
 };
 
 template <typename S, template <typename> class ModelT, int JAC, int COV, bool COST_ONLY>
-__global__ __launch_bounds__(kBlockThreads) void scalarModelKernel(const ScalarSweepArgs<S> A) {
+__device__ __forceinline__ void scalarModelBody(const ScalarSweepArgs<S> &A) {
   using Model = ModelT<S>;
   constexpr int N = Model::N, M = Model::M, D = Model::D;
   constexpr int NACC =
@@ -547,6 +591,19 @@ __global__ __launch_bounds__(kBlockThreads) void scalarModelKernel(const ScalarS
     }
   }
   blockReduceStore<NACC>(acc, A.partials + size_t(blockIdx.x) * NACC);
+}
+
+template <typename S, template <typename> class ModelT, int JAC, int COV, bool COST_ONLY>
+__global__ __launch_bounds__(kBlockThreads) void scalarModelKernel(const ScalarSweepArgs<S> A) {
+  scalarModelBody<S, ModelT, JAC, COV, COST_ONLY>(A);
+}
+
+template <typename S, template <typename> class ModelT, int JAC, int COV>
+__global__ __launch_bounds__(kBlockThreads) void scalarModelResidentKernel(
+    const ScalarSweepArgs<S> *__restrict__ d_args, const LmControl *__restrict__ control) {
+  if (control->done) return;
+  const ScalarSweepArgs<S> A = *d_args;
+  scalarModelBody<S, ModelT, JAC, COV, false>(A);
 }
 
 // ---- correspondence search (ICP update step) ---------------------------------------------------
@@ -804,11 +861,10 @@ __device__ __forceinline__ void columnTotals(const double *partials, int grid, i
 
 // rows of [upper triangle or full H | b | sum_sq] over n parameters -> H (n x n column-major) | b |
 // sum_sq.  nacc tells the form: n(n+1)/2 + n + 1 (symmetric) or n*n + n + 1 (full).
-__global__ __launch_bounds__(kFinalThreads) void finalizeDenseKernel(const double *partials,
-                                                                      int grid, int nacc, int n,
-                                                                      double *result,
-                                                                      const HostPublish pub,
-                                                                      const PeerCombine pc) {
+__device__ __forceinline__ unsigned long long finalizeDenseBody(const double *partials, int grid,
+                                                                int nacc, int n, double *result,
+                                                                const HostPublish &pub,
+                                                                const PeerCombine &pc) {
   __shared__ double scratch[kFinalThreads];
   __shared__ double total[kMaxAccumulators];
   columnTotals(partials, grid, nacc, scratch, total);
@@ -834,17 +890,37 @@ __global__ __launch_bounds__(kFinalThreads) void finalizeDenseKernel(const doubl
   v = peerCombine(pc, count, v, &status);
   if (k < count) result[k] = v;
   publishToHost(pub, count, v, status);
+  return status;
+}
+
+__global__ __launch_bounds__(kFinalThreads) void finalizeDenseKernel(const double *partials,
+                                                                      int grid, int nacc, int n,
+                                                                      double *result,
+                                                                      const HostPublish pub,
+                                                                      const PeerCombine pc) {
+  finalizeDenseBody(partials, grid, nacc, n, result, pub, pc);
+}
+
+// Resident forms (device-resident LM): nothing goes to the host, the peer-combine sequence number
+// is the base the host assigned plus the number of trials the step kernel has counted.
+__global__ __launch_bounds__(kFinalThreads) void finalizeDenseResidentKernel(
+    const double *partials, int grid, int nacc, int n, double *result, LmControl *control,
+    PeerCombine pc) {
+  if (control->done) return;
+  pc.sequence += (unsigned long long)control->trial;
+  const unsigned long long status =
+      finalizeDenseBody(partials, grid, nacc, n, result, HostPublish(), pc);
+  if (status && threadIdx.x == 0) control->pad[0] = int(status);  // a rank went missing
 }
 
 // Moments -> H, b.  With p_0 = 1:  W(a,b) = sum w p_a p_b,  V(a,c) = sum w p_a r_c  and
 //   H(i,j) = sum_{a,b} W(a,b) (J_a^T S J_b)(i,j),   b(i) = sum_a (J_a^T S V(a,.))(i).
 // 576 threads form one (a,b) term of one H entry each, 24 threads one (a) term of one b entry.
-__global__ __launch_bounds__(kFinalThreads) void finalizeMomentsKernel(const double *partials,
-                                                                        int grid,
-                                                                        const AffineBasis B,
-                                                                        double *result,
-                                                                        const HostPublish pub,
-                                                                        const PeerCombine pc) {
+__device__ __forceinline__ unsigned long long finalizeMomentsBody(const double *partials, int grid,
+                                                                  const AffineBasis &B,
+                                                                  double *result,
+                                                                  const HostPublish &pub,
+                                                                  const PeerCombine &pc) {
   __shared__ double scratch[kFinalThreads];
   __shared__ double total[kMaxAccumulators];
   __shared__ double terms[36 * 16 + 6 * 4];
@@ -902,6 +978,30 @@ __global__ __launch_bounds__(kFinalThreads) void finalizeMomentsKernel(const dou
   v = peerCombine(pc, kResultDoubles, v, &status);
   if (t < kResultDoubles) result[t] = v;
   publishToHost(pub, kResultDoubles, v, status);
+  return status;
+}
+
+__global__ __launch_bounds__(kFinalThreads) void finalizeMomentsKernel(const double *partials,
+                                                                        int grid,
+                                                                        const AffineBasis B,
+                                                                        double *result,
+                                                                        const HostPublish pub,
+                                                                        const PeerCombine pc) {
+  finalizeMomentsBody(partials, grid, B, result, pub, pc);
+}
+
+__global__ __launch_bounds__(kFinalThreads) void finalizeMomentsResidentKernel(
+    const double *partials, int grid, const AffineBasis *__restrict__ d_basis, double *result,
+    LmControl *control, PeerCombine pc) {
+  if (control->done) return;
+  __shared__ AffineBasis B;
+  for (int i = threadIdx.x; i < int(sizeof(AffineBasis) / sizeof(double)); i += kFinalThreads)
+    reinterpret_cast<double *>(&B)[i] = reinterpret_cast<const double *>(d_basis)[i];
+  __syncthreads();
+  pc.sequence += (unsigned long long)control->trial;
+  const unsigned long long status =
+      finalizeMomentsBody(partials, grid, B, result, HostPublish(), pc);
+  if (status && threadIdx.x == 0) control->pad[0] = int(status);
 }
 
 __global__ __launch_bounds__(kFinalThreads) void finalizeCostKernel(const double *partials,
@@ -1149,6 +1249,153 @@ hipError_t launchPublish(const double *d_values, int count, const HostPublish &p
                          hipStream_t stream) {
   if (count < 0 || count > kMaxAccumulators) return hipErrorInvalidValue;
   hipLaunchKernelGGL(publishKernel, dim3(1), dim3(kMaxAccumulators), 0, stream, d_values, count, pub);
+  return hipGetLastError();
+}
+
+// ---- resident forms (device-resident LM) ---------------------------------------------------------
+template <typename S>
+hipError_t launchP2PMomentsResident(const S *tiles, int num_tiles, const P2PSweepArgs<S> *d_args,
+                                    const LmControl *control, int grid, const LaunchSite &site) {
+  if (site.streaming)
+    hipLaunchKernelGGL((p2pMomentsResidentKernel<S, true>), dim3(grid), dim3(kBlockThreads), 0,
+                       site.stream, tiles, num_tiles, d_args, control);
+  else
+    hipLaunchKernelGGL((p2pMomentsResidentKernel<S, false>), dim3(grid), dim3(kBlockThreads), 0,
+                       site.stream, tiles, num_tiles, d_args, control);
+  return hipGetLastError();
+}
+template hipError_t launchP2PMomentsResident<float>(const float *, int, const P2PSweepArgs<float> *,
+                                                    const LmControl *, int, const LaunchSite &);
+template hipError_t launchP2PMomentsResident<double>(const double *, int,
+                                                     const P2PSweepArgs<double> *,
+                                                     const LmControl *, int, const LaunchSite &);
+
+namespace {
+template <typename S, int JAC>
+hipError_t launchLiteralResidentCov(const P2PSweepArgs<S> *d_args, const LmControl *control,
+                                    int cov_mode, int grid, const LaunchSite &site) {
+  const dim3 g(grid), b(kBlockThreads);
+  switch (cov_mode) {
+    case kCovIdentity:
+      hipLaunchKernelGGL((p2pLinearizeLiteralResidentKernel<S, JAC, kCovIdentity>), g, b, 0,
+                         site.stream, d_args, control);
+      break;
+    case kCovSymmetric:
+      hipLaunchKernelGGL((p2pLinearizeLiteralResidentKernel<S, JAC, kCovSymmetric>), g, b, 0,
+                         site.stream, d_args, control);
+      break;
+    default:
+      hipLaunchKernelGGL((p2pLinearizeLiteralResidentKernel<S, JAC, kCovGeneral>), g, b, 0,
+                         site.stream, d_args, control);
+      break;
+  }
+  return hipGetLastError();
+}
+}  // namespace
+
+template <typename S>
+hipError_t launchP2PLiteralResident(const P2PSweepArgs<S> *d_args, const LmControl *control,
+                                    int jac_mode, int cov_mode, int grid, const LaunchSite &site) {
+  switch (jac_mode) {
+    case kJacAnalytic:
+      return launchLiteralResidentCov<S, kJacAnalytic>(d_args, control, cov_mode, grid, site);
+    case kJacAnalyticTst:
+      return launchLiteralResidentCov<S, kJacAnalyticTst>(d_args, control, cov_mode, grid, site);
+    case kJacNumeric:
+      return launchLiteralResidentCov<S, kJacNumeric>(d_args, control, cov_mode, grid, site);
+    default:
+      return hipErrorInvalidValue;
+  }
+}
+template hipError_t launchP2PLiteralResident<float>(const P2PSweepArgs<float> *, const LmControl *,
+                                                    int, int, int, const LaunchSite &);
+template hipError_t launchP2PLiteralResident<double>(const P2PSweepArgs<double> *,
+                                                     const LmControl *, int, int, int,
+                                                     const LaunchSite &);
+
+hipError_t launchReprojResident(const ReprojSweepArgs *d_args, const LmControl *control,
+                                int cov_mode, int grid, const LaunchSite &site) {
+  const dim3 g(grid), b(kBlockThreads);
+  switch (cov_mode) {
+    case kCovIdentity:
+      hipLaunchKernelGGL((reprojResidentKernel<kCovIdentity>), g, b, 0, site.stream, d_args, control);
+      break;
+    case kCovSymmetric:
+      hipLaunchKernelGGL((reprojResidentKernel<kCovSymmetric>), g, b, 0, site.stream, d_args, control);
+      break;
+    default:
+      hipLaunchKernelGGL((reprojResidentKernel<kCovGeneral>), g, b, 0, site.stream, d_args, control);
+      break;
+  }
+  return hipGetLastError();
+}
+
+namespace {
+template <typename S, template <typename> class ModelT>
+hipError_t launchScalarResidentFor(const ScalarSweepArgs<S> *d_args, const LmControl *control,
+                                   int jac_mode, int cov_mode, int grid, hipStream_t stream) {
+  const dim3 g(grid), b(kBlockThreads);
+  const bool numeric = (jac_mode == kJacNumeric);
+#define MOPT_LAUNCH_SCALAR_RESIDENT(JAC, COV)                                                    \
+  hipLaunchKernelGGL((scalarModelResidentKernel<S, ModelT, JAC, COV>), g, b, 0, stream, d_args, \
+                     control)
+  switch (cov_mode) {
+    case kCovIdentity:
+      if (numeric) MOPT_LAUNCH_SCALAR_RESIDENT(kJacNumeric, kCovIdentity);
+      else MOPT_LAUNCH_SCALAR_RESIDENT(kJacAnalytic, kCovIdentity);
+      break;
+    case kCovSymmetric:
+      if (numeric) MOPT_LAUNCH_SCALAR_RESIDENT(kJacNumeric, kCovSymmetric);
+      else MOPT_LAUNCH_SCALAR_RESIDENT(kJacAnalytic, kCovSymmetric);
+      break;
+    default:
+      if (numeric) MOPT_LAUNCH_SCALAR_RESIDENT(kJacNumeric, kCovGeneral);
+      else MOPT_LAUNCH_SCALAR_RESIDENT(kJacAnalytic, kCovGeneral);
+      break;
+  }
+#undef MOPT_LAUNCH_SCALAR_RESIDENT
+  return hipGetLastError();
+}
+}  // namespace
+
+template <typename S>
+hipError_t launchScalarModelResident(const ScalarSweepArgs<S> *d_args, const LmControl *control,
+                                     int model, int jac_mode, int cov_mode, int grid,
+                                     hipStream_t stream) {
+  switch (model) {
+    case kScalarExpCurve:
+      return launchScalarResidentFor<S, ExpCurve>(d_args, control, jac_mode, cov_mode, grid, stream);
+    case kScalarRational:
+      return launchScalarResidentFor<S, Rational>(d_args, control, jac_mode, cov_mode, grid, stream);
+    case kScalarPowell:
+      return launchScalarResidentFor<S, Powell>(d_args, control, jac_mode, cov_mode, grid, stream);
+    default:
+      return hipErrorInvalidValue;
+  }
+}
+template hipError_t launchScalarModelResident<float>(const ScalarSweepArgs<float> *,
+                                                     const LmControl *, int, int, int, int,
+                                                     hipStream_t);
+template hipError_t launchScalarModelResident<double>(const ScalarSweepArgs<double> *,
+                                                      const LmControl *, int, int, int, int,
+                                                      hipStream_t);
+
+hipError_t launchFinalizeDenseResident(const double *partials, int grid, int nacc, int n,
+                                       double *result, LmControl *control,
+                                       hipStream_t stream, const PeerCombine *peers) {
+  if (n < 1 || n > kMaxParams || (nacc != n * (n + 1) / 2 + n + 1 && nacc != n * n + n + 1))
+    return hipErrorInvalidValue;
+  hipLaunchKernelGGL(finalizeDenseResidentKernel, dim3(1), dim3(kFinalThreads), 0, stream, partials,
+                     grid, nacc, n, result, control, peers ? *peers : PeerCombine());
+  return hipGetLastError();
+}
+
+hipError_t launchFinalizeMomentsResident(const double *partials, int grid,
+                                         const AffineBasis *d_basis, double *result,
+                                         LmControl *control, hipStream_t stream,
+                                         const PeerCombine *peers) {
+  hipLaunchKernelGGL(finalizeMomentsResidentKernel, dim3(1), dim3(kFinalThreads), 0, stream,
+                     partials, grid, d_basis, result, control, peers ? *peers : PeerCombine());
   return hipGetLastError();
 }
 

@@ -63,8 +63,25 @@ def main():
         for k in range(200):
             acc += cost.compute_cost(ds.X_GENERIC * (0.01 * k))
         res[name + "_chain"] = np.array([acc])
+    if "peer" in usable:
+        # the whole LM loop resident on every rank's device, each on its shard, the sums of every
+        # point added over the ranks inside the finalize kernels: identical iterates everywhere
+        cost.set_combine(mo.COMBINE_PEER)
+        cost.set_loss(mo.LOSS_NONE)
+        x, rep = mo.capi.lm_minimize([cost], [mo.JAC_NUMERIC], np.zeros(6))
+        res["lm_x"] = x
+        res["lm_rep"] = np.array([rep["status"], rep["iterations"], rep["sweeps"]])
+        # ... and the blocking path keeps working afterwards (sequence numbers stayed in step)
+        H, b, s = cost.linearize(ds.X_GENERIC, mo.JAC_ANALYTIC)
+        res["after_lm_H"] = H
+        cost.set_loss(mo.LOSS_GEMAN_MCCLURE, 50.0)
     dist.barrier()
     if rank == 0:
+        whole = mo.Point2PointCost(src, tgt, device=device)
+        x, rep = mo.capi.lm_minimize([whole], [mo.JAC_NUMERIC], np.zeros(6))
+        res["lm_whole_x"] = x
+        res["lm_whole_rep"] = np.array([rep["status"], rep["iterations"], rep["sweeps"]])
+        whole.close()
         # what the sums must be: the same shards, in one process, added on the host in shard order
         group = mo.Point2PointGroup(src, tgt, [0] * world)
         group.set_loss(mo.LOSS_GEMAN_MCCLURE, 50.0)

@@ -1,0 +1,172 @@
+"""mopt_lm_minimize — LevenbergMarquadtDynamic::minimize (src/levenberg_marquadt_dyn.cpp:34-119)
+with the iteration resident on the device — against the CPU restatement of the same loop over the
+CPU restatement of the costs (oracle), and against the host loop driving the HIP cost through the
+boundary.  Bar: same status, same number of outer iterations, iterates within 1e-9 (the device forms
+sin / cos with its own libm, so forward-difference Jacobians differ in the last digits; LM contracts
+that)."""
+import numpy as np
+import pytest
+
+from tests import datasets as ds
+from tests import oracle_binding as ob
+
+pytestmark = pytest.mark.gpu
+
+CONVERGED, MAX_ITERATIONS, SMALL_DELTA, NUMERIC_ERROR = 0, 1, 2, 3
+
+
+def host_lm(cost, jac_mode, x0, max_iter=15, lm_iter=3):
+    """The reference's loop written against the blocking boundary calls of ONE HIP cost."""
+    x = np.array(x0, dtype=np.float64)
+    lam, eps, sweeps = -1.0, np.finfo(np.float64).eps, 0
+    it = 0
+    while it < max_iter:
+        H, b, y0 = cost.linearize(x, jac_mode)
+        if abs(y0) < 8 * eps:
+            return x, CONVERGED, it
+        if lam < 0:
+            lam = 1e-9 * np.abs(np.diag(H)).max()
+        nu = 2.0
+        for _ in range(lm_iter):
+            delta = np.linalg.solve(H + lam * np.diag(np.diag(H)), -b)
+            xi = x + delta
+            yi = cost.compute_cost(xi)
+            if np.isnan(yi):
+                return x, NUMERIC_ERROR, it
+            rho = (y0 - yi) / delta.dot(lam * delta - b)
+            if rho < 0:
+                if np.abs(delta).max() < np.sqrt(eps):
+                    return x, (CONVERGED if abs(yi) < 8 * eps else SMALL_DELTA), it
+                lam *= nu
+                nu *= 2
+                continue
+            x = xi
+            lam *= max(1.0 / 3.0, 1 - (2 * rho - 1) ** 3)
+            break
+        it += 1
+    return x, MAX_ITERATIONS, it
+
+
+def test_facade_registration_matches_the_cpu_loop(hip_lib, oracle, facade):
+    """tst/point2point.cpp:192-217: numerical cost, x0 = 0 -> the fixture pose."""
+    mo = hip_lib
+    src, tgt = facade
+    cost = mo.Point2PointCost(src, tgt)
+    x, rep = mo.capi.lm_minimize([cost], [mo.JAC_NUMERIC], np.zeros(6))
+    xr, status, iters = oracle.p2p_minimize(src, tgt, np.zeros(6), cost_class=ob.NUMERIC_DYN,
+                                            layout=ob.LAYOUT_ROW_MAJOR)
+    assert rep["status"] == status and rep["iterations"] == iters
+    assert np.abs(x - xr).max() < 1e-9
+    assert np.abs(x - ds.FIXTURE_X).max() < 1e-8
+    # one sweep per evaluated point, none on the host's initiative
+    assert rep["sweeps"] <= 1 + 3 * max(iters, 1)
+    cost.close()
+
+
+@pytest.mark.parametrize("n", [1000, 100_000, 1_000_000])
+@pytest.mark.parametrize("jac", [0, 2])
+def test_iterates_match_the_cpu_loop(hip_lib, oracle, n, jac):
+    """Truncating both loops after k outer iterations exposes the k-th iterate."""
+    mo = hip_lib
+    src, tgt = ds.synthetic_pair(n, seed=5, noise=0.01)
+    cost = mo.Point2PointCost(src, tgt)
+    cc = ob.NUMERIC_DYN if jac == 2 else ob.ANALYTIC_DYN
+    ks = (1, 2, 3, 5, 15) if n <= 100_000 else (2, 15)
+    for k in ks:
+        x, rep = mo.capi.lm_minimize([cost], [jac], np.zeros(6), max_iterations=k)
+        xr, status, iters = oracle.p2p_minimize(src, tgt, np.zeros(6), cost_class=cc,
+                                                layout=ob.LAYOUT_ROW_MAJOR, max_iter=k)
+        assert (rep["status"], rep["iterations"]) == (status, iters), (k, rep, status, iters)
+        assert np.abs(x - xr).max() < 1e-9 * max(1.0, np.abs(xr).max()), (k, x, xr)
+    cost.close()
+
+
+def test_same_answer_as_the_host_loop_over_the_hip_cost(hip_lib):
+    mo = hip_lib
+    src, tgt = ds.synthetic_pair(50_000, seed=8, noise=0.05)
+    cost = mo.Point2PointCost(src, tgt)
+    cost.set_loss(mo.LOSS_GEMAN_MCCLURE, 30.0)
+    cost.set_covariance(np.diag([1.0, 0.5, 2.0]))
+    for jac in (mo.JAC_ANALYTIC, mo.JAC_NUMERIC):
+        for variant in (mo.KERNEL_MOMENTS, mo.KERNEL_LITERAL):
+            cost.set_kernel_variant(variant)
+            xh, sh, ih = host_lm(cost, jac, np.zeros(6))
+            x, rep = mo.capi.lm_minimize([cost], [jac], np.zeros(6))
+            assert (rep["status"], rep["iterations"]) == (sh, ih)
+            assert np.abs(x - xh).max() < 1e-9 * max(1.0, np.abs(xh).max())
+    cost.close()
+
+
+def test_every_optimization_status(hip_lib):
+    mo = hip_lib
+    # CONVERGED by vanishing cost: exact correspondences
+    src, tgt = ds.synthetic_pair(4000, seed=2, noise=0.0)
+    cost = mo.Point2PointCost(src, tgt)
+    x, rep = mo.capi.lm_minimize([cost], [mo.JAC_NUMERIC], np.zeros(6), max_iterations=30)
+    assert rep["status"] == CONVERGED and np.abs(x - ds.FIXTURE_X).max() < 1e-8
+    # MAXIMUM_ITERATIONS_REACHED
+    x, rep = mo.capi.lm_minimize([cost], [mo.JAC_NUMERIC], np.zeros(6), max_iterations=2)
+    assert rep["status"] == MAX_ITERATIONS and rep["iterations"] == 2
+    # zero iterations: the loop body never runs, x untouched, no sweep
+    x, rep = mo.capi.lm_minimize([cost], [mo.JAC_NUMERIC], np.full(6, 0.25), max_iterations=0)
+    assert rep["status"] == MAX_ITERATIONS and rep["sweeps"] == 0 and np.all(x == 0.25)
+    cost.close()
+    # SMALL_DELTA: noisy data, started at the optimum found by a first run
+    src, tgt = ds.synthetic_pair(4000, seed=3, noise=0.05)
+    cost = mo.Point2PointCost(src, tgt)
+    x1, rep1 = mo.capi.lm_minimize([cost], [mo.JAC_NUMERIC], np.zeros(6), max_iterations=50)
+    xh, sh, ih = host_lm(cost, mo.JAC_NUMERIC, np.zeros(6), max_iter=50)
+    assert rep1["status"] == sh == SMALL_DELTA and rep1["iterations"] == ih
+    assert np.abs(x1 - xh).max() < 1e-9 * np.abs(xh).max()
+    cost.close()
+    # NUMERIC_ERROR: a NaN source coordinate makes every trial cost NaN (:88-91)
+    bad = src.copy()
+    bad[17, 1] = np.nan
+    cost = mo.Point2PointCost(bad, tgt)
+    x, rep = mo.capi.lm_minimize([cost], [mo.JAC_ANALYTIC], np.zeros(6))
+    assert rep["status"] == NUMERIC_ERROR
+    cost.close()
+
+
+def test_camera_calibration_two_costs_with_robust_loss(hip_lib, oracle):
+    """tst/camera_calibration.cpp / multiple_objectives.cpp shape: two reprojection costs summed."""
+    mo = hip_lib
+    pts, pix = ds.synthetic_camera(20_000, seed=17)
+    split = 8000
+    costs = [mo.ReprojectionCost(pts[:split], pix[:split]), mo.ReprojectionCost(pts[split:], pix[split:])]
+    for c in costs:
+        c.set_loss(mo.LOSS_GEMAN_MCCLURE, 100.0)
+    x, rep = mo.capi.lm_minimize(costs, [mo.JAC_NUMERIC] * 2, np.zeros(6), max_iterations=25)
+    xr, status, iters = oracle.camera_minimize(pts, pix, [split, len(pts) - split], np.zeros(6),
+                                               max_iter=25, loss_kind=1, loss_param=100.0)
+    assert (rep["status"], rep["iterations"]) == (status, iters)
+    assert np.abs(x - xr).max() < 1e-7  # pixel rounding makes the valley flat: forward differences
+    for c in costs:
+        c.close()
+
+
+def test_float32_cost(hip_lib):
+    mo = hip_lib
+    src, tgt = ds.synthetic_pair(20_000, seed=4, noise=0.01, dtype=np.float32)
+    cost = mo.Point2PointCost(src, tgt, dtype=np.float32)
+    x, rep = mo.capi.lm_minimize([cost], [mo.JAC_ANALYTIC], np.zeros(6, dtype=np.float32),
+                                 max_iterations=30)
+    assert x.dtype == np.float32
+    assert np.abs(x - ds.FIXTURE_X).max() < 5e-3
+    cost.close()
+
+
+def test_blocking_calls_still_work_after_a_device_resident_solve(hip_lib, oracle):
+    mo = hip_lib
+    src, tgt = ds.synthetic_pair(30_000, seed=6, noise=0.01)
+    cost = mo.Point2PointCost(src, tgt)
+    before = cost.linearize(ds.X_GENERIC, mo.JAC_NUMERIC)
+    mo.capi.lm_minimize([cost], [mo.JAC_NUMERIC], np.zeros(6))
+    after = cost.linearize(ds.X_GENERIC, mo.JAC_NUMERIC)
+    for a, b in zip(before, after):
+        assert np.asarray(a).tobytes() == np.asarray(b).tobytes()
+    cost.set_loss(mo.LOSS_GEMAN_MCCLURE, 10.0)  # the resident constants are re-uploaded
+    x, rep = mo.capi.lm_minimize([cost], [mo.JAC_NUMERIC], np.zeros(6))
+    xh, sh, ih = host_lm(cost, mo.JAC_NUMERIC, np.zeros(6))
+    assert (rep["status"], rep["iterations"]) == (sh, ih) and np.abs(x - xh).max() < 1e-9 * 11
+    cost.close()

@@ -67,6 +67,17 @@ def test_ranks_combine_through_the_library(hip_lib, tmp_path, world):
             assert res[r][name + "_chain"].tobytes() == res[0]["group_chain"].tobytes()
 
 
+def test_device_resident_lm_over_sharded_cost(hip_lib, tmp_path):
+    """mopt_lm_minimize on every rank with MOPT_COMBINE_PEER: all ranks return the same x, bit for
+    bit, and it is the solution of the unsharded problem."""
+    res = run_ranks(tmp_path, 2, 200_003)
+    assert list(res[0]["lm_rep"]) == list(res[1]["lm_rep"]) == list(res[0]["lm_whole_rep"])
+    assert res[0]["lm_x"].tobytes() == res[1]["lm_x"].tobytes()
+    assert np.abs(res[0]["lm_x"] - res[0]["lm_whole_x"]).max() < 1e-9 * 11
+    assert np.abs(res[0]["lm_x"] - ds.FIXTURE_X).max() < 1e-3  # noisy data: near the fixture pose
+    assert res[0]["after_lm_H"].tobytes() == res[1]["after_lm_H"].tobytes()
+
+
 def test_sharded_sums_match_the_unsharded_cost(hip_lib, tmp_path, oracle):
     """Shard-invariance against the oracle on the whole data set (1e-6 bar; the sums differ from a
     single-cost sweep only by fp64 reassociation)."""
