@@ -17,22 +17,26 @@ int ensureWorkspace(mopt_cost *c) {
     MOPT_HIP_TRY(deviceAlloc(reinterpret_cast<void **>(&c->d_lm_control), sizeof(mopt::LmControl)));
   if (!c->d_lm_state) MOPT_HIP_TRY(deviceAlloc(&c->d_lm_state, 4096));  // >= LmState<double>
   if (!c->h_lm_report) {
-    MOPT_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_lm_report), sizeof(mopt::LmReport),
+    MOPT_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_lm_report),
+                               2 * sizeof(mopt::LmReport),
                                hipHostMallocMapped | hipHostMallocCoherent));
-    std::memset(c->h_lm_report, 0, sizeof(mopt::LmReport));
+    std::memset(c->h_lm_report, 0, 2 * sizeof(mopt::LmReport));
     MOPT_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->h_lm_report_dev),
                                          c->h_lm_report, 0));
   }
   return MOPT_OK;
 }
 
-// A consistent copy of the report: the progress word is read before and after the payload.
+// A consistent copy of the latest report.  Run k of the step kernel writes its payload into
+// live[k & 1], drains it and only then stores k into the progress word live[0].flag; run k + 1
+// writes the other buffer.  So the payload of run k is complete when the word reads k, and stays
+// untouched until run k + 2 starts: a copy is good if the word has not moved past k + 1 meanwhile.
 unsigned long long readReport(const mopt::LmReport *live, mopt::LmReport *out) {
   for (;;) {
-    const unsigned long long before = __atomic_load_n(&live->flag, __ATOMIC_ACQUIRE);
-    std::memcpy(out, live, sizeof *out);
+    const unsigned long long k = __atomic_load_n(&live[0].flag, __ATOMIC_ACQUIRE);
+    std::memcpy(out, &live[k & 1], sizeof *out);
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    if (__atomic_load_n(&live->flag, __ATOMIC_ACQUIRE) == before) return before;
+    if (__atomic_load_n(&live[0].flag, __ATOMIC_ACQUIRE) <= k + 1) return k;
   }
 }
 
@@ -98,7 +102,7 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
   for (int k = 0; k < num_costs; ++k) base_sequence[k] = costs[k]->combine.sequence + 1;
 
   mopt::LmReport *live = lead->h_lm_report;
-  __atomic_store_n(&live->flag, 0ull, __ATOMIC_RELEASE);
+  __atomic_store_n(&live[0].flag, 0ull, __ATOMIC_RELEASE);
   if (lead->scalar_bytes == 8)
     MOPT_HIP_TRY(mopt::launchLmStep<double>(problem, true, static_cast<const double *>(x), s));
   else

@@ -390,9 +390,10 @@ __global__ __launch_bounds__(128) void lmStepKernel(const LmProblem P, int init,
   __syncthreads();
   if (propose) writeSweepConstants<S>(P, next_x);
 
-  // progress for the host: payload write-through, drained, then the progress word
+  // progress for the host: payload write-through into the buffer of this run's parity (the host
+  // may still be reading the previous run's), drained, then the progress word
   if (threadIdx.x == 0 && P.report) {
-    double *rep = reinterpret_cast<double *>(P.report);
+    double *rep = reinterpret_cast<double *>(P.report + (st.steps & 1));
     for (int i = 0; i < kMaxParams; ++i) storeReport(rep + i, double(st.x0[i]));
     storeReport(rep + 8, double(st.y0));
     storeReport(rep + 9, double(st.lambda));

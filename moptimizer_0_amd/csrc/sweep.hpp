@@ -208,7 +208,8 @@ struct LmReport {  // mapped host memory (as doubles so that one layout serves f
   double peer_status; // kStatusPeerTimeout when a rank went missing
   double pad[2];
   unsigned long long flag;  // progress word: number of step-kernel runs that have completed
-};
+};                          // (two of these in mapped memory: run k reports into [k & 1], the
+                            // progress word is [0].flag)
 
 struct LmProblem {
   int num_costs = 0;
