@@ -16,7 +16,7 @@ LIBDIR      = moptimizer_0_amd/lib
 LIB         = $(LIBDIR)/libmoptimizer_hip.so
 
 PUBLIC_HEADERS = include/moptimizer_hip.h include/moptimizer_amd/so3.hpp $(CSRC)/sweep.hpp \
-                 $(CSRC)/jit_model.hpp $(CSRC)/cost_state.hpp
+                 $(CSRC)/jit_model.hpp $(CSRC)/cost_state.hpp $(CSRC)/lm_device.hpp
 
 all: $(LIB)
 

@@ -291,9 +291,19 @@ class JitDeviceModel : public DeviceModel<Scalar> {
 };
 
 // ---- cost functions ---------------------------------------------------------------------------
+// What the device-resident LM loop (levenberg_marquadt_device.hpp) needs to know of a cost it is
+// handed as a CostFunctionBase*: the device object behind it and which Jacobian its class stands for.
+class DeviceCostAccess {
+ public:
+  virtual ~DeviceCostAccess() = default;
+  virtual mopt_cost *deviceCost() const = 0;  // nullptr for a cost sharded over a device group
+  virtual int deviceJacobianMode() const = 0;
+  virtual void syncDeviceState() = 0;  // forward the current loss / covariance to the device
+};
+
 // Shared implementation; JacobianMode selects what linearize() means.
 template <class Scalar, int JacobianMode>
-class CostFunctionHip : public CostFunctionBase<Scalar> {
+class CostFunctionHip : public CostFunctionBase<Scalar>, public DeviceCostAccess {
  public:
   using Base = CostFunctionBase<Scalar>;
   using typename Base::ModelPtr;
@@ -355,6 +365,9 @@ class CostFunctionHip : public CostFunctionBase<Scalar> {
 
   mopt_cost *handle() const { return handle_; }
   mopt_group *group() const { return group_; }
+  mopt_cost *deviceCost() const override { return handle_; }
+  int deviceJacobianMode() const override { return JacobianMode; }
+  void syncDeviceState() override { pushState(); }
 
  protected:
   // setLossFunction / setCovariance are non-virtual setters on the base (cost_function.h:37-40),

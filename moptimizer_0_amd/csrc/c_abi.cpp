@@ -727,7 +727,7 @@ int residentPrepare(mopt_cost *c, int jac_mode, hipStream_t s, mopt::LmCostDesc 
 }
 
 int residentSweep(mopt_cost *c, int jac_mode, mopt::LmControl *control, hipStream_t s,
-                  unsigned long long base_sequence) {
+                  unsigned long long base_sequence, const mopt::LmProblem *step, int own_index) {
   mopt::PeerCombine pc;
   const mopt::PeerCombine *peers = nullptr;
   if (c->combine.mode == MOPT_COMBINE_PEER) {
@@ -758,7 +758,8 @@ int residentSweep(mopt_cost *c, int jac_mode, mopt::LmControl *control, hipStrea
               static_cast<const float *>(c->d_tiles), c->num_tiles,
               static_cast<const mopt::P2PSweepArgs<float> *>(c->d_lm_args), control, grid, site));
         MOPT_HIP_TRY(mopt::launchFinalizeMomentsResident(c->d_partials, grid, c->d_lm_basis,
-                                                         c->d_result, control, s, peers));
+                                                         c->d_result, control, s, peers, step,
+                                                         own_index, c->scalar_bytes));
       } else {
         const int grid = gridFor(c, blocksPerCu(2));
         const int nacc = c->cov_mode == mopt::kCovGeneral ? mopt::kAccFull : mopt::kAccSym;
@@ -771,7 +772,8 @@ int residentSweep(mopt_cost *c, int jac_mode, mopt::LmControl *control, hipStrea
               static_cast<const mopt::P2PSweepArgs<float> *>(c->d_lm_args), control, jac_mode,
               c->cov_mode, grid, site));
         MOPT_HIP_TRY(mopt::launchFinalizeDenseResident(c->d_partials, grid, nacc, kNumParams,
-                                                       c->d_result, control, s, peers));
+                                                       c->d_result, control, s, peers, step,
+                                                       own_index, c->scalar_bytes));
       }
       return MOPT_OK;
     }
@@ -781,7 +783,8 @@ int residentSweep(mopt_cost *c, int jac_mode, mopt::LmControl *control, hipStrea
       MOPT_HIP_TRY(mopt::launchReprojResident(
           static_cast<const mopt::ReprojSweepArgs *>(c->d_lm_args), control, c->cov_mode, grid, site));
       MOPT_HIP_TRY(mopt::launchFinalizeDenseResident(c->d_partials, grid, nacc, kNumParams,
-                                                     c->d_result, control, s, peers));
+                                                     c->d_result, control, s, peers, step, own_index,
+                                                     c->scalar_bytes));
       return MOPT_OK;
     }
     case kModelScalar: {
@@ -799,7 +802,8 @@ int residentSweep(mopt_cost *c, int jac_mode, mopt::LmControl *control, hipStrea
             static_cast<const mopt::ScalarSweepArgs<float> *>(c->d_lm_args), control,
             c->scalar_model, jac_mode, c->cov_mode, grid, s));
       MOPT_HIP_TRY(mopt::launchFinalizeDenseResident(c->d_partials, grid, nacc, n, c->d_result,
-                                                     control, s, peers));
+                                                     control, s, peers, step, own_index,
+                                                     c->scalar_bytes));
       return MOPT_OK;
     }
     default:

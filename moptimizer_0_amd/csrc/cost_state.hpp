@@ -208,8 +208,10 @@ void releaseCombine(mopt_cost *c);  // combine.cpp: unmaps / closes whatever was
 // constants if it changed and describe the cost to the step kernel; enqueue one resident sweep +
 // finalize on `s` (peer-combine sequence numbers = base_sequence + trials counted on the device)
 int residentPrepare(mopt_cost *c, int jac_mode, hipStream_t s, mopt::LmCostDesc *desc);
+// `step` non-NULL: this is the last cost of the problem, its finalize kernel also runs the LM step
 int residentSweep(mopt_cost *c, int jac_mode, mopt::LmControl *control, hipStream_t s,
-                  unsigned long long base_sequence);
+                  unsigned long long base_sequence, const mopt::LmProblem *step = nullptr,
+                  int own_index = 0);
 void releaseResident(mopt_cost *c);
 void destroyCost(mopt_cost *c);
 // enqueue one linearization / cost sweep + its finalize on `s`; results to d_result (+ optional

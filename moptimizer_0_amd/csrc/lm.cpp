@@ -17,27 +17,19 @@ int ensureWorkspace(mopt_cost *c) {
     MOPT_HIP_TRY(deviceAlloc(reinterpret_cast<void **>(&c->d_lm_control), sizeof(mopt::LmControl)));
   if (!c->d_lm_state) MOPT_HIP_TRY(deviceAlloc(&c->d_lm_state, 4096));  // >= LmState<double>
   if (!c->h_lm_report) {
-    MOPT_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_lm_report),
-                               2 * sizeof(mopt::LmReport),
+    MOPT_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_lm_report), sizeof(mopt::LmReport),
                                hipHostMallocMapped | hipHostMallocCoherent));
-    std::memset(c->h_lm_report, 0, 2 * sizeof(mopt::LmReport));
+    std::memset(c->h_lm_report, 0, sizeof(mopt::LmReport));
     MOPT_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->h_lm_report_dev),
                                          c->h_lm_report, 0));
   }
   return MOPT_OK;
 }
 
-// A consistent copy of the latest report.  Run k of the step kernel writes its payload into
-// live[k & 1], drains it and only then stores k into the progress word live[0].flag; run k + 1
-// writes the other buffer.  So the payload of run k is complete when the word reads k, and stays
-// untouched until run k + 2 starts: a copy is good if the word has not moved past k + 1 meanwhile.
-unsigned long long readReport(const mopt::LmReport *live, mopt::LmReport *out) {
-  for (;;) {
-    const unsigned long long k = __atomic_load_n(&live[0].flag, __ATOMIC_ACQUIRE);
-    std::memcpy(out, &live[k & 1], sizeof *out);
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    if (__atomic_load_n(&live[0].flag, __ATOMIC_ACQUIRE) <= k + 1) return k;
-  }
+// The progress word: 2 * (step runs completed) + 1 once the loop has stopped.  The payload of the
+// report is written once, before the word gets its low bit.
+inline unsigned long long progressWord(const mopt::LmReport *live) {
+  return __atomic_load_n(&live->flag, __ATOMIC_ACQUIRE);
 }
 
 }  // namespace
@@ -102,7 +94,7 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
   for (int k = 0; k < num_costs; ++k) base_sequence[k] = costs[k]->combine.sequence + 1;
 
   mopt::LmReport *live = lead->h_lm_report;
-  __atomic_store_n(&live[0].flag, 0ull, __ATOMIC_RELEASE);
+  __atomic_store_n(&live->flag, 0ull, __ATOMIC_RELEASE);
   if (lead->scalar_bytes == 8)
     MOPT_HIP_TRY(mopt::launchLmStep<double>(problem, true, static_cast<const double *>(x), s));
   else
@@ -116,23 +108,22 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
   static const int default_window = envInt("MOPT_LM_WINDOW", 3);
   const int window = opt.window > 0 ? opt.window : default_window;
   long long enqueued = 0;
-  mopt::LmReport snap;
   const auto started = std::chrono::steady_clock::now();
   unsigned long long spins = 0;
   for (;;) {
-    const unsigned long long steps = readReport(live, &snap);
-    const long long completed = steps > 0 ? (long long)steps - 1 : 0;  // the init run counts one
-    if (steps > 0 && int(snap.status) != mopt::kLmRunning) break;
+    const unsigned long long word = progressWord(live);
+    if (word & 1ull) break;  // the loop has stopped and its report is complete
+    const long long steps = (long long)(word >> 1);
+    const long long completed = steps > 0 ? steps - 1 : 0;  // the init run counts one
     bool queued = false;
     while (enqueued < max_points && enqueued - completed < window) {
+      // per point: every cost's sweep + finalize; the last finalize also takes the LM step
       for (int k = 0; k < num_costs; ++k) {
-        rc = residentSweep(costs[k], jacobian_modes[k], problem.control, s, base_sequence[k]);
+        const bool last = k == num_costs - 1;
+        rc = residentSweep(costs[k], jacobian_modes[k], problem.control, s, base_sequence[k],
+                           last ? &problem : nullptr, k);
         if (rc != MOPT_OK) return rc;
       }
-      if (lead->scalar_bytes == 8)
-        MOPT_HIP_TRY(mopt::launchLmStep<double>(problem, false, nullptr, s));
-      else
-        MOPT_HIP_TRY(mopt::launchLmStep<float>(problem, false, nullptr, s));
       ++enqueued;
       queued = true;
     }
@@ -142,8 +133,7 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
       if (q != hipSuccess && q != hipErrorNotReady)
         return fail(MOPT_ERR_HIP, std::string("device-resident LM failed: ") + hipGetErrorString(q));
       if (q == hipSuccess) {
-        const unsigned long long now = readReport(live, &snap);
-        if (now > 0 && int(snap.status) != mopt::kLmRunning) break;
+        if (progressWord(live) & 1ull) break;
         if (enqueued >= max_points)
           return fail(MOPT_ERR_HIP, "device-resident LM drained without reaching a status");
       }
@@ -152,6 +142,8 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
     }
     __builtin_ia32_pause();
   }
+  mopt::LmReport snap;
+  std::memcpy(&snap, live, sizeof snap);
 
   const long long trials = (long long)snap.trials;
   for (int k = 0; k < num_costs; ++k) {

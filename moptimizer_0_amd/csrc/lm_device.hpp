@@ -1,0 +1,619 @@
+// Device code of the device-resident Levenberg-Marquardt step (see lm_kernels.hip for what it does
+// and which reference lines it follows).  Included by lm_kernels.hip (the stand-alone step / init
+// kernel) and by sweep_kernels.hip, whose finalize kernels run the step in the same launch when
+// they belong to the last cost of a problem.  Everything here is in an anonymous namespace of the
+// including translation unit.
+#pragma once
+
+#include "sweep.hpp"
+
+#include <limits>
+
+namespace mopt {
+namespace {
+
+template <typename S>
+struct LmState {
+  S x0[kMaxParams];
+  S xi[kMaxParams];
+  S delta[kMaxParams];
+  S H[kMaxParams * kMaxParams];  // column-major n x n, at x0
+  S b[kMaxParams];
+  S y0;
+  S lambda;
+  S nu;
+  int k;            // trial points tried in this outer iteration
+  int it;           // executed outer iterations
+  int awaiting_x0;  // the sweep in flight is the linearization at x0, not a trial
+  int status;       // LmStatus
+  int trials;
+  unsigned long long steps;  // step-kernel runs: the host's progress word
+};
+
+template <typename S>
+struct LmStart {
+  S x[kMaxParams];
+};
+
+__device__ __forceinline__ void sinCosOf(double t, double *s, double *c) { sincos(t, s, c); }
+__device__ __forceinline__ void sinCosOf(float t, float *s, float *c) { sincosf(t, s, c); }
+
+// x = (t, w) -> row-major 3x4 [Exp(w) | t], the arithmetic of include/moptimizer_amd/so3.hpp
+// (so3::convert6DOFParameterToMatrix + so3::Exp, src/so3.cpp:7-19,43-57).
+template <typename S>
+__device__ void rigidFrom6DOF(const S *x, S (&T)[12]) {
+#pragma clang fp contract(off)
+  const S *w = x + 3;
+  S R[9];
+  const S theta = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  if (theta > S(10) * std::numeric_limits<S>::epsilon()) {
+    const S ax = w[0] / theta, ay = w[1] / theta, az = w[2] / theta;
+    S s, c;
+    sinCosOf(theta, &s, &c);
+    const S c1 = S(1) - c;
+    const S xx = ax * ax, yy = ay * ay, zz = az * az;
+    R[0] = S(1) + c1 * (-(yy + zz));
+    R[1] = s * (-az) + c1 * (ax * ay);
+    R[2] = s * (ay) + c1 * (ax * az);
+    R[3] = s * (az) + c1 * (ax * ay);
+    R[4] = S(1) + c1 * (-(xx + zz));
+    R[5] = s * (-ax) + c1 * (ay * az);
+    R[6] = s * (-ay) + c1 * (ax * az);
+    R[7] = s * (ax) + c1 * (ay * az);
+    R[8] = S(1) + c1 * (-(xx + yy));
+  } else {
+    R[0] = 1; R[1] = 0; R[2] = 0;
+    R[3] = 0; R[4] = 1; R[5] = 0;
+    R[6] = 0; R[7] = 0; R[8] = 1;
+  }
+  for (int i = 0; i < 3; ++i) {
+    T[i * 4 + 0] = R[i * 3 + 0];
+    T[i * 4 + 1] = R[i * 3 + 1];
+    T[i * 4 + 2] = R[i * 3 + 2];
+    T[i * 4 + 3] = x[i];
+  }
+}
+
+// Forward-difference step of linearization.h:85-89.
+template <typename S>
+__device__ __forceinline__ S forwardStep(S xj) {
+#pragma clang fp contract(off)
+  const S min_step = sqrt(std::numeric_limits<S>::epsilon());
+  S h = min_step * fabs(xj);
+  if (h == S(0)) h = min_step;
+  return h;
+}
+
+// delta = (H + lambda diag H)^{-1} (-b) by LDL^T with diagonal pivoting: the factorisation the
+// reference asks Eigen for (levenberg_marquadt_dyn.cpp:78-80), operation for operation the host
+// statement of tests/support/moptimizer_caller/ldlt.hpp (vanishing pivots give a zero component).
+// Runs on one lane; its work arrays live in LDS (indexed dynamically: as private arrays they would
+// go to scratch memory, a global-memory round trip per dependent access).
+template <typename S>
+struct SolveScratch {
+  S m[kMaxParams][kMaxParams];
+  S scaled[kMaxParams], y[kMaxParams];
+  int perm[kMaxParams];
+};
+
+template <typename S>
+__device__ void solveDamped(const S *H, const S *b, S lambda, int n, S *delta,
+                            SolveScratch<S> &w) {
+#pragma clang fp contract(off)
+  auto &m = w.m;
+  auto &perm = w.perm;
+  auto &scaled = w.scaled;
+  auto &y = w.y;
+  for (int c = 0; c < n; ++c)
+    for (int r = 0; r < n; ++r) m[r][c] = H[c * n + r];
+  for (int i = 0; i < n; ++i) {
+    m[i][i] += lambda * H[i * n + i];
+    perm[i] = i;
+  }
+  for (int k = 0; k < n; ++k) {
+    int piv = k;
+    S best = fabs(m[k][k]);
+    for (int i = k + 1; i < n; ++i) {
+      const S v = fabs(m[i][i]);
+      if (v > best) {
+        best = v;
+        piv = i;
+      }
+    }
+    if (piv != k) {  // exchange rows / columns k < piv of the symmetric matrix in the lower triangle
+      const int a = k, bb = piv;
+      for (int j = 0; j < a; ++j) { const S t = m[a][j]; m[a][j] = m[bb][j]; m[bb][j] = t; }
+      for (int i = bb + 1; i < n; ++i) { const S t = m[i][a]; m[i][a] = m[i][bb]; m[i][bb] = t; }
+      for (int i = a + 1; i < bb; ++i) { const S t = m[i][a]; m[i][a] = m[bb][i]; m[bb][i] = t; }
+      { const S t = m[a][a]; m[a][a] = m[bb][bb]; m[bb][bb] = t; }
+      { const int t = perm[a]; perm[a] = perm[bb]; perm[bb] = t; }
+    }
+    S dk = m[k][k];
+    for (int j = 0; j < k; ++j) {
+      scaled[j] = m[k][j] * m[j][j];
+      dk -= m[k][j] * scaled[j];
+    }
+    m[k][k] = dk;
+    for (int i = k + 1; i < n; ++i) {
+      S v = m[i][k];
+      for (int j = 0; j < k; ++j) v -= m[i][j] * scaled[j];
+      m[i][k] = v;
+    }
+    if (fabs(dk) > S(0))
+      for (int i = k + 1; i < n; ++i) m[i][k] /= dk;
+  }
+  for (int i = 0; i < n; ++i) y[i] = -b[perm[i]];
+  for (int i = 0; i < n; ++i) {
+    S v = y[i];
+    for (int j = 0; j < i; ++j) v -= m[i][j] * y[j];
+    y[i] = v;
+  }
+  const S tiny = std::numeric_limits<S>::min();
+  for (int i = 0; i < n; ++i) {
+    const S d = m[i][i];
+    y[i] = (fabs(d) > tiny) ? y[i] / d : S(0);
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    S v = y[i];
+    for (int j = i + 1; j < n; ++j) v -= m[j][i] * y[j];
+    y[i] = v;
+  }
+  for (int i = 0; i < n; ++i) delta[perm[i]] = y[i];
+}
+
+// The same factorisation for a compile-time n, fully unrolled so that the matrix lives in registers
+// (every index is a constant after unrolling; the run-time pivot choice becomes a chain of
+// predicated swaps).  One lane runs it: ~n^3 / 3 dependent fp64 operations instead of as many LDS
+// round trips.  Same operations in the same order as solveDamped.
+template <typename S, int N>
+__device__ void solveDampedFixed(const S *H, const S *b, S lambda, S *delta) {
+#pragma clang fp contract(off)
+  S m[N][N];
+  S scaled[N], y[N];
+  int perm[N];
+#pragma unroll
+  for (int c = 0; c < N; ++c)
+#pragma unroll
+    for (int r = 0; r < N; ++r) m[r][c] = H[c * N + r];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    m[i][i] += lambda * H[i * N + i];
+    perm[i] = i;
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    int piv = k;
+    S best = fabs(m[k][k]);
+#pragma unroll
+    for (int i = k + 1; i < N; ++i) {
+      const S v = fabs(m[i][i]);
+      if (v > best) {
+        best = v;
+        piv = i;
+      }
+    }
+#pragma unroll
+    for (int p = k + 1; p < N; ++p) {
+      if (piv == p) {
+#pragma unroll
+        for (int j = 0; j < k; ++j) { const S t = m[k][j]; m[k][j] = m[p][j]; m[p][j] = t; }
+#pragma unroll
+        for (int i = p + 1; i < N; ++i) { const S t = m[i][k]; m[i][k] = m[i][p]; m[i][p] = t; }
+#pragma unroll
+        for (int i = k + 1; i < p; ++i) { const S t = m[i][k]; m[i][k] = m[p][i]; m[p][i] = t; }
+        { const S t = m[k][k]; m[k][k] = m[p][p]; m[p][p] = t; }
+        { const int t = perm[k]; perm[k] = perm[p]; perm[p] = t; }
+      }
+    }
+    S dk = m[k][k];
+#pragma unroll
+    for (int j = 0; j < k; ++j) {
+      scaled[j] = m[k][j] * m[j][j];
+      dk -= m[k][j] * scaled[j];
+    }
+    m[k][k] = dk;
+#pragma unroll
+    for (int i = k + 1; i < N; ++i) {
+      S v = m[i][k];
+#pragma unroll
+      for (int j = 0; j < k; ++j) v -= m[i][j] * scaled[j];
+      m[i][k] = v;
+    }
+    if (fabs(dk) > S(0)) {
+#pragma unroll
+      for (int i = k + 1; i < N; ++i) m[i][k] /= dk;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    S v = S(0);
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+      if (perm[i] == j) v = -b[j];
+    y[i] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    S v = y[i];
+#pragma unroll
+    for (int j = 0; j < i; ++j) v -= m[i][j] * y[j];
+    y[i] = v;
+  }
+  const S tiny = std::numeric_limits<S>::min();
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const S d = m[i][i];
+    y[i] = (fabs(d) > tiny) ? y[i] / d : S(0);
+  }
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+    S v = y[i];
+#pragma unroll
+    for (int j = i + 1; j < N; ++j) v -= m[j][i] * y[j];
+    y[i] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+      if (perm[i] == j) delta[j] = y[i];
+}
+
+// (K T) C, row-major 3x4: the matrix products of tst/camera_calibration.cpp:37 in the association
+// of the host statement (c_abi.cpp projectionFor).
+__device__ void projectionFor(const LmCostDesc &d, const double (&T)[12], double (&M)[12]) {
+#pragma clang fp contract(off)
+  double T4[16];
+  for (int r = 0; r < 3; ++r)
+    for (int k = 0; k < 4; ++k) T4[r * 4 + k] = T[r * 4 + k];
+  T4[12] = T4[13] = T4[14] = 0.0;
+  T4[15] = 1.0;
+  double KT[12];
+  for (int r = 0; r < 3; ++r)
+    for (int k = 0; k < 4; ++k) {
+      double v = 0.0;
+      for (int q = 0; q < 4; ++q) v += d.camera[r * 4 + q] * T4[q * 4 + k];
+      KT[r * 4 + k] = v;
+    }
+  for (int r = 0; r < 3; ++r)
+    for (int k = 0; k < 4; ++k) {
+      double v = 0.0;
+      for (int q = 0; q < 4; ++q) v += KT[r * 4 + q] * d.frame[q * 4 + k];
+      M[r * 4 + k] = v;
+    }
+}
+
+// The per-x constants of every cost's next sweep, at point x (LDS).  Lane j (0..6) forms the
+// transform at x (j = 0) or at x + h_j e_j.
+template <typename S>
+__device__ void writeSweepConstants(const LmProblem &P, const S *x) {
+  __shared__ S Tj[1 + kNumParams][12];
+  __shared__ S inv_h[kNumParams];
+  const int tid = threadIdx.x;
+  for (int ci = 0; ci < P.num_costs; ++ci) {
+    const LmCostDesc &d = P.cost[ci];
+    const bool numeric = d.jac_mode == kJacNumeric;
+    if (d.model == kLmPoint2Point || d.model == kLmReprojection) {
+      if (tid <= kNumParams) {
+        S xp[kNumParams];
+        for (int k = 0; k < kNumParams; ++k) xp[k] = x[k];
+        if (tid > 0) {
+          if (numeric) {
+            const S h = forwardStep<S>(x[tid - 1]);
+            xp[tid - 1] = x[tid - 1] + h;
+            inv_h[tid - 1] = S(1) / h;
+          } else {
+            inv_h[tid - 1] = S(0);
+          }
+        }
+        rigidFrom6DOF<S>(xp, Tj[tid]);
+      }
+      __syncthreads();
+      if (d.model == kLmPoint2Point) {
+        P2PSweepArgs<S> *a = static_cast<P2PSweepArgs<S> *>(d.args);
+        if (tid < (1 + kNumParams) * 12) a->T[tid / 12][tid % 12] = Tj[tid / 12][tid % 12];
+        if (tid < kNumParams) a->inv_h[tid] = inv_h[tid];
+        if (d.moments && numeric && tid < 18) {
+          // column j of J is ((R_j - R) p + (t_j - t)) / h_j  (c_abi.cpp fillBasis)
+          const int r = tid / 6, j = tid % 6;
+          d.basis->J[0][r * 6 + j] = double((Tj[1 + j][r * 4 + 3] - Tj[0][r * 4 + 3]) * inv_h[j]);
+          for (int k = 0; k < 3; ++k)
+            d.basis->J[1 + k][r * 6 + j] =
+                double((Tj[1 + j][r * 4 + k] - Tj[0][r * 4 + k]) * inv_h[j]);
+        }
+      } else {
+        if constexpr (sizeof(S) == 8) {
+          ReprojSweepArgs *a = static_cast<ReprojSweepArgs *>(d.args);
+          if (tid <= kNumParams) {
+            double M[12];
+            projectionFor(d, Tj[tid], M);
+            for (int k = 0; k < 12; ++k) a->M[tid][k] = M[k];
+            if (tid > 0) a->inv_h[tid - 1] = inv_h[tid - 1];
+          }
+        }
+      }
+      __syncthreads();
+    } else {  // scalar models: the sweep differentiates by itself, it needs x and the steps
+      ScalarSweepArgs<S> *a = static_cast<ScalarSweepArgs<S> *>(d.args);
+      if (tid < kMaxParams) {
+        const S xv = tid < P.n ? x[tid] : S(0);
+        a->x[tid] = xv;
+        a->h[tid] = forwardStep<S>(xv);
+      }
+    }
+  }
+}
+
+template <typename S>
+__device__ __forceinline__ bool isCostSmall(S y) {  // optimizer.h:26-29
+  return fabs(y) < S(8) * std::numeric_limits<S>::epsilon();
+}
+
+__device__ __forceinline__ void storeReport(double *p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p),
+                     static_cast<unsigned long long>(__double_as_longlong(v)), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+
+// One run of the LM step by the calling workgroup (any size >= 128 threads; all threads must call).
+//   init        start a minimisation from start.x
+//   own_result  H | b | sum_sq of cost `own_index` in LDS when the caller has just finalized it in
+//               this same launch (its copy in HBM may not be visible to this workgroup yet);
+//               nullptr when every cost's result comes from HBM
+//   state_word  word `threadIdx.x` of the stored state, loaded by the caller ahead of its own work
+//               so that the round trip overlaps it (ignored when `prefetched` is false)
+template <typename S>
+__device__ void lmStepBody(const LmProblem &P, bool init, const LmStart<S> &start,
+                           const double *own_result, int own_index, bool prefetched,
+                           unsigned int state_word) {
+#ifdef MOPT_LM_TIMING
+  __shared__ unsigned long long tick[8];
+#define MOPT_TICK(i) if (threadIdx.x == 0) tick[i] = wall_clock64()
+#else
+#define MOPT_TICK(i)
+#endif
+  MOPT_TICK(0);
+  LmControl *ctl = P.control;
+  // The loop's state lives in HBM between launches; this run works on a copy in LDS (loaded and
+  // written back by all lanes: one memory round trip each way instead of one per access).
+  __shared__ LmState<S> st;
+  __shared__ S sums[kMaxParams * kMaxParams + kMaxParams + 1];  // H | b | sum_sq over the costs
+  __shared__ S next_x[kMaxParams];
+  __shared__ int propose, finished;
+  __shared__ SolveScratch<S> solve_scratch;
+  LmState<S> *stored = static_cast<LmState<S> *>(P.state);
+  const int n = P.n;
+  const int nn = n * n;
+  const int tid = threadIdx.x;
+  constexpr int kStateWords = int(sizeof(LmState<S>) / sizeof(unsigned int));
+  if (!init) {
+    if (prefetched) {
+      if (tid < kStateWords) reinterpret_cast<unsigned int *>(&st)[tid] = state_word;
+    } else {
+      for (int i = tid; i < kStateWords; i += blockDim.x)
+        reinterpret_cast<unsigned int *>(&st)[i] = reinterpret_cast<const unsigned int *>(stored)[i];
+    }
+    // sums over the costs, accumulated in Scalar in cost order (:48-60, :86)
+    if (tid < nn + n + 1) {
+      S v = S(0);
+      for (int ci = 0; ci < P.num_costs; ++ci)
+        v += S((own_result && ci == own_index) ? own_result[tid] : P.cost[ci].result[tid]);
+      sums[tid] = v;
+    }
+  }
+  __syncthreads();
+  MOPT_TICK(1);
+
+  __shared__ int adopt_sums;
+  if (tid == 0) {
+#pragma clang fp contract(off)
+    // The decision runs on one lane, so what it costs is a chain of dependent operations: the
+    // small vectors are pulled into registers with constant indices (independent LDS reads, one
+    // wait), loops run to the compile-time bound under `i < n`, and the 43-value adoption of the
+    // sums as the new H | b is left to all lanes afterwards — the solve reads whichever copy holds
+    // the current H, b.
+    propose = 0;
+    finished = 0;
+    adopt_sums = 0;
+    S x0[kMaxParams], xi[kMaxParams], delta[kMaxParams], bcur[kMaxParams];
+#pragma unroll
+    for (int i = 0; i < kMaxParams; ++i) {
+      x0[i] = init ? (i < n ? start.x[i] : S(0)) : st.x0[i];
+      xi[i] = init ? x0[i] : st.xi[i];
+      delta[i] = init ? S(0) : st.delta[i];
+      bcur[i] = init ? S(0) : st.b[i];
+    }
+    S y0 = init ? S(0) : st.y0;
+    S lambda = init ? S(-1) : st.lambda;  // prepare(): :16-17
+    S nu = init ? S(2) : st.nu;
+    int k = init ? 0 : st.k;
+    int it = init ? 0 : st.it;
+    int status = kLmRunning;
+    const S *Hcur = st.H;  // where the current H | b live: the stored state, or the fresh sums
+    const S *bsrc = st.b;
+
+    auto finish = [&](int code) {
+      status = code;
+      finished = 1;
+    };
+    // (H + lambda D) delta = -b ; xi = x0 + delta  (levenberg_marquadt_dyn.cpp:78-83)
+    auto proposeTrial = [&]() {
+      MOPT_TICK(5);
+      switch (n) {
+        case 6: solveDampedFixed<S, 6>(Hcur, bsrc, lambda, delta); break;
+        case 4: solveDampedFixed<S, 4>(Hcur, bsrc, lambda, delta); break;
+        case 2: solveDampedFixed<S, 2>(Hcur, bsrc, lambda, delta); break;
+        default: {
+          S d[kMaxParams];
+          solveDamped<S>(Hcur, bsrc, lambda, n, d, solve_scratch);
+#pragma unroll
+          for (int i = 0; i < kMaxParams; ++i)
+            if (i < n) delta[i] = d[i];
+          break;
+        }
+      }
+      MOPT_TICK(6);
+#pragma unroll
+      for (int i = 0; i < kMaxParams; ++i) {
+        if (i < n) xi[i] = x0[i] + delta[i];
+        next_x[i] = xi[i];
+      }
+      propose = 1;
+    };
+    // top of an outer iteration once H, b, y0 at x0 are known (:62-70)
+    auto beginOuter = [&]() {
+      if (isCostSmall<S>(y0)) return finish(kLmConverged);
+      if (lambda < S(0)) {
+        S max_diag = 0;
+#pragma unroll
+        for (int i = 0; i < kMaxParams; ++i)
+          if (i < n) max_diag = fmax(max_diag, fabs(Hcur[i * n + i]));
+        lambda = S(1e-9) * max_diag;
+      }
+      nu = S(2);
+      k = 0;
+      proposeTrial();
+    };
+
+    if (init) {
+      st.awaiting_x0 = 1;
+      st.trials = 0;
+      st.steps = 0;
+#pragma unroll
+      for (int i = 0; i < kMaxParams; ++i) next_x[i] = x0[i];
+      propose = 1;
+    } else {
+      const S ys = sums[nn + n];
+      st.trials += 1;
+      auto adopt = [&]() {  // the sums become H | b | y0 (copied into the state by all lanes below)
+        adopt_sums = 1;
+        Hcur = sums;
+        bsrc = sums + nn;
+        y0 = ys;
+      };
+      if (st.awaiting_x0) {
+        st.awaiting_x0 = 0;
+        adopt();
+        beginOuter();
+      } else if (ys != ys) {
+        finish(kLmNumericError);  // :88-91
+      } else {
+        S predicted = S(0);
+#pragma unroll
+        for (int i = 0; i < kMaxParams; ++i)
+          if (i < n) predicted += delta[i] * (lambda * delta[i] - bcur[i]);
+        const S rho = (y0 - ys) / predicted;  // :93
+        if (rho < S(0)) {
+          S max_delta = S(0);
+#pragma unroll
+          for (int i = 0; i < kMaxParams; ++i)
+            if (i < n) max_delta = fmax(max_delta, fabs(delta[i]));
+          if (max_delta < sqrt(std::numeric_limits<S>::epsilon())) {  // delta.h:10-16
+            finish(isCostSmall<S>(ys) ? kLmConverged : kLmSmallDelta);
+          } else {
+            lambda = nu * lambda;  // :108-109
+            nu = S(2) * nu;
+            k += 1;
+            if (k < P.lm_max_iterations) {
+              proposeTrial();
+            } else {
+              // inner loop exhausted: the next outer iteration linearizes at the same x0, which
+              // gives the H, b, y0 already held
+              it += 1;
+              if (it >= P.max_iterations) finish(kLmMaxIterations);
+              else beginOuter();
+            }
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < kMaxParams; ++i)
+            if (i < n) x0[i] = xi[i];  // :112
+          const double t = 2.0 * double(rho) - 1.0;
+          const double shrink = fmax(1.0 / 3.0, 1.0 - t * t * t);  // :113
+          lambda = S(double(lambda) * shrink);
+          it += 1;
+          adopt();  // the trial sweep WAS the linearization at the new x0
+          if (it >= P.max_iterations) finish(kLmMaxIterations);
+          else beginOuter();
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < kMaxParams; ++i) {
+      st.x0[i] = x0[i];
+      st.xi[i] = xi[i];
+      st.delta[i] = delta[i];
+    }
+    st.y0 = y0;
+    st.lambda = lambda;
+    st.nu = nu;
+    st.k = k;
+    st.it = it;
+    st.status = status;
+    st.steps += 1;
+  }
+  __syncthreads();
+  if (init) {
+    for (int q = tid; q < kMaxParams * kMaxParams; q += blockDim.x) st.H[q] = S(0);
+    if (tid < kMaxParams) st.b[tid] = S(0);
+    __syncthreads();
+  } else if (adopt_sums) {
+    if (tid < nn) st.H[tid] = sums[tid];
+    else if (tid < nn + n) st.b[tid - nn] = sums[tid];
+    __syncthreads();
+  }
+  MOPT_TICK(2);
+  for (int i = tid; i < kStateWords; i += blockDim.x)
+    reinterpret_cast<unsigned int *>(stored)[i] = reinterpret_cast<const unsigned int *>(&st)[i];
+  if (tid == 0) {
+    if (init) {
+      ctl->pad[0] = 0;
+      ctl->pad[1] = 0;
+    }
+    ctl->trial = st.trials;
+    ctl->done = finished;
+  }
+  MOPT_TICK(3);
+  if (propose) writeSweepConstants<S>(P, next_x);
+  MOPT_TICK(4);
+
+  // For the host: the progress word after every run (one write-through store: the host only needs
+  // it to keep its queue a few points ahead), the whole report once, when the loop has stopped —
+  // payload write-through, drained, then the word with its low bit set.
+  if (tid == 0 && P.report) {
+    if (finished) {
+      double *rep = reinterpret_cast<double *>(P.report);
+      for (int i = 0; i < kMaxParams; ++i) storeReport(rep + i, double(st.x0[i]));
+      storeReport(rep + 8, double(st.y0));
+      storeReport(rep + 9, double(st.lambda));
+      storeReport(rep + 10, double(st.status));
+      storeReport(rep + 11, double(st.it));
+      storeReport(rep + 12, double(st.trials));
+      storeReport(rep + 13, double(ctl->pad[0]));
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#ifdef MOPT_LM_TIMING
+    // 10 ns ticks since entry: state+sums loaded | decision taken | state stored | constants written
+    if (!init && !finished)
+      printf("lm step %llu: load %llu decide %llu (before solve %llu, solve %llu) store %llu constants %llu (x10 ns)\n",
+             st.steps, tick[1] - tick[0], tick[2] - tick[1], tick[5] - tick[1], tick[6] - tick[5],
+             tick[3] - tick[2], tick[4] - tick[3]);
+#endif
+    __hip_atomic_store(&P.report->flag, st.steps * 2 + (finished ? 1ull : 0ull), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+#undef MOPT_TICK
+}
+
+// Word `threadIdx.x` of the stored state, for lmStepBody's `state_word`.
+template <typename S>
+__device__ __forceinline__ unsigned int lmPrefetchState(const LmProblem &P) {
+  constexpr int kStateWords = int(sizeof(LmState<S>) / sizeof(unsigned int));
+  return int(threadIdx.x) < kStateWords
+             ? reinterpret_cast<const unsigned int *>(P.state)[threadIdx.x]
+             : 0u;
+}
+
+}  // namespace
+}  // namespace mopt

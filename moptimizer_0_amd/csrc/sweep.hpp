@@ -207,9 +207,8 @@ struct LmReport {  // mapped host memory (as doubles so that one layout serves f
   double trials;      // sweeps evaluated
   double peer_status; // kStatusPeerTimeout when a rank went missing
   double pad[2];
-  unsigned long long flag;  // progress word: number of step-kernel runs that have completed
-};                          // (two of these in mapped memory: run k reports into [k & 1], the
-                            // progress word is [0].flag)
+  unsigned long long flag;  // progress word: 2 * (step runs completed) + (1 once the loop has
+};                          // stopped: only then is the payload above written, before the word)
 
 struct LmProblem {
   int num_costs = 0;
@@ -245,13 +244,17 @@ template <typename S>
 hipError_t launchScalarModelResident(const ScalarSweepArgs<S> *d_args, const LmControl *control,
                                      int model, int jac_mode, int cov_mode, int grid,
                                      hipStream_t stream);
+// `step` (optional): this is the last cost of the problem — run the LM step in the same launch
+// (`scalar_bytes` selects LevenbergMarquadtDynamic<float | double>, `own_index` = this cost's slot)
 hipError_t launchFinalizeDenseResident(const double *partials, int grid, int nacc, int n,
                                        double *result, LmControl *control, hipStream_t stream,
-                                       const PeerCombine *peers);
+                                       const PeerCombine *peers, const LmProblem *step = nullptr,
+                                       int own_index = 0, int scalar_bytes = 8);
 hipError_t launchFinalizeMomentsResident(const double *partials, int grid,
                                          const AffineBasis *d_basis, double *result,
                                          LmControl *control, hipStream_t stream,
-                                         const PeerCombine *peers);
+                                         const PeerCombine *peers, const LmProblem *step = nullptr,
+                                         int own_index = 0, int scalar_bytes = 8);
 
 // ---- launches (all asynchronous on `stream`) ------------------------------------------------
 template <typename S>

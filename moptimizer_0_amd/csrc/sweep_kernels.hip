@@ -20,6 +20,7 @@
 //   * A second tiny kernel adds the workgroup partials in a fixed order and writes
 //     H (column-major) | b | sum_sq; no atomics anywhere.
 #include "sweep.hpp"
+#include "lm_device.hpp"
 
 #include <hip/hip_ext.h>
 
@@ -864,7 +865,8 @@ __device__ __forceinline__ void columnTotals(const double *partials, int grid, i
 __device__ __forceinline__ unsigned long long finalizeDenseBody(const double *partials, int grid,
                                                                 int nacc, int n, double *result,
                                                                 const HostPublish &pub,
-                                                                const PeerCombine &pc) {
+                                                                const PeerCombine &pc,
+                                                                double *result_lds = nullptr) {
   __shared__ double scratch[kFinalThreads];
   __shared__ double total[kMaxAccumulators];
   columnTotals(partials, grid, nacc, scratch, total);
@@ -888,7 +890,10 @@ __device__ __forceinline__ unsigned long long finalizeDenseBody(const double *pa
   }
   unsigned long long status;
   v = peerCombine(pc, count, v, &status);
-  if (k < count) result[k] = v;
+  if (k < count) {
+    result[k] = v;
+    if (result_lds) result_lds[k] = v;
+  }
   publishToHost(pub, count, v, status);
   return status;
 }
@@ -902,25 +907,45 @@ __global__ __launch_bounds__(kFinalThreads) void finalizeDenseKernel(const doubl
 }
 
 // Resident forms (device-resident LM): nothing goes to the host, the peer-combine sequence number
-// is the base the host assigned plus the number of trials the step kernel has counted.
+// is the base the host assigned plus the number of trials the step kernel has counted.  STEP = 4 or
+// 8: this cost is the last of its problem and the LM step (lm_device.hpp) runs right here, on the
+// result still in LDS, as LevenbergMarquadtDynamic<float> or <double> — one launch and one memory
+// round trip less per evaluated point; the stored LM state is requested before the finalize work so
+// that its latency hides behind it.
+template <int STEP>
+struct StepScalar {
+  using type = double;
+};
+template <>
+struct StepScalar<4> {
+  using type = float;
+};
+
+template <int STEP>
 __global__ __launch_bounds__(kFinalThreads) void finalizeDenseResidentKernel(
     const double *partials, int grid, int nacc, int n, double *result, LmControl *control,
-    PeerCombine pc) {
+    PeerCombine pc, const LmProblem P, int own_index) {
   if (control->done) return;
+  using S = typename StepScalar<STEP>::type;
+  unsigned int state_word = 0;
+  if constexpr (STEP != 0) state_word = lmPrefetchState<S>(P);
+  __shared__ double own[kSlotData];
   pc.sequence += (unsigned long long)control->trial;
   const unsigned long long status =
-      finalizeDenseBody(partials, grid, nacc, n, result, HostPublish(), pc);
+      finalizeDenseBody(partials, grid, nacc, n, result, HostPublish(), pc, own);
   if (status && threadIdx.x == 0) control->pad[0] = int(status);  // a rank went missing
+  if constexpr (STEP != 0) {
+    __syncthreads();
+    lmStepBody<S>(P, false, LmStart<S>(), own, own_index, true, state_word);
+  }
 }
 
-// Moments -> H, b.  With p_0 = 1:  W(a,b) = sum w p_a p_b,  V(a,c) = sum w p_a r_c  and
-//   H(i,j) = sum_{a,b} W(a,b) (J_a^T S J_b)(i,j),   b(i) = sum_a (J_a^T S V(a,.))(i).
-// 576 threads form one (a,b) term of one H entry each, 24 threads one (a) term of one b entry.
 __device__ __forceinline__ unsigned long long finalizeMomentsBody(const double *partials, int grid,
                                                                   const AffineBasis &B,
                                                                   double *result,
                                                                   const HostPublish &pub,
-                                                                  const PeerCombine &pc) {
+                                                                  const PeerCombine &pc,
+                                                                  double *result_lds = nullptr) {
   __shared__ double scratch[kFinalThreads];
   __shared__ double total[kMaxAccumulators];
   __shared__ double terms[36 * 16 + 6 * 4];
@@ -976,7 +1001,10 @@ __device__ __forceinline__ unsigned long long finalizeMomentsBody(const double *
   }
   unsigned long long status;
   v = peerCombine(pc, kResultDoubles, v, &status);
-  if (t < kResultDoubles) result[t] = v;
+  if (t < kResultDoubles) {
+    result[t] = v;
+    if (result_lds) result_lds[t] = v;
+  }
   publishToHost(pub, kResultDoubles, v, status);
   return status;
 }
@@ -990,18 +1018,31 @@ __global__ __launch_bounds__(kFinalThreads) void finalizeMomentsKernel(const dou
   finalizeMomentsBody(partials, grid, B, result, pub, pc);
 }
 
+template <int STEP>
 __global__ __launch_bounds__(kFinalThreads) void finalizeMomentsResidentKernel(
     const double *partials, int grid, const AffineBasis *__restrict__ d_basis, double *result,
-    LmControl *control, PeerCombine pc) {
+    LmControl *control, PeerCombine pc, const LmProblem P, int own_index) {
   if (control->done) return;
+  using S = typename StepScalar<STEP>::type;
+  unsigned int state_word = 0;
+  if constexpr (STEP != 0) state_word = lmPrefetchState<S>(P);
+  // the basis is requested now and parked in LDS after the partial rows have been requested too
+  constexpr int kBasisDoubles = int(sizeof(AffineBasis) / sizeof(double));
+  const double basis_value = int(threadIdx.x) < kBasisDoubles
+                                 ? reinterpret_cast<const double *>(d_basis)[threadIdx.x]
+                                 : 0.0;
   __shared__ AffineBasis B;
-  for (int i = threadIdx.x; i < int(sizeof(AffineBasis) / sizeof(double)); i += kFinalThreads)
-    reinterpret_cast<double *>(&B)[i] = reinterpret_cast<const double *>(d_basis)[i];
+  __shared__ double own[kSlotData];
+  if (int(threadIdx.x) < kBasisDoubles) reinterpret_cast<double *>(&B)[threadIdx.x] = basis_value;
   __syncthreads();
   pc.sequence += (unsigned long long)control->trial;
   const unsigned long long status =
-      finalizeMomentsBody(partials, grid, B, result, HostPublish(), pc);
+      finalizeMomentsBody(partials, grid, B, result, HostPublish(), pc, own);
   if (status && threadIdx.x == 0) control->pad[0] = int(status);
+  if constexpr (STEP != 0) {
+    __syncthreads();
+    lmStepBody<S>(P, false, LmStart<S>(), own, own_index, true, state_word);
+  }
 }
 
 __global__ __launch_bounds__(kFinalThreads) void finalizeCostKernel(const double *partials,
@@ -1381,21 +1422,41 @@ template hipError_t launchScalarModelResident<double>(const ScalarSweepArgs<doub
                                                       hipStream_t);
 
 hipError_t launchFinalizeDenseResident(const double *partials, int grid, int nacc, int n,
-                                       double *result, LmControl *control,
-                                       hipStream_t stream, const PeerCombine *peers) {
+                                       double *result, LmControl *control, hipStream_t stream,
+                                       const PeerCombine *peers, const LmProblem *step,
+                                       int own_index, int scalar_bytes) {
   if (n < 1 || n > kMaxParams || (nacc != n * (n + 1) / 2 + n + 1 && nacc != n * n + n + 1))
     return hipErrorInvalidValue;
-  hipLaunchKernelGGL(finalizeDenseResidentKernel, dim3(1), dim3(kFinalThreads), 0, stream, partials,
-                     grid, nacc, n, result, control, peers ? *peers : PeerCombine());
+  const PeerCombine pc = peers ? *peers : PeerCombine();
+  const dim3 g(1), b(kFinalThreads);
+  if (!step)
+    hipLaunchKernelGGL(finalizeDenseResidentKernel<0>, g, b, 0, stream, partials, grid, nacc, n,
+                       result, control, pc, LmProblem(), 0);
+  else if (scalar_bytes == 8)
+    hipLaunchKernelGGL(finalizeDenseResidentKernel<8>, g, b, 0, stream, partials, grid, nacc, n,
+                       result, control, pc, *step, own_index);
+  else
+    hipLaunchKernelGGL(finalizeDenseResidentKernel<4>, g, b, 0, stream, partials, grid, nacc, n,
+                       result, control, pc, *step, own_index);
   return hipGetLastError();
 }
 
 hipError_t launchFinalizeMomentsResident(const double *partials, int grid,
                                          const AffineBasis *d_basis, double *result,
                                          LmControl *control, hipStream_t stream,
-                                         const PeerCombine *peers) {
-  hipLaunchKernelGGL(finalizeMomentsResidentKernel, dim3(1), dim3(kFinalThreads), 0, stream,
-                     partials, grid, d_basis, result, control, peers ? *peers : PeerCombine());
+                                         const PeerCombine *peers, const LmProblem *step,
+                                         int own_index, int scalar_bytes) {
+  const PeerCombine pc = peers ? *peers : PeerCombine();
+  const dim3 g(1), b(kFinalThreads);
+  if (!step)
+    hipLaunchKernelGGL(finalizeMomentsResidentKernel<0>, g, b, 0, stream, partials, grid, d_basis,
+                       result, control, pc, LmProblem(), 0);
+  else if (scalar_bytes == 8)
+    hipLaunchKernelGGL(finalizeMomentsResidentKernel<8>, g, b, 0, stream, partials, grid, d_basis,
+                       result, control, pc, *step, own_index);
+  else
+    hipLaunchKernelGGL(finalizeMomentsResidentKernel<4>, g, b, 0, stream, partials, grid, d_basis,
+                       result, control, pc, *step, own_index);
   return hipGetLastError();
 }
 

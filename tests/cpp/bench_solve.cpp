@@ -2,7 +2,9 @@
 // x0 = 0 to the fixture pose with the numerical cost), same LM loop, two cost implementations:
 //   CPU  oracle::CostFunctionNumericalDynamic  (restatement of the reference cost, its linearize
 //        single-threaded like the original)
-//   HIP  moptimizer::hip::CostFunctionNumericalDynamic (construction = PCIe copy included)
+//   HIP  moptimizer::hip::CostFunctionNumericalDynamic (construction = PCIe copy included), driven
+//        (a) by that same host loop through the boundary, (b) by the device-resident loop
+//        (moptimizer::hip::LevenbergMarquadtDevice = mopt_lm_minimize)
 //   bench_solve [N ...]     default 30000 1000000 10000000
 #include <chrono>
 #include <cmath>
@@ -12,6 +14,7 @@
 #include <vector>
 
 #include "moptimizer_amd/cost_function_hip.hpp"
+#include "moptimizer_amd/levenberg_marquadt_device.hpp"
 #include "moptimizer_caller/levenberg_marquadt.hpp"
 #include "moptimizer_amd/so3.hpp"
 
@@ -39,8 +42,10 @@ int main(int argc, char **argv) {
       double x[6] = {0, 0, 0, 0, 0, 0}, H[36], b[6];
       for (int k = 0; k < 50; ++k) cost.linearize(x, H, b);
     }
-    std::printf("| N | CPU solve ms (iterations) | HIP construct ms | HIP solve ms (iterations, sweeps) | "
-                "solve speed-up | incl. construction | max |x_cpu - x_hip| |\n|---|---|---|---|---|---|---|\n");
+    std::printf("| N | CPU solve ms (iterations) | HIP construct ms | HIP solve ms, host loop (iterations, sweeps) | "
+                "HIP solve ms, device-resident loop (iterations, sweeps) | us per sweep host / device | "
+                "speed-up vs CPU (device loop) | max |x_cpu - x_hip| host / device loop |\n"
+                "|---|---|---|---|---|---|---|---|\n");
     for (long n : sizes) {
       std::vector<double> src(size_t(n) * 3), tgt(size_t(n) * 3);
       std::mt19937_64 gen(42);
@@ -52,10 +57,10 @@ int main(int argc, char **argv) {
           tgt[3 * i + r] = T[0 * 4 + r] * src[3 * i] + T[1 * 4 + r] * src[3 * i + 1] +
                            T[2 * 4 + r] * src[3 * i + 2] + T[3 * 4 + r] + noise(gen);
       }
-      double x_cpu[6] = {0, 0, 0, 0, 0, 0}, x_hip[6] = {0, 0, 0, 0, 0, 0};
-      unsigned it_cpu = 0, it_hip = 0;
-      double cpu_ms = 0, build_ms = 0, hip_ms = 0;
-      long long sweeps = 0;
+      double x_cpu[6] = {0, 0, 0, 0, 0, 0}, x_hip[6] = {0, 0, 0, 0, 0, 0}, x_dev[6] = {0, 0, 0, 0, 0, 0};
+      unsigned it_cpu = 0, it_hip = 0, it_dev = 0;
+      double cpu_ms = 0, build_ms = 0, hip_ms = 0, dev_ms = 1e30;
+      long long sweeps = 0, dev_sweeps = 0;
       {
         auto model = std::make_shared<oracle::Point2Point<double>>(src.data(), tgt.data());
         oracle::CostFunctionNumericalDynamic<double> cost(model, 6, 3, int(n));
@@ -83,11 +88,27 @@ int main(int argc, char **argv) {
         mopt_cost_stats(cost.handle(), &s1, &h);
         sweeps = s1 - s0;
         it_hip = lm.getExecutedIterations();
+        // the same cost under the device-resident loop; best of a few solves from x0 = 0 (the first
+        // one also uploads the cost's static constants)
+        mh::LevenbergMarquadtDevice<double> dlm(6);
+        dlm.setMaximumIterations(50);
+        dlm.addCost(&cost);
+        for (int rep = 0; rep < 5; ++rep) {
+          for (double &v : x_dev) v = 0.0;
+          t0 = Clock::now();
+          dlm.minimize(x_dev);
+          dev_ms = std::min(dev_ms, msSince(t0));
+        }
+        dev_sweeps = dlm.sweeps();
+        it_dev = dlm.getExecutedIterations();
       }
-      double diff = 0;
+      double diff = 0, diff_dev = 0;
       for (int i = 0; i < 6; ++i) diff = std::max(diff, std::fabs(x_cpu[i] - x_hip[i]));
-      std::printf("| %ld | %.1f (%u) | %.2f | %.3f (%u, %lld) | %.0fx | %.0fx | %.1e |\n", n, cpu_ms, it_cpu,
-                  build_ms, hip_ms, it_hip, sweeps, cpu_ms / hip_ms, cpu_ms / (hip_ms + build_ms), diff);
+      for (int i = 0; i < 6; ++i) diff_dev = std::max(diff_dev, std::fabs(x_cpu[i] - x_dev[i]));
+      std::printf("| %ld | %.1f (%u) | %.2f | %.3f (%u, %lld) | %.3f (%u, %lld) | %.1f / %.1f | %.0fx | %.1e / %.1e |\n",
+                  n, cpu_ms, it_cpu, build_ms, hip_ms, it_hip, sweeps, dev_ms, it_dev, dev_sweeps,
+                  1e3 * hip_ms / double(sweeps), 1e3 * dev_ms / double(dev_sweeps), cpu_ms / dev_ms,
+                  diff, diff_dev);
       std::fflush(stdout);
     }
   } catch (const std::exception &e) {
