@@ -4,12 +4,14 @@
 //   bounding box of the targets -> cell ids -> stable sort of (cell id, index) -> cell offsets ->
 //   targets gathered cell by cell (32-byte padded), sources gathered in cell order.
 // Everything O(points) runs on the device; the host only picks the grid resolution from the six
-// bounding-box numbers.  The sort is rocPRIM's radix sort (through hipCUB): it is stable, so
-// inside a cell the points keep their original order, which is the tie-break rule the search
-// documents.  (The reference has no correspondence search to follow - model.h:24-26 leaves it
-// to the user's update().)
+// bounding-box numbers.  The sort is a least-significant-digit radix sort written here for wave64
+// (8-bit digits, as many passes as the cell count needs: 2-3 in practice): per pass a per-workgroup
+// digit histogram, one exclusive scan over the (digit, workgroup) table, and a scatter in which
+// every wavefront ranks its 64 keys among equal digits with eight ballots — no atomics on the
+// output, so the sort is stable: inside a cell the points keep their original order, which is the
+// tie-break rule the search documents.  (The reference has no correspondence search to follow -
+// model.h:24-26 leaves it to the user's update().)
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <vector>
 
@@ -67,11 +69,11 @@ struct GridShape {
   int dims[3];
 };
 
-// cell id of every point (clamped into the grid), and the identity permutation to carry along
+// cell id of every point (clamped into the grid)
 template <typename S>
 __global__ __launch_bounds__(kBlockThreads) void cellKeyKernel(const S *xyz, long long m,
                                                                const GridShape g,
-                                                               unsigned int *keys, int *index) {
+                                                               unsigned int *keys) {
   const long long i = (long long)blockIdx.x * kBlockThreads + threadIdx.x;
   if (i >= m) return;
   long long id = 0, stride = 1;
@@ -83,7 +85,98 @@ __global__ __launch_bounds__(kBlockThreads) void cellKeyKernel(const S *xyz, lon
     stride *= g.dims[a];
   }
   keys[i] = (unsigned int)id;
-  index[i] = int(i);
+}
+
+// ---- stable LSD radix sort of (cell id, point index) pairs, 8 bits per pass --------------------
+constexpr int kSortRounds = 8;                            // keys per thread
+constexpr int kSortTile = kBlockThreads * kSortRounds;    // keys per workgroup
+constexpr int kDigits = 256;
+static_assert(kBlockThreads == kDigits, "one thread per digit in the tables below");
+
+// hist[digit][workgroup]: how many keys of this workgroup's tile carry the digit
+__global__ __launch_bounds__(kBlockThreads) void radixHistogramKernel(
+    const unsigned int *__restrict__ keys, long long m, int shift, unsigned int *__restrict__ hist,
+    int num_groups) {
+  __shared__ unsigned int h[kDigits];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const long long base = (long long)blockIdx.x * kSortTile;
+#pragma unroll
+  for (int r = 0; r < kSortRounds; ++r) {
+    const long long i = base + r * kBlockThreads + threadIdx.x;
+    if (i < m) atomicAdd(&h[(keys[i] >> shift) & (kDigits - 1)], 1u);  // LDS atomic: counts only
+  }
+  __syncthreads();
+  hist[(size_t)threadIdx.x * num_groups + blockIdx.x] = h[threadIdx.x];
+}
+
+// In-place exclusive scan of `length` counters by one workgroup of 1024 threads: in the
+// digit-major table the result is the first output slot of every (digit, workgroup).
+__global__ __launch_bounds__(1024) void exclusiveScanKernel(unsigned int *data, long long length) {
+  __shared__ unsigned int part[1024];
+  const long long chunk = (length + 1023) / 1024;
+  const long long lo = (long long)threadIdx.x * chunk;
+  const long long hi = lo + chunk < length ? lo + chunk : length;
+  unsigned int sum = 0;
+  for (long long i = lo; i < hi; ++i) sum += data[i];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele over the 1024 chunk sums
+    const unsigned int add = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += add;
+    __syncthreads();
+  }
+  unsigned int run = threadIdx.x == 0 ? 0u : part[threadIdx.x - 1];
+  for (long long i = lo; i < hi; ++i) {
+    const unsigned int v = data[i];
+    data[i] = run;
+    run += v;
+  }
+}
+
+// values_in == nullptr: the value of key i is i (first pass).
+__global__ __launch_bounds__(kBlockThreads) void radixScatterKernel(
+    const unsigned int *__restrict__ keys_in, const int *__restrict__ values_in, long long m,
+    int shift, const unsigned int *__restrict__ offsets, int num_groups,
+    unsigned int *__restrict__ keys_out, int *__restrict__ values_out) {
+  __shared__ unsigned int next_slot[kDigits];                      // per digit, for this workgroup
+  __shared__ unsigned int wave_count[kBlockThreads / 64][kDigits];  // keys per (wave, digit), per round
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  next_slot[threadIdx.x] = offsets[(size_t)threadIdx.x * num_groups + blockIdx.x];
+  const long long base = (long long)blockIdx.x * kSortTile;
+  for (int r = 0; r < kSortRounds; ++r) {
+#pragma unroll
+    for (int w = 0; w < kBlockThreads / 64; ++w) wave_count[w][threadIdx.x] = 0;
+    __syncthreads();
+    const long long i = base + r * kBlockThreads + threadIdx.x;
+    const bool valid = i < m;
+    const unsigned int key = valid ? keys_in[i] : 0u;
+    const unsigned int digit = (key >> shift) & (kDigits - 1);
+    // lanes of this wavefront holding the same digit: eight ballots, one per bit
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (digit >> b) & 1u;
+      const unsigned long long with_bit = __ballot(bit);
+      peers &= bit ? with_bit : ~with_bit;
+    }
+    const unsigned int rank = (unsigned int)__popcll(peers & ((1ull << lane) - 1ull));
+    if (valid && rank == 0) wave_count[wave][digit] = (unsigned int)__popcll(peers);
+    __syncthreads();
+    if (valid) {
+      unsigned int before = 0;
+      for (int w = 0; w < wave; ++w) before += wave_count[w][digit];
+      const unsigned int pos = next_slot[digit] + before + rank;
+      keys_out[pos] = key;
+      values_out[pos] = values_in ? values_in[i] : int(i);
+    }
+    __syncthreads();
+    unsigned int used = 0;
+#pragma unroll
+    for (int w = 0; w < kBlockThreads / 64; ++w) used += wave_count[w][threadIdx.x];
+    next_slot[threadIdx.x] += used;  // column threadIdx.x is touched by this thread only from here on
+  }
 }
 
 // sorted keys -> offsets: cell_start[c] = first position whose key is >= c (c = 0 .. ncells, so the
@@ -164,34 +257,50 @@ hipError_t icpSortByCell(const S *d_xyz, long long m, const double origin[3], do
       return hipMemsetAsync(d_cell_start, 0, size_t(ncells + 1) * sizeof(int), stream);
     return hipSuccess;
   }
-  unsigned int *keys = nullptr, *keys_sorted = nullptr;
-  int *index = nullptr;
-  void *temp = nullptr;
+  // scratch: two key buffers, one value buffer (the other one is d_perm) and the histogram table
+  const int num_groups = int((m + kSortTile - 1) / kSortTile);
+  int bits = 1;
+  while ((1ll << bits) < ncells) ++bits;
+  const int passes = (bits + 7) / 8;
+  unsigned int *keys = nullptr, *keys_alt = nullptr, *hist = nullptr;
+  int *values_alt = nullptr;
   auto release = [&]() {
     if (keys) (void)hipFree(keys);
-    if (keys_sorted) (void)hipFree(keys_sorted);
-    if (index) (void)hipFree(index);
-    if (temp) (void)hipFree(temp);
+    if (keys_alt) (void)hipFree(keys_alt);
+    if (values_alt) (void)hipFree(values_alt);
+    if (hist) (void)hipFree(hist);
   };
   hipError_t e = hipMalloc(reinterpret_cast<void **>(&keys), size_t(m) * sizeof(unsigned int));
   if (e == hipSuccess)
-    e = hipMalloc(reinterpret_cast<void **>(&keys_sorted), size_t(m) * sizeof(unsigned int));
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&index), size_t(m) * sizeof(int));
+    e = hipMalloc(reinterpret_cast<void **>(&keys_alt), size_t(m) * sizeof(unsigned int));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&values_alt), size_t(m) * sizeof(int));
+  if (e == hipSuccess)
+    e = hipMalloc(reinterpret_cast<void **>(&hist), size_t(kDigits) * num_groups * sizeof(unsigned int));
   if (e != hipSuccess) {
     release();
     return e;
   }
   hipLaunchKernelGGL(cellKeyKernel<S>, dim3(blocksFor(m)), dim3(kBlockThreads), 0, stream, d_xyz, m,
-                     g, keys, index);
-  int bits = 1;
-  while ((1ll << bits) < ncells) ++bits;
-  size_t temp_bytes = 0;
-  e = hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys, keys_sorted, index, d_perm,
-                                         int(m), 0, bits, stream);
-  if (e == hipSuccess) e = hipMalloc(&temp, temp_bytes ? temp_bytes : 16);
-  if (e == hipSuccess)
-    e = hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, keys_sorted, index, d_perm,
-                                           int(m), 0, bits, stream);
+                     g, keys);
+  const unsigned int *keys_in = keys;
+  unsigned int *keys_out = keys_alt;
+  const int *values_in = nullptr;  // pass 1: value i = index i
+  for (int p = 0; p < passes; ++p) {
+    // ping-pong so that the last pass writes the permutation into d_perm
+    int *values_out = ((passes - 1 - p) % 2 == 0) ? d_perm : values_alt;
+    hipLaunchKernelGGL(radixHistogramKernel, dim3(num_groups), dim3(kBlockThreads), 0, stream,
+                       keys_in, m, 8 * p, hist, num_groups);
+    hipLaunchKernelGGL(exclusiveScanKernel, dim3(1), dim3(1024), 0, stream, hist,
+                       (long long)kDigits * num_groups);
+    hipLaunchKernelGGL(radixScatterKernel, dim3(num_groups), dim3(kBlockThreads), 0, stream, keys_in,
+                       values_in, m, 8 * p, hist, num_groups, keys_out, values_out);
+    values_in = values_out;
+    unsigned int *recycled = const_cast<unsigned int *>(keys_in);
+    keys_in = keys_out;
+    keys_out = recycled;
+  }
+  const unsigned int *keys_sorted = keys_in;
+  e = hipGetLastError();
   if (e == hipSuccess && d_cell_start) {
     hipLaunchKernelGGL(cellStartKernel, dim3(blocksFor(ncells + 1)), dim3(kBlockThreads), 0, stream,
                        keys_sorted, m, int(ncells), d_cell_start);

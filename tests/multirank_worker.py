@@ -68,7 +68,7 @@ def main():
         # point added over the ranks inside the finalize kernels: identical iterates everywhere
         cost.set_combine(mo.COMBINE_PEER)
         cost.set_loss(mo.LOSS_NONE)
-        x, rep = mo.capi.lm_minimize([cost], [mo.JAC_NUMERIC], np.zeros(6))
+        x, rep = mo.capi.lm_minimize([cost], [mo.JAC_ANALYTIC], np.zeros(6))
         res["lm_x"] = x
         res["lm_rep"] = np.array([rep["status"], rep["iterations"], rep["sweeps"]])
         # ... and the blocking path keeps working afterwards (sequence numbers stayed in step)
@@ -78,7 +78,7 @@ def main():
     dist.barrier()
     if rank == 0:
         whole = mo.Point2PointCost(src, tgt, device=device)
-        x, rep = mo.capi.lm_minimize([whole], [mo.JAC_NUMERIC], np.zeros(6))
+        x, rep = mo.capi.lm_minimize([whole], [mo.JAC_ANALYTIC], np.zeros(6))
         res["lm_whole_x"] = x
         res["lm_whole_rep"] = np.array([rep["status"], rep["iterations"], rep["sweeps"]])
         whole.close()
