@@ -402,6 +402,11 @@ using CostFunctionAnalyticalHip = CostFunctionHip<Scalar, MOPT_JAC_ANALYTIC>;
 // Bit-faithful to tst/point2point.cpp's Point2Point::f_df as written.
 template <class Scalar = double>
 using CostFunctionAnalyticalTstLayoutHip = CostFunctionHip<Scalar, MOPT_JAC_ANALYTIC_TST_LAYOUT>;
+// Point2point with the Jacobian of a left perturbation of the pose, [I | -skew(R p + t)]: the cost
+// to use with an SE(3) manifold update (LevenbergMarquadtDevice::setManifoldUpdate; the reference
+// leaves that update as a TODO, src/levenberg_marquadt_dyn.cpp:82-83).
+template <class Scalar = double>
+using CostFunctionAnalyticalLeftHip = CostFunctionHip<Scalar, MOPT_JAC_ANALYTIC_LEFT>;
 // Drop-in for CostFunctionNumericalDynamic: forward differences.
 template <class Scalar = double>
 using CostFunctionNumericalHip = CostFunctionHip<Scalar, MOPT_JAC_NUMERIC>;

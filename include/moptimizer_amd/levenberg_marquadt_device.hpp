@@ -38,6 +38,10 @@ class LevenbergMarquadtDevice {
   unsigned int getExecutedIterations() const { return executed_iterations_; }
   unsigned int getLevenbergMarquadtIterations() const { return lm_max_iterations_; }
   void setLevenbergMarquadtIterations(int max_iterations) { lm_max_iterations_ = max_iterations; }
+  // xi = x0 (+) delta on SE(3) (mopt_se3_plus) instead of the reference's xi = x0 + delta
+  // (levenberg_marquadt_dyn.cpp:82-83, "TODO Manifold operation"); 6-parameter poses, to be used
+  // with CostFunctionAnalyticalLeftHip costs.
+  void setManifoldUpdate(bool on) { manifold_update_ = on; }
 
   // Non-owning, as Optimizer::addCost (optimizer.h:58).
   void addCost(CostFunctionType *cost) {
@@ -71,7 +75,7 @@ class LevenbergMarquadtDevice {
     mopt_lm_options options;
     options.max_iterations = int(maximum_iterations_);
     options.lm_max_iterations = int(lm_max_iterations_);
-    options.manifold = 0;
+    options.manifold = manifold_update_ ? 1 : 0;
     options.window = 0;
     mopt_lm_report report;
     (void)num_parameters_;
@@ -92,6 +96,7 @@ class LevenbergMarquadtDevice {
   unsigned int maximum_iterations_ = 15;  // optimizer.h:19
   unsigned int lm_max_iterations_ = 3;    // levenberg_marquadt_dyn.cpp:9
   unsigned int executed_iterations_ = 0;
+  bool manifold_update_ = false;
   long long sweeps_ = 0;
   double final_cost_ = 0.0;
   std::vector<CostFunctionType *> costs_;

@@ -116,5 +116,42 @@ inline void logSO3(const Scalar R[9], Scalar w[3]) {
   w[2] = k * vz;
 }
 
+// so3::Log as the reference states it (src/so3.cpp:96-105): theta = 0 when trace > 3 - 1e-6, else
+// acos((trace - 1) / 2); w = K / 2 for |theta| < 1e-3, else theta / (2 sin theta) K, with
+// K = (R21 - R12, R02 - R20, R10 - R01).
+template <typename Scalar>
+inline void logSO3Reference(const Scalar R[9] /* row-major */, Scalar w[3]) {
+  const Scalar trace = R[0] + R[4] + R[8];
+  const Scalar theta =
+      (trace > Scalar(3.0) - Scalar(1e-6)) ? Scalar(0) : std::acos(Scalar(0.5) * (trace - Scalar(1)));
+  const Scalar K[3] = {R[7] - R[5], R[2] - R[6], R[3] - R[1]};
+  const Scalar k = (std::fabs(theta) < Scalar(0.001)) ? Scalar(0.5)
+                                                      : Scalar(0.5) * theta / std::sin(theta);
+  for (int i = 0; i < 3; ++i) w[i] = k * K[i];
+}
+
+// x (+) delta on SE(3) — what the reference's "TODO Manifold operation"
+// (src/levenberg_marquadt_dyn.cpp:82-83) would do in place of `xi_ = x0_map_ + delta_`, as a LEFT
+// perturbation (the one MOPT_JAC_ANALYTIC_LEFT differentiates with respect to):
+//   R' = Exp(delta_w) Exp(x_w),   t' = Exp(delta_w) x_t + delta_t,   x' = (t', Log(R')).
+template <typename Scalar>
+inline void se3Plus(const Scalar *x, const Scalar *delta, Scalar *out) {
+  Scalar R[9], D[9], RR[9];
+  expSO3<Scalar>(x + 3, R);
+  expSO3<Scalar>(delta + 3, D);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      RR[i * 3 + j] = (D[i * 3 + 0] * R[0 * 3 + j] + D[i * 3 + 1] * R[1 * 3 + j]) + D[i * 3 + 2] * R[2 * 3 + j];
+  Scalar t[3];
+  for (int i = 0; i < 3; ++i)
+    t[i] = ((D[i * 3 + 0] * x[0] + D[i * 3 + 1] * x[1]) + D[i * 3 + 2] * x[2]) + delta[i];
+  Scalar w[3];
+  logSO3Reference<Scalar>(RR, w);
+  for (int i = 0; i < 3; ++i) {
+    out[i] = t[i];
+    out[3 + i] = w[i];
+  }
+}
+
 }  // namespace so3
 }  // namespace moptimizer

@@ -74,7 +74,14 @@ enum mopt_jacobian_mode {
    * linearization.h:17-18 reads it row-major. */
   MOPT_JAC_ANALYTIC_TST_LAYOUT = 1,
   /* forward differences with the reference's step rule (linearization.h:78-105). */
-  MOPT_JAC_NUMERIC = 2
+  MOPT_JAC_NUMERIC = 2,
+  /* point2point, for the SE(3) manifold update the reference leaves as "TODO Manifold operation"
+   * (src/levenberg_marquadt_dyn.cpp:82-83; include/moptimizer/manifold.h): the derivative of the
+   * residual with respect to a LEFT perturbation of the pose, T <- [Exp(phi) R | Exp(phi) t + rho]:
+   * J = [ I3 | -skew(R p + t) ], row-major.  Exact at every pose (the Euclidean-parameter form
+   * [ I3 | -skew(p) ] is the derivative at R = I only); goes with mopt_lm_options.manifold = 1 /
+   * mopt_se3_plus, which apply the step as that perturbation instead of adding it to x. */
+  MOPT_JAC_ANALYTIC_LEFT = 3
 };
 
 enum mopt_loss_kind {
@@ -107,6 +114,11 @@ MOPT_API int mopt_device_count(int *count);
  * transform at x + h_j e_j.  Needs no device.  scalar_bytes 4 or 8 selects the type of all arrays. */
 MOPT_API int mopt_se3_from_params(int scalar_bytes, const void *x, void *T_out /* 16 */,
                                   void *T_plus_out /* 6 * 16 or NULL */, void *h_out /* 6 or NULL */);
+/* x (+) delta on SE(3), the manifold form of the reference's Euclidean `xi_ = x0_map_ + delta_`
+ * (levenberg_marquadt_dyn.cpp:82-83): with x = (t, w), delta = (rho, phi):
+ * R' = Exp(phi) Exp(w), t' = Exp(phi) t + rho, x' = (t', Log(R')) — Exp / Log of src/so3.cpp:43-57,
+ * :96-105.  6 scalars each; needs no device. */
+MOPT_API int mopt_se3_plus(int scalar_bytes, const void *x, const void *delta, void *x_out);
 MOPT_API const char *mopt_last_error(void);
 MOPT_API const char *mopt_version(void);
 
@@ -341,7 +353,8 @@ enum mopt_lm_status {
 typedef struct mopt_lm_options {
   int max_iterations;    /* Optimizer::setMaximumIterations, default 15 (optimizer.h:19)        */
   int lm_max_iterations; /* setLevenbergMarquadtIterations, default 3 (levenberg_marquadt_dyn.cpp:9) */
-  int manifold;          /* 0: xi = x0 + delta as the reference (:83)                            */
+  int manifold;          /* 0: xi = x0 + delta as the reference (:83); 1: xi = x0 (+) delta on SE(3)
+                            (mopt_se3_plus; n = 6; use MOPT_JAC_ANALYTIC_LEFT costs)              */
   int window;            /* trial points queued ahead of the device; 0 = default (3)             */
 } mopt_lm_options;
 typedef struct mopt_lm_report {

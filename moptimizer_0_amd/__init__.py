@@ -12,6 +12,7 @@ from ._capi import (  # noqa: F401
     COMBINE_PEER,
     COMBINE_RCCL,
     JAC_ANALYTIC,
+    JAC_ANALYTIC_LEFT,
     JAC_ANALYTIC_TST_LAYOUT,
     JAC_NUMERIC,
     KERNEL_AUTO,

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmoptimizer_hip.so")
 
 MOPT_OK = 0
-JAC_ANALYTIC, JAC_ANALYTIC_TST_LAYOUT, JAC_NUMERIC = 0, 1, 2
+JAC_ANALYTIC, JAC_ANALYTIC_TST_LAYOUT, JAC_NUMERIC, JAC_ANALYTIC_LEFT = 0, 1, 2, 3
 LOSS_NONE, LOSS_GEMAN_MCCLURE = 0, 1
 INPUT_HOST, INPUT_DEVICE = 0, 1
 KERNEL_AUTO, KERNEL_LITERAL, KERNEL_MOMENTS = 0, 1, 2
@@ -63,6 +63,7 @@ def load():
         "mopt_device_count": [ctypes.POINTER(ctypes.c_int)],
         "mopt_se3_from_params": [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                  ctypes.c_void_p],
+        "mopt_se3_plus": [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p],
         "mopt_point2point_create": [c_void_pp, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                     ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint],
         "mopt_point2point_set_data": [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
@@ -178,7 +179,17 @@ def se3_from_params(x, with_steps=False, dtype=np.float64):
             [Tp[16 * j:16 * j + 16].reshape(4, 4, order="F") for j in range(6)], h)
 
 
-def lm_minimize(costs, jac_modes, x0, max_iterations=15, lm_max_iterations=3, window=0):
+def se3_plus(x, delta, dtype=np.float64):
+    """x (+) delta on SE(3) (mopt_se3_plus)."""
+    x = np.ascontiguousarray(x, dtype=dtype)
+    delta = np.ascontiguousarray(delta, dtype=dtype)
+    out = np.zeros(6, dtype=dtype)
+    check(load().mopt_se3_plus(x.itemsize, _ptr(x), _ptr(delta), _ptr(out)))
+    return out
+
+
+def lm_minimize(costs, jac_modes, x0, max_iterations=15, lm_max_iterations=3, window=0,
+                manifold=False):
     """Device-resident LevenbergMarquadtDynamic::minimize over `costs` (mopt_lm_minimize).
     Returns (x, report dict)."""
     costs = list(costs)
@@ -186,7 +197,7 @@ def lm_minimize(costs, jac_modes, x0, max_iterations=15, lm_max_iterations=3, wi
     x = np.array(x0, dtype=dt).copy()
     handles = (ctypes.c_void_p * len(costs))(*[c._h for c in costs])
     modes = (ctypes.c_int * len(costs))(*[int(m) for m in jac_modes])
-    opt = LmOptions(int(max_iterations), int(lm_max_iterations), 0, int(window))
+    opt = LmOptions(int(max_iterations), int(lm_max_iterations), 1 if manifold else 0, int(window))
     rep = LmReport()
     check(load().mopt_lm_minimize(handles, len(costs), modes, _ptr(x), ctypes.byref(opt),
                                   ctypes.byref(rep)))

@@ -206,6 +206,17 @@ void fillBasis(const mopt_cost *c, int jac_mode, const mopt::P2PSweepArgs<S> &a,
         for (int k = 0; k < 3; ++k)
           B.J[1 + k][r * 6 + j] = double((a.T[1 + j][r * 4 + k] - a.T[0][r * 4 + k]) * a.inv_h[j]);
       }
+  } else if (jac_mode == MOPT_JAC_ANALYTIC_LEFT) {
+    // J(p) = [I | -skew(R p + t)] is the conformant pattern taken at the warped point, which is
+    // affine in p: J0 at t, J_k the change along column k of R
+    double w[3] = {double(a.T[0][3]), double(a.T[0][7]), double(a.T[0][11])};
+    analyticPattern(MOPT_JAC_ANALYTIC, w, B.J[0]);
+    for (int k = 0; k < 3; ++k) {
+      const double wk[3] = {w[0] + double(a.T[0][0 * 4 + k]), w[1] + double(a.T[0][1 * 4 + k]),
+                            w[2] + double(a.T[0][2 * 4 + k])};
+      analyticPattern(MOPT_JAC_ANALYTIC, wk, B.J[1 + k]);
+      for (int q = 0; q < 18; ++q) B.J[1 + k][q] -= B.J[0][q];
+    }
   } else {
     const double origin[3] = {0, 0, 0};
     analyticPattern(jac_mode, origin, B.J[0]);
@@ -365,8 +376,9 @@ template <typename S>
 int scalarSweepAsync(mopt_cost *c, bool cost_only, int jac_mode, const S *x, double *d_out,
                      hipStream_t s, const mopt::HostPublish &pub) {
   if (!cost_only) {
-    if (jac_mode == MOPT_JAC_ANALYTIC_TST_LAYOUT)
-      return fail(MOPT_ERR_UNSUPPORTED, "the as-written point2point layout applies to point2point only");
+    if (jac_mode == MOPT_JAC_ANALYTIC_TST_LAYOUT || jac_mode == MOPT_JAC_ANALYTIC_LEFT)
+      return fail(MOPT_ERR_UNSUPPORTED,
+                  "the as-written layout and the left-perturbation Jacobian apply to point2point only");
     if (jac_mode == MOPT_JAC_ANALYTIC && !scalarModelHasJacobian(c->scalar_model))
       return fail(MOPT_ERR_UNSUPPORTED,
                   "Non implemented non-jacobian model function `f_df` being used.");
@@ -396,8 +408,9 @@ template <typename S>
 int jitSweepAsync(mopt_cost *c, bool cost_only, int jac_mode, const S *x, double *d_out,
                   hipStream_t s, const mopt::HostPublish &pub) {
   if (!cost_only) {
-    if (jac_mode == MOPT_JAC_ANALYTIC_TST_LAYOUT)
-      return fail(MOPT_ERR_UNSUPPORTED, "the as-written point2point layout applies to point2point only");
+    if (jac_mode == MOPT_JAC_ANALYTIC_TST_LAYOUT || jac_mode == MOPT_JAC_ANALYTIC_LEFT)
+      return fail(MOPT_ERR_UNSUPPORTED,
+                  "the as-written layout and the left-perturbation Jacobian apply to point2point only");
     if (jac_mode == MOPT_JAC_ANALYTIC && !c->jit.has_jacobian)
       return fail(MOPT_ERR_UNSUPPORTED,
                   "Non implemented non-jacobian model function `f_df` being used.");
@@ -443,7 +456,7 @@ int jitSweepAsync(mopt_cost *c, bool cost_only, int jac_mode, const S *x, double
 namespace mopt_detail {
 int linearizeAsyncImpl(mopt_cost *c, int jac_mode, const void *x, double *d_result, hipStream_t s,
                        const mopt::HostPublish &pub) {
-  if (jac_mode < MOPT_JAC_ANALYTIC || jac_mode > MOPT_JAC_NUMERIC)
+  if (jac_mode < MOPT_JAC_ANALYTIC || jac_mode > MOPT_JAC_ANALYTIC_LEFT)
     return fail(MOPT_ERR_INVALID_ARGUMENT, "unknown jacobian_mode");
   if (c->model == kModelJit)
     return c->scalar_bytes == 8
@@ -640,9 +653,11 @@ int residentPrepareP2P(mopt_cost *c, int jac_mode, bool moments, hipStream_t s) 
   if (rc != MOPT_OK) return rc;
   if (moments) {
     mopt::AffineBasis basis;
-    // analytic modes: the whole basis is independent of x; forward differences: the step kernel
-    // rewrites J per point and only the covariance stays
-    fillBasis<S>(c, jac_mode == MOPT_JAC_NUMERIC ? MOPT_JAC_ANALYTIC : jac_mode, args, basis);
+    // analytic modes in the Euclidean parameters: the whole basis is independent of x; forward
+    // differences and the left-perturbation form: the step kernel rewrites J per point and only the
+    // covariance stays
+    const bool per_point = jac_mode == MOPT_JAC_NUMERIC || jac_mode == MOPT_JAC_ANALYTIC_LEFT;
+    fillBasis<S>(c, per_point ? MOPT_JAC_ANALYTIC : jac_mode, args, basis);
     if (!c->d_lm_basis)
       MOPT_HIP_TRY(deviceAlloc(reinterpret_cast<void **>(&c->d_lm_basis), sizeof(mopt::AffineBasis)));
     MOPT_HIP_TRY(mopt::launchStoreArgs<mopt::AffineBasis>(basis, c->d_lm_basis, s));
@@ -654,7 +669,7 @@ bool usesMoments(const mopt_cost *c) { return c->variant != MOPT_KERNEL_LITERAL;
 }  // namespace
 
 int residentPrepare(mopt_cost *c, int jac_mode, hipStream_t s, mopt::LmCostDesc *desc) {
-  if (jac_mode < MOPT_JAC_ANALYTIC || jac_mode > MOPT_JAC_NUMERIC)
+  if (jac_mode < MOPT_JAC_ANALYTIC || jac_mode > MOPT_JAC_ANALYTIC_LEFT)
     return fail(MOPT_ERR_INVALID_ARGUMENT, "unknown jacobian_mode");
   if (c->matcher)
     return fail(MOPT_ERR_UNSUPPORTED,
@@ -692,9 +707,9 @@ int residentPrepare(mopt_cost *c, int jac_mode, hipStream_t s, mopt::LmCostDesc 
       break;
     }
     case kModelScalar: {
-      if (jac_mode == MOPT_JAC_ANALYTIC_TST_LAYOUT)
+      if (jac_mode == MOPT_JAC_ANALYTIC_TST_LAYOUT || jac_mode == MOPT_JAC_ANALYTIC_LEFT)
         return fail(MOPT_ERR_UNSUPPORTED,
-                    "the as-written point2point layout applies to point2point only");
+                    "the as-written layout and the left-perturbation Jacobian apply to point2point only");
       if (jac_mode == MOPT_JAC_ANALYTIC && !scalarModelHasJacobian(c->scalar_model))
         return fail(MOPT_ERR_UNSUPPORTED,
                     "Non implemented non-jacobian model function `f_df` being used.");
@@ -1042,6 +1057,19 @@ int mopt_se3_from_params(int scalar_bytes, const void *x, void *T_out, void *T_p
   return MOPT_OK;
 }
 
+int mopt_se3_plus(int scalar_bytes, const void *x, const void *delta, void *x_out) {
+  if (!x || !delta || !x_out) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (scalar_bytes == 8)
+    moptimizer::so3::se3Plus<double>(static_cast<const double *>(x),
+                                     static_cast<const double *>(delta), static_cast<double *>(x_out));
+  else if (scalar_bytes == 4)
+    moptimizer::so3::se3Plus<float>(static_cast<const float *>(x), static_cast<const float *>(delta),
+                                    static_cast<float *>(x_out));
+  else
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "scalar_bytes must be 4 or 8");
+  return MOPT_OK;
+}
+
 int mopt_point2point_create(mopt_cost **out, int device, int scalar_bytes, const void *src_xyz,
                             const void *tgt_xyz, int64_t count, unsigned flags) {
   if (!out) return fail(MOPT_ERR_INVALID_ARGUMENT, "out is NULL");
@@ -1383,7 +1411,7 @@ void cacheStore(mopt_cost *c, const void *x, int mode) {
 int mopt_cost_linearize(mopt_cost *c, int jacobian_mode, const void *x, void *hessian, void *b,
                         void *sum_sq) {
   if (!c || !x) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
-  if (jacobian_mode < MOPT_JAC_ANALYTIC || jacobian_mode > MOPT_JAC_NUMERIC)
+  if (jacobian_mode < MOPT_JAC_ANALYTIC || jacobian_mode > MOPT_JAC_ANALYTIC_LEFT)
     return fail(MOPT_ERR_INVALID_ARGUMENT, "unknown jacobian_mode");
   if (c->speculate && cacheMatches(c, x, jacobian_mode)) {
     c->stat_cache_hits += 1;

@@ -63,8 +63,8 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
   if (options) opt = *options;
   if (opt.max_iterations < 0 || opt.lm_max_iterations < 0)
     return fail(MOPT_ERR_INVALID_ARGUMENT, "Optimization::max_iterations cannot be less than 0.");
-  if (opt.manifold)
-    return fail(MOPT_ERR_UNSUPPORTED, "the device-resident loop takes the reference's Euclidean step");
+  if (opt.manifold && lead->n_params != kNumParams)
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "the SE(3) update applies to 6-parameter poses");
   mopt_lm_report rep;
   std::memset(&rep, 0, sizeof rep);
   rep.status = MOPT_LM_MAXIMUM_ITERATIONS_REACHED;
@@ -82,6 +82,7 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
   problem.n = lead->n_params;
   problem.max_iterations = opt.max_iterations;
   problem.lm_max_iterations = opt.lm_max_iterations;
+  problem.manifold = opt.manifold ? 1 : 0;
   problem.control = lead->d_lm_control;
   problem.state = lead->d_lm_state;
   problem.report = lead->h_lm_report_dev;

@@ -74,6 +74,28 @@ __device__ void rigidFrom6DOF(const S *x, S (&T)[12]) {
   }
 }
 
+// x (+) delta on SE(3): include/moptimizer_amd/so3.hpp se3Plus (Exp / Log of src/so3.cpp:43-57,
+// :96-105), the manifold form of `xi_ = x0_map_ + delta_` (levenberg_marquadt_dyn.cpp:82-83).
+template <typename S>
+__device__ void se3Plus(const S *x, const S *delta, S *out) {
+#pragma clang fp contract(off)
+  S TR[12], TD[12];
+  rigidFrom6DOF<S>(x, TR);
+  rigidFrom6DOF<S>(delta, TD);  // rotation part Exp(delta_w); its translation column is delta_t
+  S RR[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      RR[i * 3 + j] = (TD[i * 4 + 0] * TR[0 * 4 + j] + TD[i * 4 + 1] * TR[1 * 4 + j]) +
+                      TD[i * 4 + 2] * TR[2 * 4 + j];
+  for (int i = 0; i < 3; ++i)
+    out[i] = ((TD[i * 4 + 0] * x[0] + TD[i * 4 + 1] * x[1]) + TD[i * 4 + 2] * x[2]) + delta[i];
+  const S trace = RR[0] + RR[4] + RR[8];
+  const S theta = (trace > S(3.0) - S(1e-6)) ? S(0) : acos(S(0.5) * (trace - S(1)));
+  const S K[3] = {RR[7] - RR[5], RR[2] - RR[6], RR[3] - RR[1]};
+  const S k = (fabs(theta) < S(0.001)) ? S(0.5) : S(0.5) * theta / sin(theta);
+  for (int i = 0; i < 3; ++i) out[3 + i] = k * K[i];
+}
+
 // Forward-difference step of linearization.h:85-89.
 template <typename S>
 __device__ __forceinline__ S forwardStep(S xj) {
@@ -313,6 +335,27 @@ __device__ void writeSweepConstants(const LmProblem &P, const S *x) {
         P2PSweepArgs<S> *a = static_cast<P2PSweepArgs<S> *>(d.args);
         if (tid < (1 + kNumParams) * 12) a->T[tid / 12][tid % 12] = Tj[tid / 12][tid % 12];
         if (tid < kNumParams) a->inv_h[tid] = inv_h[tid];
+        if (d.moments && d.jac_mode == kJacAnalyticLeft && tid < 18) {
+          // J(p) = [I | -skew(R p + t)] = J0 + sum_k p_k J_k (c_abi.cpp fillBasis)
+          const int r = tid / 6, j = tid % 6;
+          auto pattern = [&](const S (&w)[3]) -> S {  // entry (r, j) of [I | -skew(w)]
+            if (j < 3) return r == j ? S(1) : S(0);
+            const int c = j - 3;
+            if (r == c) return S(0);
+            // -skew(w) = [[0, w2, -w1], [-w2, 0, w0], [w1, -w0, 0]]
+            const int other = 3 - r - c;
+            const bool positive = (r == 0 && c == 1) || (r == 1 && c == 2) || (r == 2 && c == 0);
+            return positive ? w[other] : -w[other];
+          };
+          const S w0[3] = {Tj[0][3], Tj[0][7], Tj[0][11]};
+          const S base = pattern(w0);
+          d.basis->J[0][r * 6 + j] = double(base);
+          for (int k = 0; k < 3; ++k) {
+            const S wk[3] = {w0[0] + Tj[0][0 * 4 + k], w0[1] + Tj[0][1 * 4 + k],
+                             w0[2] + Tj[0][2 * 4 + k]};
+            d.basis->J[1 + k][r * 6 + j] = double(pattern(wk)) - double(base);
+          }
+        }
         if (d.moments && numeric && tid < 18) {
           // column j of J is ((R_j - R) p + (t_j - t)) / h_j  (c_abi.cpp fillBasis)
           const int r = tid / 6, j = tid % 6;
@@ -454,11 +497,18 @@ __device__ void lmStepBody(const LmProblem &P, bool init, const LmStart<S> &star
         }
       }
       MOPT_TICK(6);
+      if (P.manifold && n == kNumParams) {
+        S plus[kNumParams];
+        se3Plus<S>(x0, delta, plus);
 #pragma unroll
-      for (int i = 0; i < kMaxParams; ++i) {
-        if (i < n) xi[i] = x0[i] + delta[i];
-        next_x[i] = xi[i];
+        for (int i = 0; i < kNumParams; ++i) xi[i] = plus[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < kMaxParams; ++i)
+          if (i < n) xi[i] = x0[i] + delta[i];
       }
+#pragma unroll
+      for (int i = 0; i < kMaxParams; ++i) next_x[i] = xi[i];
       propose = 1;
     };
     // top of an outer iteration once H, b, y0 at x0 are known (:62-70)

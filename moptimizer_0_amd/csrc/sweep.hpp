@@ -30,7 +30,7 @@ struct TileShape {
 constexpr int kReprojTilePoints = kBlockThreads * 2;
 constexpr int kReprojTileBytes = kReprojTilePoints * (4 * 8 + 2 * 4);
 
-enum JacMode : int { kJacAnalytic = 0, kJacAnalyticTst = 1, kJacNumeric = 2 };
+enum JacMode : int { kJacAnalytic = 0, kJacAnalyticTst = 1, kJacNumeric = 2, kJacAnalyticLeft = 3 };
 enum CovMode : int { kCovIdentity = 0, kCovSymmetric = 1, kCovGeneral = 2 };
 enum LossKind : int { kLossNone = 0, kLossGemanMcClure = 1 };
 

@@ -259,6 +259,16 @@ __device__ __forceinline__ void p2pPointLiteral(
     for (int a = 0; a < 3; ++a)
 #pragma unroll
       for (int j = 0; j < 6; ++j) J[a][j] = Jt[a][j];
+  } else if (JAC == kJacAnalyticLeft) {
+    // derivative with respect to a left perturbation of the pose: [ I3 | -skew(R p + t) ], with
+    // R p + t = r + q (levenberg_marquadt_dyn.cpp:82-83 "TODO Manifold operation")
+    const S z = S(0), o = S(1);
+    const S w0 = r[0] + q[0], w1 = r[1] + q[1], w2 = r[2] + q[2];
+    const S Jl[3][6] = {{o, z, z, z, w2, -w1}, {z, o, z, -w2, z, w0}, {z, z, o, w1, -w0, z}};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) J[a][j] = Jl[a][j];
   } else {
     // forward differences, nominal step (linearization.h:103-106); 1/h_j is formed on the host
 #pragma unroll
@@ -1145,6 +1155,8 @@ hipError_t launchP2PLinearizeLiteral(const P2PSweepArgs<S> &args, int jac_mode, 
       return launchLiteralCov<S, kJacAnalyticTst>(args, cov_mode, grid, site);
     case kJacNumeric:
       return launchLiteralCov<S, kJacNumeric>(args, cov_mode, grid, site);
+    case kJacAnalyticLeft:
+      return launchLiteralCov<S, kJacAnalyticLeft>(args, cov_mode, grid, site);
     default:
       return hipErrorInvalidValue;
   }
@@ -1344,6 +1356,8 @@ hipError_t launchP2PLiteralResident(const P2PSweepArgs<S> *d_args, const LmContr
       return launchLiteralResidentCov<S, kJacAnalyticTst>(d_args, control, cov_mode, grid, site);
     case kJacNumeric:
       return launchLiteralResidentCov<S, kJacNumeric>(d_args, control, cov_mode, grid, site);
+    case kJacAnalyticLeft:
+      return launchLiteralResidentCov<S, kJacAnalyticLeft>(d_args, control, cov_mode, grid, site);
     default:
       return hipErrorInvalidValue;
   }

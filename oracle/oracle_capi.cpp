@@ -63,13 +63,18 @@ std::unique_ptr<moptimizer::CostFunctionBase<S>> makeCost(
   return cost;
 }
 
+inline oracle::P2PJacobianLayout layoutOf(int layout) {
+  return layout == 1 ? oracle::P2PJacobianLayout::kAsWrittenInTst
+                     : (layout == 2 ? oracle::P2PJacobianLayout::kLeftPerturbation
+                                    : oracle::P2PJacobianLayout::kRowMajor);
+}
+
 template <class S>
 int p2pLinearize(int cost_class, int layout, const S *src, const S *tgt, int n, const S *x,
                  const S *cov, int loss_kind, double loss_param, S *H, S *b, S *cost_out) {
   auto model = std::make_shared<oracle::Point2Point<S>>(
       src, tgt,
-      layout == 1 ? oracle::P2PJacobianLayout::kAsWrittenInTst
-                  : oracle::P2PJacobianLayout::kRowMajor);
+      layoutOf(layout));
   auto cost = makeCost<S>(cost_class, model, 6, 3, n, cov, loss_kind, loss_param);
   *cost_out = cost->linearize(x, H, b);
   return 0;
@@ -111,12 +116,12 @@ int p2pMinimize(int cost_class, int layout, const S *src, const S *tgt, int n, S
                 int *iterations) {
   auto model = std::make_shared<oracle::Point2Point<S>>(
       src, tgt,
-      layout == 1 ? oracle::P2PJacobianLayout::kAsWrittenInTst
-                  : oracle::P2PJacobianLayout::kRowMajor);
+      layoutOf(layout & 3));
   auto cost = makeCost<S>(cost_class, model, 6, 3, n, cov, loss_kind, loss_param);
   moptimizer::LevenbergMarquadtDynamic<S> lm(6);
   lm.setMaximumIterations(max_iter);
   if (lm_iter > 0) lm.setLevenbergMarquadtIterations(lm_iter);
+  lm.setManifoldUpdate((layout & 4) != 0);  // bit 2 of `layout`: x (+) delta on SE(3)
   lm.addCost(cost.get());
   *status = int(lm.minimize(x));
   *iterations = int(lm.getExecutedIterations());

@@ -28,6 +28,11 @@ enum class P2PJacobianLayout {
   // As written in tst/point2point.cpp:71-75: the buffer is mapped as a COLUMN-major 3x6 and
   // filled with [I3 | -skew(p)], while the consumer reads it row-major (linearization.h:17-18).
   kAsWrittenInTst,
+  // Not in the reference (its manifold update is a TODO, src/levenberg_marquadt_dyn.cpp:82-83):
+  // the derivative with respect to a LEFT perturbation of the pose, [I3 | -skew(R p + t)],
+  // row-major — what an SE(3) update x (+) delta needs.  Restated here as the checker of
+  // MOPT_JAC_ANALYTIC_LEFT.
+  kLeftPerturbation,
 };
 
 template <typename Scalar>
@@ -51,7 +56,15 @@ class Point2Point : public moptimizer::BaseModelJacobian<Scalar, Point2Point<Sca
     const Scalar *p = src_ + 3 * std::size_t(index);
     // -skew(src): rows (0, z, -y), (-z, 0, x), (y, -x, 0)
     const Scalar neg_skew[3][3] = {{0.0, p[2], -p[1]}, {-p[2], 0.0, p[0]}, {p[1], -p[0], 0.0}};
-    if (layout_ == P2PJacobianLayout::kAsWrittenInTst) {
+    if (layout_ == P2PJacobianLayout::kLeftPerturbation) {
+      const Scalar *q = tgt_ + 3 * std::size_t(index);
+      const Scalar w[3] = {f_x[0] + q[0], f_x[1] + q[1], f_x[2] + q[2]};  // R p + t
+      const Scalar neg_skew_w[3][3] = {{0.0, w[2], -w[1]}, {-w[2], 0.0, w[0]}, {w[1], -w[0], 0.0}};
+      for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) jacobian[r * 6 + c] = (r == c) ? Scalar(1) : Scalar(0);
+        for (int c = 0; c < 3; ++c) jacobian[r * 6 + 3 + c] = neg_skew_w[r][c];
+      }
+    } else if (layout_ == P2PJacobianLayout::kAsWrittenInTst) {
       // jacobian_map(r, c) lives at jacobian[c * 3 + r]  (column-major 3x6, :18,:71)
       for (int c = 0; c < 3; ++c)
         for (int r = 0; r < 3; ++r) jacobian[c * 3 + r] = (r == c) ? Scalar(1) : Scalar(0);

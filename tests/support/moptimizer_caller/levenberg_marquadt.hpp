@@ -27,6 +27,7 @@
 #include "moptimizer_amd/dense.hpp"
 #include "moptimizer_caller/ldlt.hpp"
 #include "moptimizer_amd/host_api.hpp"
+#include "moptimizer_amd/so3.hpp"
 
 namespace duna {
 // Level-filtered line logger; only what the optimizer uses.
@@ -175,8 +176,12 @@ class LevenbergMarquadtDynamic : public Optimizer<Scalar> {
         for (int i = 0; i < n; ++i) rhs[i] = -b_[i];
         delta_ = dense::PivotedLDLT<Scalar>(damped).solve(rhs);
 
-        // Euclidean update (the reference leaves the manifold update as a TODO, :82-83)
-        for (int i = 0; i < n; ++i) xi_[i] = x0[i] + delta_[i];
+        // Euclidean update, as the reference (:83); the manifold update it leaves as a TODO
+        // (:82) is available behind setManifoldUpdate for 6-parameter poses
+        if (manifold_update_ && n == 6)
+          so3::se3Plus<Scalar>(x0, delta_.data(), xi_.data());
+        else
+          for (int i = 0; i < n; ++i) xi_[i] = x0[i] + delta_[i];
 
         Scalar yi = 0;
         for (auto *cost : costs_) yi += cost->computeCost(xi_.data());
@@ -215,6 +220,9 @@ class LevenbergMarquadtDynamic : public Optimizer<Scalar> {
   void setLogger(std::shared_ptr<duna::Logger> logger) { logger_ = std::move(logger); }
   unsigned int getLevenbergMarquadtIterations() const { return lm_max_iterations_; }
   void setLevenbergMarquadtIterations(int max_iterations) { lm_max_iterations_ = max_iterations; }
+  // Not in the reference: xi = x0 (+) delta on SE(3) (include/moptimizer_amd/so3.hpp se3Plus) in
+  // place of xi = x0 + delta; pair it with left-perturbation Jacobians.
+  void setManifoldUpdate(bool on) { manifold_update_ = on; }
 
  protected:
   bool hasConverged() override { return false; }
@@ -237,6 +245,7 @@ class LevenbergMarquadtDynamic : public Optimizer<Scalar> {
   using Optimizer<Scalar>::logger_;
 
   int num_parameters_;
+  bool manifold_update_ = false;
   Scalar lm_init_lambda_factor_ = Scalar(1e-9);
   Scalar lm_lambda_ = Scalar(-1);
   unsigned int lm_max_iterations_;

@@ -199,3 +199,37 @@ def test_blocking_calls_still_work_after_a_device_resident_solve(hip_lib, oracle
     assert rep["status"] == sh and abs(rep["iterations"] - ih) <= 1
     assert np.abs(x - xh).max() < FD_ITERATE_TOL * 11
     cost.close()
+
+
+def _exp(w):
+    th = np.linalg.norm(w)
+    a = w / th
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+
+
+def test_manifold_update_on_the_device(hip_lib, oracle):
+    """mopt_lm_options.manifold with MOPT_JAC_ANALYTIC_LEFT costs: the iterates of the CPU loop with
+    setManifoldUpdate over the oracle's left-perturbation model, from a start 2.5 rad off."""
+    mo = hip_lib
+    src, tgt = ds.synthetic_pair(20_000, seed=12, noise=0.01)
+    R0 = _exp(np.array([0.0, 0.0, 2.5])) @ ds.fixture_rotation()
+    th = np.arccos((np.trace(R0) - 1) / 2)
+    w0 = th / (2 * np.sin(th)) * np.array([R0[2, 1] - R0[1, 2], R0[0, 2] - R0[2, 0], R0[1, 0] - R0[0, 1]])
+    x0 = np.concatenate([ds.FIXTURE_T + 1.0, w0])
+    cost = mo.Point2PointCost(src, tgt)
+    for variant in (mo.KERNEL_MOMENTS, mo.KERNEL_LITERAL):
+        cost.set_kernel_variant(variant)
+        for k in (1, 2, 4, 60):
+            x, rep = mo.capi.lm_minimize([cost], [mo.JAC_ANALYTIC_LEFT], x0, max_iterations=k,
+                                         manifold=True)
+            xr, status, iters = oracle.p2p_minimize(src, tgt, x0, cost_class=ob.ANALYTIC_DYN,
+                                                    layout=ob.LAYOUT_LEFT | ob.MANIFOLD_UPDATE,
+                                                    max_iter=k)
+            assert (rep["status"], rep["iterations"]) == (status, iters), (k, rep, status, iters)
+            assert np.abs(x - xr).max() < 1e-9 * max(1.0, np.abs(xr).max()), (k, x, xr)
+    assert np.abs(_exp(x[3:]) - ds.fixture_rotation()).max() < 1e-3
+    # the Euclidean update from the same start needs more than twice the outer iterations
+    xe, repe = mo.capi.lm_minimize([cost], [mo.JAC_ANALYTIC], x0, max_iterations=200)
+    assert repe["iterations"] > 2 * rep["iterations"], (repe, rep)
+    cost.close()

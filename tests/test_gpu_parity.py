@@ -40,7 +40,7 @@ def oracle_ref(oracle, src, tgt, x, jac_mode, **kw):
     """The reference computation a jacobian_mode stands for."""
     if jac_mode == 2:
         return oracle.p2p_linearize(src, tgt, x, cost_class=ob.NUMERIC_DYN, **kw)
-    layout = ob.LAYOUT_TST if jac_mode == 1 else ob.LAYOUT_ROW_MAJOR
+    layout = {1: ob.LAYOUT_TST, 3: ob.LAYOUT_LEFT}.get(jac_mode, ob.LAYOUT_ROW_MAJOR)
     return oracle.p2p_linearize(src, tgt, x, cost_class=ob.ANALYTIC_DYN, layout=layout, **kw)
 
 
@@ -1047,3 +1047,32 @@ def test_group_shards_on_one_gpu(hip_lib, oracle):
                                     loss_param=100.0))
     want = oracle.p2p_cost(src, tgt, ds.X_GENERIC)
     assert abs(grp.compute_cost(ds.X_GENERIC) - want) <= REL * want
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_left_perturbation_jacobian_matches_oracle(hip_lib, oracle, variant):
+    """MOPT_JAC_ANALYTIC_LEFT, J = [I | -skew(R p + t)] (the Jacobian of the SE(3) manifold update
+    the reference leaves as a TODO, levenberg_marquadt_dyn.cpp:82-83): both kernel variants, poses
+    near and far from the identity, loss and covariance."""
+    mo = hip_lib
+    src, tgt = ds.synthetic_pair(70_001, seed=21, noise=0.03)
+    cost = mo.Point2PointCost(src, tgt)
+    cost.set_kernel_variant(variant)
+    far = np.array([0.4, -1.1, 2.0, 1.2, -0.9, 1.5])
+    for cov in (None, np.diag([1.0, 0.25, 4.0]), np.array([[2.0, 0.3, 0.1], [0.0, 1.0, 0.2], [0.4, 0.0, 0.5]])):
+        for loss in ((mo.LOSS_NONE, 0.0), (mo.LOSS_GEMAN_MCCLURE, 20.0)):
+            cost.set_covariance(cov)
+            cost.set_loss(*loss)
+            for x in (ds.X_ZERO, ds.X_GENERIC, far):
+                got = cost.linearize(x, mo.JAC_ANALYTIC_LEFT)
+                want = oracle.p2p_linearize(src, tgt, x, cost_class=ob.ANALYTIC_DYN,
+                                            layout=ob.LAYOUT_LEFT, cov=cov, loss_kind=loss[0],
+                                            loss_param=loss[1])
+                check(got, want)
+    # at R = I, t = 0 the left and the Euclidean-parameter forms coincide
+    cost.set_covariance(None)
+    cost.set_loss(mo.LOSS_NONE)
+    a = cost.linearize(ds.X_ZERO, mo.JAC_ANALYTIC_LEFT)
+    b = cost.linearize(ds.X_ZERO, mo.JAC_ANALYTIC)
+    check(a, b, 1e-12)
+    cost.close()
