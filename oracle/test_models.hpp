@@ -153,7 +153,9 @@ class CameraModel : public moptimizer::BaseModel<double, CameraModel> {
   const double *projection() const { return projection_; }
 
  private:
-  void rebuildProjection() {
+  // rounded operation by operation (so3_ref.hpp): forward differences amplify an ulp of M by 1 / h
+  ORACLE_SO3_EXACT void rebuildProjection() {
+    ORACLE_SO3_EXACT_BODY
     double kt[12];
     for (int r = 0; r < 3; ++r)
       for (int c = 0; c < 4; ++c) {
