@@ -120,6 +120,24 @@ __device__ __forceinline__ void sweepTiles(const S *tiles, int num_tiles, Body &
   }
 }
 
+// The same walk with one register set: for sweeps whose arithmetic, not the memory stream, sets the
+// pace and that need their registers for it — latency is then hidden by the 2-3 waves a SIMD holds
+// instead of by a second tile in flight per wave.
+template <typename S, bool STREAMING, typename Body>
+__device__ __forceinline__ void sweepTilesSingle(const S *tiles, int num_tiles, Body &&body) {
+  constexpr int V = TileShape<S>::kVec;
+  constexpr int TP = TileShape<S>::kPoints;
+  const S *lane_base = tiles + threadIdx.x * V;
+  for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
+    const S *base = lane_base + size_t(tile) * TileShape<S>::kP2PScalars;
+    Pack<S> cur[6];
+#pragma unroll
+    for (int pl = 0; pl < 6; ++pl)
+      cur[pl] = STREAMING ? loadPackStreaming<S>(base + pl * TP) : loadPack<S>(base + pl * TP);
+    body(cur, (long long)tile * TP + threadIdx.x * V);
+  }
+}
+
 __device__ __forceinline__ double waveSum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -319,6 +337,148 @@ __global__ __launch_bounds__(kBlockThreads) void p2pLinearizeLiteralResidentKern
   if (control->done) return;
   const P2PSweepArgs<S> A = *d_args;
   p2pLinearizeLiteralBody<S, JAC, COV>(A);
+}
+
+// ---- point-to-point, forward differences as the reference evaluates them, identity covariance --
+// The literal kernel above carries 7 transforms x 12 scalars as kernel arguments; in fp64 that is
+// 168 SGPRs of constants against ~100 available, so the compiler spills them and the sweep ran at
+// 28-44 % of the HBM roof.  This form of the same arithmetic
+//   * keeps the constants in LDS and re-reads what a step needs (same-address reads: one broadcast
+//     each; a compiler barrier in front keeps them from being hoisted into ~114 VGPRs);
+//   * uses what the reference's perturbed models have in common: x + h e_j for a translation
+//     parameter leaves R untouched, so r+_a - r_a is EXACTLY zero for a != j and the j-th entry
+//     only needs the shared partial sum (R p)_j — three columns cost 4 operations each instead of
+//     a transformed point each — and J^T J then has three structural zeros and nine one-term
+//     entries;
+//   * spells the transformed point as fma(T2, p2, fma(T1, p1, T0 p0)) + t, the contraction of the
+//     reference's 4x4 * [p;1] product (tst/point2point.cpp:42-45 under -march=native), for every
+//     one of the seven residuals alike, so that r+ - r carries the same rounding as on the CPU.
+// Every J entry, the loss weight and every product are still formed per point (linearization.h:
+// 101-117); rows have the kAccSym layout of the literal kernel.
+template <typename S>
+struct ForwardDiffConstants {
+  S T0[12];           // [R | t] at x
+  S Tr[3][12];        // at x + h_j e_j, j = 3..5 (rotation parameters)
+  S t_plus[3];        // t_j + h_j, j = 0..2
+  S inv_h[kNumParams];
+  S loss_param;
+  int loss_kind;
+};
+
+template <typename S, bool STREAMING>
+__device__ __forceinline__ void p2pForwardDiffBody(const S *tiles, int num_tiles,
+                                                   const P2PSweepArgs<S> &A) {
+  constexpr int V = TileShape<S>::kVec;
+  __shared__ ForwardDiffConstants<S> K;
+  if (threadIdx.x < 12) K.T0[threadIdx.x] = A.T[0][threadIdx.x];
+  if (threadIdx.x >= 64 && threadIdx.x < 64 + 36)
+    K.Tr[(threadIdx.x - 64) / 12][(threadIdx.x - 64) % 12] =
+        A.T[4 + (threadIdx.x - 64) / 12][(threadIdx.x - 64) % 12];
+  if (threadIdx.x >= 128 && threadIdx.x < 131)
+    K.t_plus[threadIdx.x - 128] = A.T[1 + (threadIdx.x - 128)][(threadIdx.x - 128) * 4 + 3];
+  if (threadIdx.x >= 192 && threadIdx.x < 192 + kNumParams) K.inv_h[threadIdx.x - 192] = A.inv_h[threadIdx.x - 192];
+  if (threadIdx.x == 255) {
+    K.loss_param = A.loss_param;
+    K.loss_kind = A.loss_kind;
+  }
+  __syncthreads();
+
+  double acc[kAccSym];
+#pragma unroll
+  for (int k = 0; k < kAccSym; ++k) acc[k] = 0.0;
+  const long long count = A.count;
+
+  sweepTiles<S, STREAMING>(tiles, num_tiles, [&](const Pack<S>(&cur)[6], long long first) {
+    // one point at a time, as a real loop: unrolled, the scheduler interleaves the points and the
+    // kernel needs > 300 registers
+#pragma unroll 1
+    for (int e = 0; e < V; ++e) {
+      asm volatile("" ::: "memory");  // constants come from LDS here, not from registers kept alive
+      S in[6];
+#pragma unroll
+      for (int pl = 0; pl < 6; ++pl) {
+        in[pl] = cur[pl].v[0];
+#pragma unroll
+        for (int k = 1; k < V; ++k) in[pl] = (e == k) ? cur[pl].v[k] : in[pl];
+      }
+      const S p[3] = {in[0], in[1], in[2]};
+      const bool valid = isCorrespondence(first + e, count, in[3]);
+      const S q[3] = {valid ? in[3] : S(0), valid ? in[4] : S(0), valid ? in[5] : S(0)};
+      S s[3], r[3], d[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        s[a] = __builtin_fma(K.T0[a * 4 + 2], p[2],
+                             __builtin_fma(K.T0[a * 4 + 1], p[1], K.T0[a * 4 + 0] * p[0]));
+        r[a] = (s[a] + K.T0[a * 4 + 3]) - q[a];
+      }
+      // translation columns: only entry (j, j) moves
+#pragma unroll
+      for (int j = 0; j < 3; ++j) d[j] = (((s[j] + K.t_plus[j]) - q[j]) - r[j]) * K.inv_h[j];
+      // rotation columns: a transformed point each
+      S Acol[3][3];  // Acol[a][c] = J[a][3 + c]
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const S sp = __builtin_fma(K.Tr[c][a * 4 + 2], p[2],
+                                     __builtin_fma(K.Tr[c][a * 4 + 1], p[1], K.Tr[c][a * 4 + 0] * p[0]));
+          const S rp = (sp + K.Tr[c][a * 4 + 3]) - q[a];
+          Acol[a][c] = (rp - r[a]) * K.inv_h[3 + c];
+        }
+      }
+      S rr = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+      S w = lossWeight<S>(K.loss_kind, K.loss_param, rr);
+      w = valid ? w : S(0);
+      rr = valid ? rr : S(0);
+      // w J^T J (upper triangle, column-wise: k = j (j + 1) / 2 + i), w J^T r, r^T r with
+      // J = [diag(d) | Acol]; entries (0,1), (0,2), (1,2) are sums of exact zeros
+      S wd[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) wd[a] = w * d[a];
+      auto wA = [&](int a, int c) { return w * Acol[a][c]; };
+      acc[0] += double(wd[0] * d[0]);
+      acc[2] += double(wd[1] * d[1]);
+      acc[5] += double(wd[2] * d[2]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int col = 3 + c, base = col * (col + 1) / 2;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) acc[base + i] += double(wd[i] * Acol[i][c]);
+#pragma unroll
+        for (int c2 = 0; c2 <= c; ++c2) {
+          S v = 0;
+#pragma unroll
+          for (int a = 0; a < 3; ++a) v += wA(a, c2) * Acol[a][c];
+          acc[base + 3 + c2] += double(v);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) acc[21 + i] += double(wd[i] * r[i]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        S v = 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) v += wA(a, c) * r[a];
+        acc[24 + c] += double(v);
+      }
+      acc[27] += double(rr);
+    }
+  });
+  blockReduceStore<kAccSym>(acc, A.partials + size_t(blockIdx.x) * kAccSym);
+}
+
+template <typename S, bool STREAMING>
+__global__ __launch_bounds__(kBlockThreads) void p2pForwardDiffKernel(const S *tiles, int num_tiles,
+                                                                      const P2PSweepArgs<S> A) {
+  p2pForwardDiffBody<S, STREAMING>(tiles, num_tiles, A);
+}
+
+template <typename S, bool STREAMING>
+__global__ __launch_bounds__(kBlockThreads) void p2pForwardDiffResidentArgsKernel(
+    const P2PSweepArgs<S> *__restrict__ d_args, const LmControl *__restrict__ control) {
+  if (control->done) return;
+  p2pForwardDiffBody<S, STREAMING>(d_args->tiles, d_args->num_tiles, *d_args);
 }
 
 // ---- point-to-point, weighted moments --------------------------------------------------------
@@ -1154,6 +1314,9 @@ hipError_t launchP2PLinearizeLiteral(const P2PSweepArgs<S> &args, int jac_mode, 
     case kJacAnalyticTst:
       return launchLiteralCov<S, kJacAnalyticTst>(args, cov_mode, grid, site);
     case kJacNumeric:
+      if (cov_mode == kCovIdentity)
+        return site.streaming ? launchTiled(p2pForwardDiffKernel<S, true>, grid, site, args)
+                              : launchTiled(p2pForwardDiffKernel<S, false>, grid, site, args);
       return launchLiteralCov<S, kJacNumeric>(args, cov_mode, grid, site);
     case kJacAnalyticLeft:
       return launchLiteralCov<S, kJacAnalyticLeft>(args, cov_mode, grid, site);
@@ -1355,6 +1518,17 @@ hipError_t launchP2PLiteralResident(const P2PSweepArgs<S> *d_args, const LmContr
     case kJacAnalyticTst:
       return launchLiteralResidentCov<S, kJacAnalyticTst>(d_args, control, cov_mode, grid, site);
     case kJacNumeric:
+      if (cov_mode == kCovIdentity) {
+        // tiles / num_tiles are not in reach of this signature: read them through the argument
+        // block like everything else
+        if (site.streaming)
+          hipLaunchKernelGGL((p2pForwardDiffResidentArgsKernel<S, true>), dim3(grid),
+                             dim3(kBlockThreads), 0, site.stream, d_args, control);
+        else
+          hipLaunchKernelGGL((p2pForwardDiffResidentArgsKernel<S, false>), dim3(grid),
+                             dim3(kBlockThreads), 0, site.stream, d_args, control);
+        return hipGetLastError();
+      }
       return launchLiteralResidentCov<S, kJacNumeric>(d_args, control, cov_mode, grid, site);
     case kJacAnalyticLeft:
       return launchLiteralResidentCov<S, kJacAnalyticLeft>(d_args, control, cov_mode, grid, site);
