@@ -452,7 +452,8 @@ int jitSweepAsync(mopt_cost *c, bool cost_only, int jac_mode, const S *x, double
   const bool cov_symmetric = c->cov_mode != mopt::kCovGeneral;
   const mopt::JitVariant *variant = mopt::jitVariant(c->jit, mode, cov_symmetric);
   if (!variant) return fail(MOPT_ERR_INVALID_ARGUMENT, mopt::jitLastError());
-  long long blocks = (c->count + mopt::kBlockThreads - 1) / mopt::kBlockThreads;
+  const long long per_block = (long long)mopt::kBlockThreads * (16 / c->scalar_bytes);
+  long long blocks = (c->count + per_block - 1) / per_block;
   if (blocks > c->num_cus * 4) blocks = c->num_cus * 4;
   if (blocks < 1) blocks = 1;
   const int grid = int(blocks);
@@ -1271,9 +1272,15 @@ int mopt_jit_model_create(mopt_cost **out, int device, int scalar_bytes, int n_p
                        residual_body, jacobian_body, c->jit))
     return fail(MOPT_ERR_INVALID_ARGUMENT, mopt::jitLastError());
   if (n_planes > 0) {
-    const size_t row = size_t(count) * scalar_bytes;
-    MOPT_HIP_TRY(deviceAlloc(&c->d_tiles, row * n_planes));
-    MOPT_HIP_TRY(hipMemcpy2D(c->d_tiles, row, data, size_t(plane_stride) * scalar_bytes, row,
+    // plane stride padded to whole 16-byte packs (the sweep loads 16 bytes per lane and plane);
+    // the tail of the last pack is zero-filled and enters no sum
+    const int vec = 16 / scalar_bytes;
+    const long long padded = (count + vec - 1) / vec * vec;
+    c->data_stride = padded;
+    const size_t row = size_t(count) * scalar_bytes, pitch = size_t(padded) * scalar_bytes;
+    MOPT_HIP_TRY(deviceAlloc(&c->d_tiles, pitch * n_planes));
+    MOPT_HIP_TRY(hipMemset(c->d_tiles, 0, pitch * n_planes));
+    MOPT_HIP_TRY(hipMemcpy2D(c->d_tiles, pitch, data, size_t(plane_stride) * scalar_bytes, row,
                              size_t(n_planes),
                              (flags & MOPT_INPUT_DEVICE) ? hipMemcpyDeviceToDevice
                                                          : hipMemcpyHostToDevice));

@@ -53,13 +53,50 @@ struct JitArgs {
 )JIT";
 
 const char *const kJitSweep = R"JIT(
-__device__ inline double wave_sum(double v) {
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
+// 16-byte loads: a lane takes VEC consecutive elements of every data plane per step (planes start
+// 16-byte aligned: the library pads their stride), so one wavefront instruction reads 1 KiB of
+// contiguous memory as the hand-written sweeps do.
+#define VEC (16 / (int)sizeof(S))
+struct __attribute__((aligned(16))) Pack {
+  S v[VEC];
+};
+
+// Per-thread accumulators -> one row of NACC doubles per workgroup through an LDS transpose (the
+// epilogue of the hand-written sweeps, sweep_kernels.hip blockReduceStore): every lane stores its
+// values once, thread (k, part) adds the 4 waves x 8 lanes of value k whose lane index is = part
+// (mod 8), three xor-shuffles combine the parts.  Six shuffle steps per value through the CU's
+// single LDS crossbar cost several times as much.
+#define RCHUNK (NACC < 23 ? NACC : 23)
+#define RROW 72
+__device__ inline void block_reduce_store(double (&acc)[NACC], double *out_row) {
+  __shared__ double lds[kBlock / 64][RCHUNK][RROW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k_read = threadIdx.x >> 3, part = threadIdx.x & 7;
+#pragma unroll
+  for (int pass = 0; pass < (NACC + RCHUNK - 1) / RCHUNK; ++pass) {
+    if (pass > 0) __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < RCHUNK; ++kk) {
+      const int k = pass * RCHUNK + kk;
+      if (k < NACC) lds[wave][kk][lane] = acc[k];
+    }
+    __syncthreads();
+    const int k_out = pass * RCHUNK + k_read;
+    if (k_read < RCHUNK && k_out < NACC) {
+      double v = 0.0;
+#pragma unroll
+      for (int w = 0; w < kBlock / 64; ++w)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v += lds[w][k_read][j * 8 + part];
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      if (part == 0) out_row[k_out] = v;
+    }
+  }
 }
 
 extern "C" __global__ __launch_bounds__(kBlock) void mopt_jit_sweep(const JitArgs A) {
-  __shared__ double lds[kBlock / 64][NACC];
   // IBaseModel::setup (model.h:19-22): once per parameter vector, here once per workgroup and
   // parameter vector - x itself and, for forward differences, x + h_j e_j (the reference sets
   // up one clone of the model per perturbed vector, linearization.h:91-95).
@@ -77,20 +114,39 @@ extern "C" __global__ __launch_bounds__(kBlock) void mopt_jit_sweep(const JitArg
   double acc[NACC];
 #pragma unroll
   for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
-  const long long step = (long long)gridDim.x * kBlock;
-  long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
-  S d[D > 0 ? D : 1], d_next[D > 0 ? D : 1];
+  const long long step = (long long)gridDim.x * kBlock * VEC;
+  long long i = ((long long)blockIdx.x * kBlock + threadIdx.x) * VEC;
+  Pack cur[D > 0 ? D : 1], nxt[D > 0 ? D : 1];
   if (i < A.count) {
 #pragma unroll
-    for (int p = 0; p < D; ++p) d_next[p] = A.data[p * A.stride + i];
+    for (int p = 0; p < D; ++p) nxt[p] = *(const Pack *)(A.data + p * A.stride + i);
   }
   for (; i < A.count; i += step) {
 #pragma unroll
-    for (int p = 0; p < D; ++p) d[p] = d_next[p];
-    // the next element's data are requested before this one's arithmetic starts
+    for (int p = 0; p < D; ++p) cur[p] = nxt[p];
+    // the next step's data are requested before this one's arithmetic starts
     const long long ahead = i + step < A.count ? i + step : i;
 #pragma unroll
-    for (int p = 0; p < D; ++p) d_next[p] = A.data[p * A.stride + ahead];
+    for (int p = 0; p < D; ++p) nxt[p] = *(const Pack *)(A.data + p * A.stride + ahead);
+    // forward differences evaluate the residual N + 1 times per element: the elements of a pack
+    // are then taken one at a time in a real loop (unrolled, the scheduler interleaves them and the
+    // register count doubles); the cheaper sweeps are unrolled
+#if MODE == 2
+#pragma unroll 1
+#else
+#pragma unroll
+#endif
+    for (int e = 0; e < VEC; ++e) {
+    // an element past the end (the padded tail of the last pack) is evaluated on the pack's first
+    // element, which is in range, and enters every sum with weight zero
+    const bool valid = i + e < A.count;
+    S d[D > 0 ? D : 1];
+#pragma unroll
+    for (int p = 0; p < D; ++p) {
+      d[p] = cur[p].v[0];
+#pragma unroll
+      for (int k = 1; k < VEC; ++k) d[p] = (valid && e == k) ? cur[p].v[k] : d[p];
+    }
     // the per-x values stay in LDS: without this the compiler keeps all (N + 1) * AUX of them in
     // registers across the loop
     asm volatile("" ::: "memory");
@@ -99,6 +155,7 @@ extern "C" __global__ __launch_bounds__(kBlock) void mopt_jit_sweep(const JitArg
     S rr = 0;
 #pragma unroll
     for (int a = 0; a < M; ++a) rr += r[a] * r[a];
+    rr = valid ? rr : S(0);
 #if MODE == 0
     acc[0] += (double)rr;
 #else
@@ -124,6 +181,7 @@ extern "C" __global__ __launch_bounds__(kBlock) void mopt_jit_sweep(const JitArg
       const S den = rr + A.loss_param;
       w = (A.loss_param * A.loss_param) / (den * den);
     }
+    w = valid ? w : S(0);
     S SJ[M * N], Sr[M];
 #pragma unroll
     for (int a = 0; a < M; ++a) {
@@ -157,20 +215,9 @@ extern "C" __global__ __launch_bounds__(kBlock) void mopt_jit_sweep(const JitArg
     }
     acc[NH + N] += (double)rr;
 #endif
+    }
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < NACC; ++k) {
-    const double v = wave_sum(acc[k]);
-    if (lane == 0) lds[wave][k] = v;
-  }
-  __syncthreads();
-  if ((int)threadIdx.x < NACC) {
-    double v = 0.0;
-#pragma unroll
-    for (int w2 = 0; w2 < kBlock / 64; ++w2) v += lds[w2][threadIdx.x];
-    A.partials[(size_t)blockIdx.x * NACC + threadIdx.x] = v;
-  }
+  block_reduce_store(acc, A.partials + (size_t)blockIdx.x * NACC);
 }
 )JIT";
 
