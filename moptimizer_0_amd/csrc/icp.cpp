@@ -90,6 +90,7 @@ int icpUpdate(mopt_cost *c, const S *x, int64_t *num_matched) {
     a.dims[k] = mt.dims[k];
   }
   a.inv_cell = S(1.0 / mt.cell);
+  a.cell = S(mt.cell);
   a.max_dist2 = S(mt.max_dist * mt.max_dist);
   const auto T = moptimizer::so3::rigidFrom6DOF<S>(x);
   std::memcpy(a.T, T.m, sizeof T.m);

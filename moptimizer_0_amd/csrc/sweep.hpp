@@ -102,6 +102,7 @@ struct IcpMatchArgs {
   const int *cell_start;  // [cells + 1]
   S origin[3];
   S inv_cell;
+  S cell;                 // cell edge (>= the maximum correspondence distance)
   int dims[3];
   S max_dist2;
   S T[12];                // row-major [R | t] applied to the source before the search

@@ -805,28 +805,16 @@ __global__ __launch_bounds__(kBlockThreads) void icpMatchKernel(const IcpMatchAr
     if (inside) {
       const int c[3] = {int(g[0]), int(g[1]), int(g[2])};
       S best_d = A.max_dist2;
-      // The three x-neighbours of a (y, z) row are consecutive cells: one contiguous candidate
-      // range per row.  All 18 range bounds are fetched first (independent loads, one memory
-      // round trip instead of nine dependent ones); rows outside the grid get an empty range.
-      const int x0 = c[0] - 1 < 0 ? 0 : c[0] - 1;
-      const int x1 = c[0] + 1 >= A.dims[0] ? A.dims[0] - 1 : c[0] + 1;
-      int begin[9], end[9];
-#pragma unroll
-      for (int r = 0; r < 9; ++r) {
-        const int z = c[2] + r / 3 - 1, y = c[1] + r % 3 - 1;
-        const bool ok = z >= 0 && z < A.dims[2] && y >= 0 && y < A.dims[1] && x0 <= x1;
-        const long long row = ok ? ((long long)z * A.dims[1] + y) * A.dims[0] : 0;
-        const int lo = A.cell_start[row + (ok ? x0 : 0)];
-        const int hi = A.cell_start[row + (ok ? x1 + 1 : 0)];
-        begin[r] = lo;
-        end[r] = ok ? hi : lo;
-      }
-      auto consider = [&](const S (&q)[3]) {
+      // Ties go to the candidate stored first — (cell z, y, x; original index) order — whatever
+      // order the rows are visited in: the position k is part of the comparison.
+      int best_k = 0x7fffffff;
+      auto consider = [&](const S (&q)[3], int k) {
         const S d0 = w[0] - q[0], d1 = w[1] - q[1], d2 = w[2] - q[2];
         const S dist = d0 * d0 + d1 * d1 + d2 * d2;
-        if (dist <= A.max_dist2 && (!found || dist < best_d)) {
+        if (dist <= A.max_dist2 && (!found || dist < best_d || (dist == best_d && k < best_k))) {
           found = true;
           best_d = dist;
+          best_k = k;
           best[0] = q[0]; best[1] = q[1]; best[2] = q[2];
         }
       };
@@ -840,17 +828,51 @@ __global__ __launch_bounds__(kBlockThreads) void icpMatchKernel(const IcpMatchAr
           q[0] = all.v[0]; q[1] = all.v[1]; q[2] = all.v[2];
         }
       };
-#pragma unroll
-      for (int r = 0; r < 9; ++r) {
-        // two candidates per step, both loads issued before either is used; order of
-        // consideration (and so the tie-break) is the stored order
-        for (int k = begin[r]; k < end[r]; k += 2) {
+      // cells [xa, xb] of row (y, z) are consecutive in storage: one candidate range, two bounds
+      auto visit = [&](int y, int z, int xa, int xb) {
+        xa = xa < 0 ? 0 : xa;
+        xb = xb >= A.dims[0] ? A.dims[0] - 1 : xb;
+        if (z < 0 || z >= A.dims[2] || y < 0 || y >= A.dims[1] || xa > xb) return;
+        const long long row = ((long long)z * A.dims[1] + y) * A.dims[0];
+        const int lo = A.cell_start[row + xa], hi = A.cell_start[row + xb + 1];
+        // two candidates per step, both loads issued before either is used
+        for (int k = lo; k < hi; k += 2) {
           S qa[3], qb[3];
-          const bool pair = k + 1 < end[r];
+          const bool pair = k + 1 < hi;
           fetch(k, qa);
           fetch(pair ? k + 1 : k, qb);
-          consider(qa);
-          if (pair) consider(qb);
+          consider(qa, k);
+          if (pair) consider(qb, k + 1);
+        }
+      };
+      // The source's own cell first; every other cell of the 3 x 3 x 3 block is visited only if
+      // its box can hold something at least as close as what has been found (or within the
+      // maximum distance while nothing has) — the bound is the distance to the own cell's faces,
+      // relaxed by 1e-9 relative (targets were binned with the same floor()).  Range bounds are
+      // fetched only for what is visited.  At about one target per cell and a source close to its
+      // target this leaves 1-3 cells of 27 and takes most of the divergent tail off the wave.
+      const S fx = w[0] - (A.origin[0] + S(c[0]) * A.cell);  // offsets inside the own cell, [0, cell)
+      const S fy = w[1] - (A.origin[1] + S(c[1]) * A.cell);
+      const S fz = w[2] - (A.origin[2] + S(c[2]) * A.cell);
+      const S gx[2] = {fx, A.cell - fx};
+      const S gap_y[3] = {fy, S(0), A.cell - fy};
+      const S gap_z[3] = {fz, S(0), A.cell - fz};
+      auto within = [&](S bound) {
+        return bound * (S(1) - S(1e-9)) <= (found ? best_d : A.max_dist2);
+      };
+      auto sq = [](S v) { return v > S(0) ? v * v : S(0); };
+      visit(c[1], c[2], c[0], c[0]);
+#pragma unroll
+      for (int r = 0; r < 9; ++r) {
+        const int y = c[1] + r % 3 - 1, z = c[2] + r / 3 - 1;
+        const S yz = sq(gap_y[r % 3]) + sq(gap_z[r / 3]);
+        if (!within(yz)) continue;
+        const bool left = within(yz + sq(gx[0])), right = within(yz + sq(gx[1]));
+        if (r == 4) {  // the own row: its centre cell is done
+          if (left) visit(y, z, c[0] - 1, c[0] - 1);
+          if (right) visit(y, z, c[0] + 1, c[0] + 1);
+        } else {
+          visit(y, z, left ? c[0] - 1 : c[0], right ? c[0] + 1 : c[0]);
         }
       }
     }
