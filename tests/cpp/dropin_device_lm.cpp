@@ -1,0 +1,203 @@
+// The reference's known-answer LM tests with the optimizer itself swapped for the device-resident
+// one: `moptimizer::hip::LevenbergMarquadtDevice<Scalar>` (mopt_lm_minimize) where the reference
+// programs say `LevenbergMarquadtDynamic<Scalar>` — tst/curve_fitting.cpp:101-147,
+// tst/powell.cpp:62-136, tst/simple_model.cpp:28-82, tst/loss_function.cpp:45-60,
+// tst/multiple_objectives.cpp:102-132, tst/camera_calibration.cpp:101-122 — expected values and
+// tolerances the reference's, and each solve compared with the host loop (the reference's loop
+// restated, tests/support) over the very same HIP cost: same status, same number of outer
+// iterations up to the noise-level stop (forward differences through device libm), same x.
+// Covers n = 2, 4, 6, float and double, one and two costs, loss and covariance, and the error
+// behaviour of optimizer.h:33-54.
+#include <cmath>
+#include <cstdio>
+#include <memory>
+#include <stdexcept>
+#include <vector>
+
+#include "moptimizer_amd/cost_function_hip.hpp"
+#include "moptimizer_amd/levenberg_marquadt_device.hpp"
+#include "moptimizer_caller/levenberg_marquadt.hpp"
+
+#include "curve_data.inc"
+
+namespace mh = moptimizer::hip;
+using moptimizer::LevenbergMarquadtDynamic;
+using moptimizer::OptimizationStatus;
+
+static int g_fail = 0, g_checks = 0;
+static void expectNear(const char *what, double got, double want, double tol) {
+  ++g_checks;
+  const bool ok = std::fabs(got - want) <= tol && !std::isnan(got);
+  if (!ok) ++g_fail;
+  std::printf("%s %-64s got % .10g want % .10g tol %.1e\n", ok ? "PASS" : "FAIL", what, got, want, tol);
+}
+static void expectTrue(const char *what, bool ok) {
+  ++g_checks;
+  if (!ok) ++g_fail;
+  std::printf("%s %s\n", ok ? "PASS" : "FAIL", what);
+}
+
+// Run the same problem under the host loop and under the device-resident loop; report the device
+// result and check it against the host loop's.
+template <typename S>
+static void solveBoth(const char *name, std::vector<moptimizer::CostFunctionBase<S> *> costs, int n,
+                      const S *start, int max_iterations, S *x_out, double agree_tol) {
+  std::vector<S> xh(start, start + n), xd(start, start + n);
+  LevenbergMarquadtDynamic<S> host(n);
+  mh::LevenbergMarquadtDevice<S> device(n);
+  if (max_iterations > 0) {
+    host.setMaximumIterations(max_iterations);
+    device.setMaximumIterations(max_iterations);
+  }
+  for (auto *c : costs) {
+    host.addCost(c);
+    device.addCost(c);
+  }
+  const OptimizationStatus sh = host.minimize(xh.data());
+  const OptimizationStatus sd = device.minimize(xd.data());
+  char label[160];
+  std::snprintf(label, sizeof label, "%s: device status == host status (%d)", name, int(sh));
+  const bool either_limit = sh == OptimizationStatus::MAXIMUM_ITERATIONS_REACHED ||
+                            sd == OptimizationStatus::MAXIMUM_ITERATIONS_REACHED;
+  expectTrue(label, sd == sh || either_limit);
+  std::snprintf(label, sizeof label, "%s: outer iterations %u vs host %u", name,
+                device.getExecutedIterations(), host.getExecutedIterations());
+  expectTrue(label, std::abs(int(device.getExecutedIterations()) - int(host.getExecutedIterations())) <= 1);
+  for (int i = 0; i < n; ++i) {
+    std::snprintf(label, sizeof label, "%s: x[%d] device vs host loop", name, i);
+    expectNear(label, double(xd[i]), double(xh[i]), agree_tol);
+    x_out[i] = xd[i];
+  }
+}
+
+static void curveFitting() {
+  for (int ic = 0; ic < 2; ++ic) {
+    mh::CostFunctionNumerical<double, 2, 1> cost(std::make_shared<mh::ExpCurveDeviceModel>(kCurveData),
+                                                kNumObservations);
+    const double start[2] = {ic == 0 ? 0.0 : 1.20, ic == 0 ? 0.0 : 2.0};
+    double x[2];
+    solveBoth<double>(ic == 0 ? "CurveFitting.InitialCondition1" : "CurveFitting.InitialCondition2", {&cost}, 2,
+                      start, ic == 1 ? 50 : 0, x, 1e-6);
+    expectNear("  x[0] vs the reference's known answer", x[0], 0.291861, ic == 0 ? 5e-5 : 1e-4);
+    expectNear("  x[1] vs the reference's known answer", x[1], 0.131439, ic == 0 ? 5e-5 : 1e-4);
+  }
+}
+
+static void powell() {
+  for (int variant = 0; variant < 3; ++variant) {
+    const double start[] = {3, -1, 0, 4};
+    std::unique_ptr<moptimizer::CostFunctionBase<double>> cost;
+    if (variant == 0)
+      cost.reset(new mh::CostFunctionNumerical<double, 4, 4>(std::make_shared<mh::PowellDeviceModel>(), 1));
+    else
+      cost.reset(new mh::CostFunctionAnalyticalDynamic<double>(std::make_shared<mh::PowellDeviceModel>(), 4, 4, 1));
+    if (variant == 2) {
+      auto covariance = std::make_shared<moptimizer::covariance::Matrix<double>>();
+      covariance->resize(4, 4);
+      covariance->setIdentity();
+      *covariance *= 0.01;
+      cost->setCovariance(covariance);
+    }
+    static const char *names[] = {"PowellFunction numeric", "PowellFunction analytic",
+                                  "PowellFunction analytic, covariance"};
+    double x[4];
+    solveBoth<double>(names[variant], {cost.get()}, 4, start, 25, x, 1e-6);
+    for (int i = 0; i < 4; ++i) expectNear("  x[i] vs the reference's known answer", x[i], 0.0, 5e-5);
+  }
+}
+
+static void simpleModelFloat() {
+  float x_data[7] = {0.038, 0.194, 0.425, 0.626, 1.253, 2.5, 3.70};
+  float y_data[7] = {0.05, 0.127, 0.094, 0.2122, 0.2729, 0.2665, 0.3317};
+  const float starts[2][2] = {{0.9f, 0.2f}, {1.9f, 1.5f}};
+  for (int with_loss = 0; with_loss < 2; ++with_loss)
+    for (int s = 0; s < 2; ++s) {
+      auto model = std::make_shared<mh::RationalDeviceModel<float>>(x_data, y_data);
+      mh::CostFunctionNumerical<float, 2, 1> cost(model, 7);
+      if (with_loss) cost.setLossFunction(std::make_shared<moptimizer::loss::GemmanMCClure<float>>(100.0f));
+      float x[2];
+      char label[96];
+      std::snprintf(label, sizeof label, "SimpleModel(float%s) start%d", with_loss ? ",GM100" : "", s);
+      solveBoth<float>(label, {&cost}, 2, starts[s], 0, x, 5e-3);
+      expectNear("  x[0] vs the reference's known answer", x[0], 0.362, 0.01);
+      expectNear("  x[1] vs the reference's known answer", x[1], 0.556, 0.01);
+    }
+}
+
+static void multipleObjectives() {
+  mh::CostFunctionNumerical<double, 2, 1> whole(std::make_shared<mh::ExpCurveDeviceModel>(kCurveData), 67);
+  mh::CostFunctionNumerical<double, 2, 1> first(std::make_shared<mh::ExpCurveDeviceModel>(kCurveData), 30);
+  mh::CostFunctionNumerical<double, 2, 1> rest(std::make_shared<mh::ExpCurveDeviceModel>(&kCurveData[60]), 37);
+  const double start[2] = {0.0, 0.0};
+  double x_multi[2], x_single[2];
+  solveBoth<double>("MultipleObjectives two costs", {&first, &rest}, 2, start, 0, x_multi, 1e-6);
+  solveBoth<double>("MultipleObjectives one cost", {&whole}, 2, start, 0, x_single, 1e-6);
+  expectNear("  multi == single x[0]", x_multi[0], x_single[0], 1e-6);
+  expectNear("  multi == single x[1]", x_multi[1], x_single[1], 1e-6);
+  expectNear("  x[0] vs the reference's known answer", x_multi[0], 0.291861, 5e-5);
+  expectNear("  x[1] vs the reference's known answer", x_multi[1], 0.131439, 5e-5);
+}
+
+static void cameraCalibration() {
+  // tst/camera_calibration.cpp:77-98: five correspondences, the Ceres solution
+  const double pts[5][4] = {{2.055643, 0.065643, 0.684357, 1}, {1.963083, -0.765833, 0.653833, 1},
+                            {2.927500, 0.707000, 0.125250, 1}, {2.957833, 0.384667, 0.123667, 1},
+                            {2.756000, 0.712000, -0.298000, 1}};
+  const std::int32_t pix[5][2] = {{621, 67}, {878, 76}, {491, 279}, {559, 282}, {481, 388}};
+  const double ceres[6] = {-0.010075911761110, 0.020714594988011, -0.058274626693636,
+                           0.018372232700639, -0.001318370512544, 0.027402383983518};
+  for (int bad_start = 0; bad_start < 2; ++bad_start) {
+    auto model = std::make_shared<mh::ReprojectionDeviceModel>(&pts[0][0], &pix[0][0], 5);
+    mh::CostFunctionNumerical<double, 6, 2> cost(model, 5);
+    const double good[6] = {0, 0, 0, 0, 0, 0}, bad[6] = {0.5, 0.5, 0.5, 0.2, 0.5, 0.5};
+    double x[6];
+    solveBoth<double>(bad_start ? "CameraCalibration.BadWeather" : "CameraCalibration.GoodWeather", {&cost}, 6,
+                      bad_start ? bad : good, bad_start ? 50 : 0, x, 1e-6);
+    for (int i = 0; i < 6; ++i) expectNear("  x[i] vs the Ceres solution", x[i], ceres[i], 5e-5);
+  }
+}
+
+static void errors() {
+  mh::LevenbergMarquadtDevice<double> lm(2);
+  bool threw = false;
+  double x[2] = {0, 0};
+  try { lm.minimize(x); } catch (const std::runtime_error &) { threw = true; }
+  expectTrue("minimize() without costs throws std::runtime_error (optimizer.h:48-54)", threw);
+  threw = false;
+  try { lm.setMaximumIterations(-1); } catch (const std::invalid_argument &) { threw = true; }
+  expectTrue("setMaximumIterations(-1) throws std::invalid_argument (optimizer.h:33-37)", threw);
+  expectTrue("step() is the reference's stub", lm.step(x) == OptimizationStatus::NUMERIC_ERROR);
+  // a host cost has nothing to run on the device
+  struct HostCost : moptimizer::CostFunctionBase<double> {
+    HostCost() : CostFunctionBase<double>(nullptr, 1) {}
+    double computeCost(const double *) override { return 0; }
+    double linearize(const double *, double *, double *) override { return 0; }
+  } host_cost;
+  threw = false;
+  try { lm.addCost(&host_cost); } catch (const moptimizer::Exception &) { threw = true; }
+  expectTrue("a host cost is refused with moptimizer::Exception", threw);
+  // zero iterations: nothing runs, x untouched
+  mh::CostFunctionNumerical<double, 2, 1> cost(std::make_shared<mh::ExpCurveDeviceModel>(kCurveData), 67);
+  lm.addCost(&cost);
+  lm.setMaximumIterations(0);
+  x[0] = 0.25; x[1] = 0.5;
+  expectTrue("zero iterations: MAXIMUM_ITERATIONS_REACHED",
+             lm.minimize(x) == OptimizationStatus::MAXIMUM_ITERATIONS_REACHED);
+  expectTrue("zero iterations: x untouched, no sweep", x[0] == 0.25 && x[1] == 0.5 && lm.sweeps() == 0);
+}
+
+int main() {
+  try {
+    curveFitting();
+    powell();
+    simpleModelFloat();
+    multipleObjectives();
+    cameraCalibration();
+    errors();
+  } catch (const std::exception &e) {
+    std::printf("FAIL exception: %s\n", e.what());
+    return 2;
+  }
+  std::printf("SUMMARY %d checks, %d failures\n", g_checks, g_fail);
+  return g_fail == 0 ? 0 : 1;
+}

@@ -33,3 +33,15 @@ def test_cpp_dropin_reference_model_tests(hip_lib):
     print(out.stdout[-6000:])
     assert out.returncode == 0, out.stdout[-6000:] + out.stderr[-2000:]
     assert "failures=0" in out.stdout
+
+
+def test_cpp_device_resident_optimizer(hip_lib):
+    """The reference's known-answer LM tests with `hip::LevenbergMarquadtDevice` in place of
+    `LevenbergMarquadtDynamic` (tests/cpp/dropin_device_lm.cpp): n = 2 / 4 / 6, float and double,
+    one and two costs, against the known answers and against the host loop over the same costs."""
+    exe = os.path.join(ds.ROOT, "tests", "cpp", "_build", "dropin_device_lm")
+    assert os.path.exists(exe), "build it with `make cpptests`"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    print(out.stdout[-8000:])
+    assert out.returncode == 0, out.stdout[-8000:] + out.stderr[-2000:]
+    assert ", 0 failures" in out.stdout
