@@ -90,7 +90,7 @@ static void powell() {
     if (variant == 0)
       cost.reset(new mh::CostFunctionNumerical<double, 4, 4>(std::make_shared<mh::PowellDeviceModel>(), 1));
     else
-      cost.reset(new mh::CostFunctionAnalyticalDynamic<double>(std::make_shared<mh::PowellDeviceModel>(), 4, 4, 1));
+      cost.reset(new mh::CostFunctionNumericalDynamic<double>(std::make_shared<mh::PowellDeviceModel>(), 4, 4, 1));
     if (variant == 2) {
       auto covariance = std::make_shared<moptimizer::covariance::Matrix<double>>();
       covariance->resize(4, 4);
@@ -98,8 +98,8 @@ static void powell() {
       *covariance *= 0.01;
       cost->setCovariance(covariance);
     }
-    static const char *names[] = {"PowellFunction numeric", "PowellFunction analytic",
-                                  "PowellFunction analytic, covariance"};
+    static const char *names[] = {"PowellFunction.InitialCondition0", "PowellFunction.IC0Dynamic",
+                                  "PowellFunction.IC0DynamicCovariance"};
     double x[4];
     solveBoth<double>(names[variant], {cost.get()}, 4, start, 25, x, 1e-6);
     for (int i = 0; i < 4; ++i) expectNear("  x[i] vs the reference's known answer", x[i], 0.0, 5e-5);
