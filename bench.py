@@ -313,12 +313,14 @@ def main():
 
     # N > 1: the 43 sums of every sweep are added over the ranks.  Transports in order of
     # preference (see --collective); a transport is used only if every rank attached it.
-    usable, collective, sweep = [], "none", None
+    usable, collective = [], "none"
     if world > 1:
+        # RCCL is attached later, among the extras behind the watchdog: its communicator is only
+        # needed for the comparison, and nothing that could stall should sit before the measurement
         if args.collective == "torch":
             want = ()
-        elif args.collective == "auto" or not args.no_compare:
-            want = ("host", "peer", "rccl")
+        elif args.collective == "auto":
+            want = ("host", "peer")
         else:
             want = (args.collective,)
         usable = attach_combines(cost, rank, world, want=want, log=log) if want else []
@@ -328,9 +330,6 @@ def main():
             collective = usable[0]
         else:
             collective = "torch"  # still RCCL (or gloo when rehearsing), through torch.distributed
-        if collective == "torch":
-            cost.set_combine(mo.COMBINE_NONE)
-            sweep = gpu_point2point_sweep(cost)
     modes = {"none": mo.COMBINE_NONE, "rccl": mo.COMBINE_RCCL, "host": mo.COMBINE_HOST,
              "peer": mo.COMBINE_PEER}
 
@@ -378,10 +377,44 @@ def main():
     # state (measured at 10 M, same box: 87.0 us per step timed after 70 steps, 85.8 after 150 ms of
     # sweeps, 84.9 after 1 s), and the metric is the steady-state rate of an LM loop that runs
     # thousands of sweeps.  The count is the same on every rank (each step holds a collective).
+    from moptimizer_0_amd.sharded import _all_agree
+
+    def guarded_pass(the_cost, name, steps, warmup, settle):
+        """A timed pass that every rank either completes or abandons together: a transport that
+        fails at run time on any rank (a peer that never delivers ends in MOPT_ERR_PEER_TIMEOUT, not
+        in a hang) is reported as unusable instead of ending the run."""
+        ok, err, res = True, None, None
+        try:
+            if name == "torch":
+                the_cost.set_combine(mo.COMBINE_NONE)
+                res = timed_pass(the_cost, None, steps, warmup, settle,
+                                 via_torch=gpu_point2point_sweep(the_cost))
+            else:
+                res = timed_pass(the_cost, name, steps, warmup, settle)
+        except Exception as e:  # noqa: BLE001 - whatever it was, the ranks must agree on it
+            ok, err = False, e
+        if world > 1 and not _all_agree(ok):
+            if err is not None:
+                log("rank %d: combine %r failed in the timed pass: %s" % (rank, name, err))
+            return None
+        return res
+
     cost.set_profiling(False)
-    elapsed, H, s = timed_pass(cost, None if collective in ("none", "torch") else collective,
-                               args.steps, args.warmup, settle_steps(args.n, args.settle_ms),
-                               via_torch=sweep)
+    settle = settle_steps(args.n, args.settle_ms)
+    if world == 1:
+        elapsed, H, s = timed_pass(cost, None, args.steps, args.warmup, settle)
+    else:
+        order = [collective] + [c for c in usable + ["torch"] if c != collective]
+        res = None
+        for name in order:
+            res = guarded_pass(cost, name, args.steps, args.warmup, settle)
+            if res is not None:
+                collective = name
+                break
+            usable = [c for c in usable if c != name]
+        if res is None:
+            raise SystemExit("rank %d: no way of adding the ranks' sums worked" % rank)
+        elapsed, H, s = res
 
     # ---- kernel time: a pass of its own, every launch carrying its dispatch timestamps ---------
     def kernel_pass(the_cost, steps):
@@ -401,29 +434,122 @@ def main():
     ksteps = args.kernel_steps if args.kernel_steps > 0 else min(args.steps, 100)
     kernel_ms, launches = kernel_pass(cost, ksteps)
 
-    extra = {}
+    total = args.total_n if args.total_n else args.n * world
+    ms_per_step = elapsed / args.steps * 1e3
+    bpc = BYTES_PER_CORRESPONDENCE[scalar_bytes]
+    achieved = args.n * bpc / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            t = json.load(open(tpath)).get("%s_%s_n%d" % (args.mode, args.dtype, args.n))
+            if t is not None:
+                # PMC counters need rocprofv3 --pmc passes of their own; what is reported here
+                # is the committed measurement of this same launch, not a reading of this run
+                traffic = {"bytes": t, "source": "profiles/hbm_traffic.json (rocprofv3 --pmc "
+                           "FETCH_SIZE x2 + WRITE_SIZE, separate passes, same command)",
+                           "measured_this_run": False}
+        except Exception:
+            traffic = None
+    how = {"none": "no collective",
+           "host": "finalize kernels publish into one shared pinned host block, host adds 43 fp64 x ranks",
+           "peer": "finalize kernels push 43 fp64 into each other's HBM slots (xGMI / IPC) and add on the device",
+           "rccl": "RCCL all-reduce of 43 fp64 on the cost's stream",
+           "torch": "torch.distributed all_reduce of 43 fp64"}[collective]
+    line = {
+        "metric": "point-correspondences/sec per LM linearization sweep; % HBM peak",
+        "value": total * args.steps / elapsed,
+        "unit": "correspondences/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong" if args.total_n else "weak",
+        "vs_baseline": None,
+        "dtype": args.dtype,
+        "data": "synthetic",
+        "config": {
+            "workload": "point2point %s Jacobian, %d correspondences per GPU (%s), "
+                        "linearize + %s + result to host each step"
+                        % (args.mode, args.n, args.dtype, how),
+            "correspondences_per_gpu": args.n,
+            "total_correspondences": total,
+            "parallelism": "shard%d" % world,
+            "collective": collective if (backend == "nccl" or collective in ("host", "peer", "none"))
+            else "torch/" + backend + " (rehearsal)",
+            "collectives_attached": list(usable),
+            "rank_backend": backend if world > 1 else None,
+            "kernel_variant": args.variant,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "kernel_ms": kernel_ms,
+            "kernel_launches_timed": launches,
+            "kernel_timing": "separate pass after the timed steps; every launch carries its "
+                             "dispatch timestamps (hipExtLaunchKernelGGL)",
+            "algorithmic_bytes_per_launch": args.n * bpc,
+        },
+        "pct_hbm_peak": 100.0 * achieved / HBM_PEAK_GBS,
+        "check": {"sum_sq": float(s), "H00": float(H[0, 0])},
+    }
+
+    # The line above is the measurement.  What follows only adds to it (other transports, the
+    # strong-scaling split, the literal kernel, the CPU baseline); if any of it stalls — this is
+    # the first time more than one GPU runs these paths — a watchdog prints the line as it stands
+    # and ends the rank, so that the run still reports.
+    import threading
+    emitted = threading.Lock()
+
+    def emit(final):
+        if not emitted.acquire(blocking=False):
+            return
+        if rank == 0:
+            if not final:
+                line["note"] = "watchdog: an extra pass did not finish; reported without it"
+            print(json.dumps(line), flush=True)
+
+    def watchdog():
+        emit(False)
+        os._exit(0)
+
+    dog = None
+    if world > 1:
+        dog = threading.Timer(float(os.environ.get("MOPT_BENCH_EXTRAS_TIMEOUT_S", "120")), watchdog)
+        dog.daemon = True
+        dog.start()
+
     if world > 1 and not args.no_compare:
         # every other way of adding the ranks' sums, and no combine at all, K steps each
-        per = {}
+        more = tuple(t for t in ("host", "peer", "rccl") if t not in usable and t in
+                     (("host", "peer", "rccl") if args.collective != "torch" else ()))
+        if more:
+            usable = usable + attach_combines(cost, rank, world, want=more, log=log)
+            line["config"]["collectives_attached"] = list(usable)
+        per = {collective: ms_per_step}
         for name in ["none"] + usable:
-            if name == collective:
-                per[name] = elapsed / args.steps * 1e3
+            if name in per:
                 continue
-            e, _, _ = timed_pass(cost, name, args.steps, min(args.warmup, 10), 20)
-            per[name] = e / args.steps * 1e3
-        if collective == "torch":
-            per["torch"] = elapsed / args.steps * 1e3
-        extra["ms_per_step_by_collective"] = per
-        extra["ms_per_step_without_collective"] = per["none"]
-    literal_ms = None
+            r = guarded_pass(cost, name, args.steps, min(args.warmup, 10), 20)
+            if r is not None:
+                per[name] = r[0] / args.steps * 1e3
+        line["ms_per_step_by_collective"] = per
+        if "none" in per:
+            line["ms_per_step_without_collective"] = per["none"]
     if world == 1 and args.variant == "auto" and args.mode != "analytic_tst":
         # the same sweep evaluated literally (every residual and Jacobian entry per point, as the
         # reference does) — a driver-timed number for that kernel too
         cost.set_kernel_variant(mo.KERNEL_LITERAL)
         literal_ms, _ = kernel_pass(cost, min(ksteps, 30))
         cost.set_kernel_variant(variant)
+        line["roofline"]["literal_kernel_ms"] = literal_ms
+        line["roofline"]["literal_frac"] = args.n * bpc / (literal_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
 
-    config4 = None
     if world > 1 and not args.no_compare and not args.total_n:
         # BASELINE config 4: 10 M correspondences IN TOTAL split over the ranks (strong scaling;
         # 60 MB per GPU at 8 ranks, Infinity-Cache resident, latency-bound)
@@ -434,96 +560,28 @@ def main():
         attached4 = attach_combines(cost4, rank, world, want=tuple(usable), log=log) if usable else []
         per4 = {}
         for name in ["none"] + attached4:
-            e, _, _ = timed_pass(cost4, name, args.steps, min(args.warmup, 10),
-                                 settle_steps(hi - lo, 50.0))
-            per4[name] = e / args.steps * 1e3
-        best = min((v, k) for k, v in per4.items() if k != "none") if attached4 else (None, None)
-        config4 = {"total_correspondences": total4, "correspondences_per_gpu": hi - lo,
-                   "ms_per_step_by_collective": per4, "collective": best[1],
-                   "ms_per_step": best[0],
-                   "value": (total4 / (best[0] * 1e-3)) if best[0] else None,
-                   "unit": "correspondences/s", "scaling": "strong"}
+            r = guarded_pass(cost4, name, args.steps, min(args.warmup, 10), settle_steps(hi - lo, 50.0))
+            if r is not None:
+                per4[name] = r[0] / args.steps * 1e3
+        combined = {k: v for k, v in per4.items() if k != "none"}
+        best = min((v, k) for k, v in combined.items()) if combined else (None, None)
+        line["config4_strong"] = {
+            "total_correspondences": total4, "correspondences_per_gpu": hi - lo,
+            "ms_per_step_by_collective": per4, "collective": best[1], "ms_per_step": best[0],
+            "value": (total4 / (best[0] * 1e-3)) if best[0] else None,
+            "unit": "correspondences/s", "scaling": "strong"}
         barrier()
         cost4.close()
 
     if rank == 0:
-        total = args.total_n if args.total_n else args.n * world
-        ms_per_step = elapsed / args.steps * 1e3
-        value = total * args.steps / elapsed
-        bpc = BYTES_PER_CORRESPONDENCE[scalar_bytes]
-        achieved = args.n * bpc / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                t = json.load(open(tpath)).get("%s_%s_n%d" % (args.mode, args.dtype, args.n))
-                if t is not None:
-                    # PMC counters need rocprofv3 --pmc passes of their own; what is reported here
-                    # is the committed measurement of this same launch, not a reading of this run
-                    traffic = {"bytes": t, "source": "profiles/hbm_traffic.json (rocprofv3 --pmc "
-                               "FETCH_SIZE x2 + WRITE_SIZE, separate passes, same command)",
-                               "measured_this_run": False}
-            except Exception:
-                traffic = None
-        how = {"none": "no collective",
-               "host": "finalize kernels publish into one shared pinned host block, host adds 43 fp64 x ranks",
-               "peer": "finalize kernels push 43 fp64 into each other's HBM slots (xGMI / IPC) and add on the device",
-               "rccl": "RCCL all-reduce of 43 fp64 on the cost's stream",
-               "torch": "torch.distributed all_reduce of 43 fp64"}[collective]
-        line = {
-            "metric": "point-correspondences/sec per LM linearization sweep; % HBM peak",
-            "value": value,
-            "unit": "correspondences/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
-            "higher_is_better": True,
-            "scaling": "strong" if args.total_n else "weak",
-            "vs_baseline": None,
-            "dtype": args.dtype,
-            "data": "synthetic",
-            "config": {
-                "workload": "point2point %s Jacobian, %d correspondences per GPU (%s), "
-                            "linearize + %s + result to host each step"
-                            % (args.mode, args.n, args.dtype, how),
-                "correspondences_per_gpu": args.n,
-                "total_correspondences": total,
-                "parallelism": "shard%d" % world,
-                "collective": collective if (backend == "nccl" or collective in ("host", "peer", "none"))
-                else "torch/" + backend + " (rehearsal)",
-                "collectives_attached": usable,
-                "rank_backend": backend if world > 1 else None,
-                "kernel_variant": args.variant,
-            },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "kernel_ms": kernel_ms,
-                "kernel_launches_timed": launches,
-                "kernel_timing": "separate pass after the timed steps; every launch carries its "
-                                 "dispatch timestamps (hipExtLaunchKernelGGL)",
-                "algorithmic_bytes_per_launch": args.n * bpc,
-            },
-            "pct_hbm_peak": 100.0 * achieved / HBM_PEAK_GBS,
-            "check": {"sum_sq": float(s), "H00": float(H[0, 0])},
-        }
-        if literal_ms is not None:
-            line["roofline"]["literal_kernel_ms"] = literal_ms
-            line["roofline"]["literal_frac"] = args.n * bpc / (literal_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-        line.update(extra)
-        if config4 is not None:
-            line["config4_strong"] = config4
         if keep_host:
             line["cpu_baseline"] = cpu_baseline(src_host, tgt_host, ds.X_GENERIC, jac_mode,
                                                 args.cpu_seconds)
         elif world == 1:
             line["cpu_baseline"] = None
-        print(json.dumps(line), flush=True)
+    if dog is not None:
+        dog.cancel()
+    emit(True)
 
     barrier()  # nobody releases its slot blocks while a peer may still push into them
     cost.close()
