@@ -28,6 +28,13 @@ def main():
     dist.init_process_group("gloo")
     src, tgt = ds.synthetic_pair(n_total, seed=11, noise=0.02)
     lo, hi = shard_range(n_total, rank, world)
+    if os.environ.get("MOPT_TEST_UNEVEN"):
+        # hand-offs have to hold under UNEVEN load: rank 0 sweeps 97 % of the points, the others a
+        # sliver each, so the fast ranks' pushes always wait in the slow rank's slots (and the slow
+        # rank's arrive last everywhere)
+        cut = [0] + [int(n_total * 0.97) + k * ((n_total - int(n_total * 0.97)) // (world - 1))
+                     for k in range(world - 1)] + [n_total]
+        lo, hi = cut[rank], cut[rank + 1]
     cost = mo.Point2PointCost(src[lo:hi], tgt[lo:hi], device=device)
     cost.set_loss(mo.LOSS_GEMAN_MCCLURE, 50.0)
     want = ("host", "peer", "rccl") if own_gpu else ("host", "peer")
@@ -63,6 +70,14 @@ def main():
         for k in range(200):
             acc += cost.compute_cost(ds.X_GENERIC * (0.01 * k))
         res[name + "_chain"] = np.array([acc])
+        # ... and a long run of full linearizations, every word of every result kept
+        chain = np.zeros((600, 43))
+        for k in range(600):
+            H, b, s = cost.linearize(ds.X_GENERIC * (0.003 * k), mo.JAC_ANALYTIC)
+            chain[k, :36] = H.ravel(order="F")
+            chain[k, 36:42] = b
+            chain[k, 42] = s
+        res[name + "_linchain"] = chain
     if "peer" in usable:
         # the whole LM loop resident on every rank's device, each on its shard, the sums of every
         # point added over the ranks inside the finalize kernels: identical iterates everywhere
@@ -83,6 +98,24 @@ def main():
         res["lm_whole_rep"] = np.array([rep["status"], rep["iterations"], rep["sweeps"]])
         whole.close()
         # what the sums must be: the same shards, in one process, added on the host in shard order
+        if os.environ.get("MOPT_TEST_UNEVEN"):
+            # the group splits evenly; the reference for uneven shards is the sum of per-shard costs
+            parts = [mo.Point2PointCost(src[cut[k]:cut[k + 1]], tgt[cut[k]:cut[k + 1]], device=device)
+                     for k in range(world)]
+            for c in parts:
+                c.set_loss(mo.LOSS_GEMAN_MCCLURE, 50.0)
+            chain = np.zeros((600, 43))
+            for k in range(600):
+                tot = np.zeros(43)
+                for c in parts:  # shard order, starting from zero: the order every rank adds in
+                    H, b, s = c.linearize(ds.X_GENERIC * (0.003 * k), mo.JAC_ANALYTIC)
+                    tot[:36] += H.ravel(order="F")
+                    tot[36:42] += b
+                    tot[42] += s
+                chain[k] = tot
+            res["expected_linchain"] = chain
+            for c in parts:
+                c.close()
         group = mo.Point2PointGroup(src, tgt, [0] * world)
         group.set_loss(mo.LOSS_GEMAN_MCCLURE, 50.0)
         for jm in (mo.JAC_ANALYTIC, mo.JAC_NUMERIC):

@@ -67,6 +67,20 @@ def test_ranks_combine_through_the_library(hip_lib, tmp_path, world):
             assert res[r][name + "_chain"].tobytes() == res[0]["group_chain"].tobytes()
 
 
+def test_handoffs_hold_under_uneven_load(hip_lib, tmp_path):
+    """3 ranks, one with 97 % of the points: 600 linearizations per transport, every one of the 43
+    words of every result on every rank equal to the sum of the per-shard results formed in shard
+    order (a stale or torn slot would show as a wrong word somewhere)."""
+    res = run_ranks(tmp_path, 3, 400_001, extra_env={"MOPT_TEST_UNEVEN": "1"})
+    want = res[0]["expected_linchain"]
+    for name in ("host", "peer"):
+        for r in range(3):
+            got = res[r][name + "_linchain"]
+            assert got.shape == want.shape
+            bad = np.argwhere(got != want)
+            assert bad.size == 0, (name, r, bad[:5], got[bad[0][0]][:3], want[bad[0][0]][:3])
+
+
 def test_device_resident_lm_over_sharded_cost(hip_lib, tmp_path):
     """mopt_lm_minimize on every rank with MOPT_COMBINE_PEER: all ranks return the same x, bit for
     bit, and it is the solution of the unsharded problem."""
