@@ -234,7 +234,7 @@ void fillBasis(const mopt_cost *c, int jac_mode, const mopt::P2PSweepArgs<S> &a,
 // ((R_j - R) p + (t_j - t)) / h_j — the reference's quotient without its per-point cancellation
 // error eps |R p + t| / h_j.  With h_j = sqrt(eps) |x_j| (linearization.h:85) that error is part of
 // what the reference computes once |x_j| is small: measured distance between the two evaluations
-// 2e-8 / |x_j| (scripts/parity_table.py; the literal sweep matches the reference to 1e-14 at every
+// 2e-8 / |x_j| (tests/tools/parity_table.py; the literal sweep matches the reference to 1e-14 at every
 // step size).  So below |x_j| = 0.08, where 4 x that measurement would pass the 1e-6 bar, AUTO
 // evaluates literally; x_j = 0 takes the fixed step sqrt(eps) and is fine.
 template <typename S>

@@ -24,7 +24,7 @@ def fd_tolerance(x, variant=0):
     The transforms at x and x + h_j e_j are bit-identical in the product and the oracle
     (tests/test_so3_bitwise.py), so the literal evaluation — every residual at x and at the six
     perturbed points, the quotient per entry, as the reference does it — reproduces the reference's
-    numbers to rounding (measured 1e-14 at every |x_j| from 1e-8 to 1, scripts/parity_table.py) and
+    numbers to rounding (measured 1e-14 at every |x_j| from 1e-8 to 1, tests/tools/parity_table.py) and
     the north-star bar applies as it stands.  AUTO selects that evaluation whenever a step is small
     enough for the other one to matter.
 
@@ -854,7 +854,7 @@ def test_parallel_cost_test_of_the_reference(hip_lib, oracle):
     points in [0,10]^3, target = source + (1,2,3), pure translation (x = 0 here since the offset is
     in the data).  The reference asserts |parallel - serial| <= 1e-8 on a sum of ~1.4e7; the
     GPU sum associates differently from the serial loop, so the bound used is 1e-12 relative
-    (the observed distance is printed by scripts/parity_table.py-style runs; it is ~1e-15)."""
+    (the observed distance is printed by tests/tools/parity_table.py-style runs; it is ~1e-15)."""
     rng = np.random.default_rng(70)
     src = rng.uniform(0.0, 10.0, (1_000_000, 3))
     tgt = src + np.array([1.0, 2.0, 3.0])

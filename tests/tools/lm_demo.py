@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """End-to-end Levenberg-Marquardt solve (the caller of the path, levenberg_marquadt_dyn.cpp:34-119)
 over the HIP cost, with and without speculative linearization, next to the CPU restatement.
-    python scripts/lm_demo.py [--n 10000000] [--cpu-n 1000000]"""
+    python tests/tools/lm_demo.py [--n 10000000] [--cpu-n 1000000]"""
 import argparse, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 

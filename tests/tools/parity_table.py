@@ -4,7 +4,7 @@ against the CPU restatement: per Jacobian mode / kernel variant / size, and — 
 differences, whose step is h_j = sqrt(eps) |x_j| (linearization.h:85) — per decade of |x_j|."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import moptimizer_0_amd as mo
 from tests import datasets as ds, oracle_binding as ob
