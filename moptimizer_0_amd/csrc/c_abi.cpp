@@ -875,6 +875,8 @@ int launchPublishedSweep(mopt_cost *c, bool cost_only, int jac_mode, const void 
 int waitPublishedSweep(mopt_cost *c, unsigned long long sequence) {
   return waitPublished(c, sequence);
 }
+mopt::HostPublish nextHostPublish(mopt_cost *c, int offset) { return nextPublish(c, offset); }
+int waitHostPublished(mopt_cost *c, unsigned long long sequence) { return waitPublished(c, sequence); }
 }  // namespace mopt_detail
 
 namespace mopt_detail {

@@ -207,6 +207,9 @@ void releaseCombine(mopt_cost *c);  // combine.cpp: unmaps / closes whatever was
 // c_abi.cpp, for the device-resident LM (lm.cpp): upload the static part of this cost's sweep
 // constants if it changed and describe the cost to the step kernel; enqueue one resident sweep +
 // finalize on `s` (peer-combine sequence numbers = base_sequence + trials counted on the device)
+// c_abi.cpp: the next (host_result, flag, sequence) of this cost's mapped host block, and the wait
+mopt::HostPublish nextHostPublish(mopt_cost *c, int offset);
+int waitHostPublished(mopt_cost *c, unsigned long long sequence);
 int residentPrepare(mopt_cost *c, int jac_mode, hipStream_t s, mopt::LmCostDesc *desc);
 // `step` non-NULL: this is the last cost of the problem, its finalize kernel also runs the LM step
 int residentSweep(mopt_cost *c, int jac_mode, mopt::LmControl *control, hipStream_t s,

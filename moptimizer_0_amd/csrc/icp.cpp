@@ -52,6 +52,7 @@ int buildIcpGrid(const S *src, long long n, const S *tgt, long long m, double ma
   IcpMatcher &g = *out_matcher;
   MOPT_HIP_TRY(deviceAlloc(reinterpret_cast<void **>(&g.d_cell_start), size_t(ncells + 1) * sizeof(int)));
   MOPT_HIP_TRY(deviceAlloc(reinterpret_cast<void **>(&g.d_matched), 64));
+  MOPT_HIP_TRY(hipMemsetAsync(g.d_matched, 0, 64, s));  // every search leaves it at zero again
   MOPT_HIP_TRY(d_perm_t.alloc(size_t(m) * sizeof(int)));
   MOPT_HIP_TRY(mopt::icpSortByCell<S>(d_tgt.as<S>(), m, g.origin, g.cell, g.dims, d_perm_t.as<int>(),
                                       g.d_cell_start, s));
@@ -94,16 +95,19 @@ int icpUpdate(mopt_cost *c, const S *x, int64_t *num_matched) {
   a.max_dist2 = S(mt.max_dist * mt.max_dist);
   const auto T = moptimizer::so3::rigidFrom6DOF<S>(x);
   std::memcpy(a.T, T.m, sizeof T.m);
-  a.matched = num_matched ? mt.d_matched : nullptr;
-  if (num_matched) MOPT_HIP_TRY(hipMemsetAsync(mt.d_matched, 0, sizeof(unsigned int), c->stream));
+  a.matched = num_matched ? mt.d_matched : nullptr;  // zero between searches (publishCounterKernel)
   MOPT_HIP_TRY(mopt::launchIcpMatch<S>(a, c->stream));
   c->cache.valid = false;
   c->state_version += 1;
   if (num_matched) {
-    unsigned int n = 0;
-    MOPT_HIP_TRY(hipMemcpyAsync(&n, mt.d_matched, sizeof n, hipMemcpyDeviceToHost, c->stream));
-    MOPT_HIP_TRY(hipStreamSynchronize(c->stream));
-    *num_matched = int64_t(n);
+    // the count comes back like a sweep result: a one-wave kernel stores it into mapped host
+    // memory and releases a sequence word — no memset, no copy, no stream synchronisation
+    const int slot = mopt_detail::kResultSlots - 1;  // beyond any n*n + n + 1 <= 73
+    const mopt::HostPublish pub = nextHostPublish(c, slot);
+    MOPT_HIP_TRY(mopt::launchPublishCounter(mt.d_matched, pub, c->stream));
+    const int rc = waitHostPublished(c, pub.sequence);
+    if (rc != MOPT_OK) return rc;
+    *num_matched = int64_t(c->h_result[slot]);
   }
   return MOPT_OK;
 }

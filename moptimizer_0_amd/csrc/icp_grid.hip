@@ -6,7 +6,7 @@
 // Everything O(points) runs on the device; the host only picks the grid resolution from the six
 // bounding-box numbers.  The sort is a least-significant-digit radix sort written here for wave64
 // (8-bit digits, as many passes as the cell count needs: 2-3 in practice): per pass a per-workgroup
-// digit histogram, one exclusive scan over the (digit, workgroup) table, and a scatter in which
+// digit histogram, an exclusive scan over the (digit, workgroup) table, and a scatter in which
 // every wavefront ranks its 64 keys among equal digits with eight ballots — no atomics on the
 // output, so the sort is stable: inside a cell the points keep their original order, which is the
 // tie-break rule the search documents.  (The reference has no correspondence search to follow -
@@ -110,29 +110,68 @@ __global__ __launch_bounds__(kBlockThreads) void radixHistogramKernel(
   hist[(size_t)threadIdx.x * num_groups + blockIdx.x] = h[threadIdx.x];
 }
 
-// In-place exclusive scan of `length` counters by one workgroup of 1024 threads: in the
-// digit-major table the result is the first output slot of every (digit, workgroup).
-__global__ __launch_bounds__(1024) void exclusiveScanKernel(unsigned int *data, long long length) {
-  __shared__ unsigned int part[1024];
-  const long long chunk = (length + 1023) / 1024;
-  const long long lo = (long long)threadIdx.x * chunk;
-  const long long hi = lo + chunk < length ? lo + chunk : length;
-  unsigned int sum = 0;
-  for (long long i = lo; i < hi; ++i) sum += data[i];
-  part[threadIdx.x] = sum;
+// In-place exclusive scan of `length` counters: in the digit-major table the result is the first
+// output slot of every (digit, workgroup).  Three coalesced steps — every workgroup scans its own
+// 1024 counters (16-byte loads, four per thread) and leaves their total; one workgroup scans the
+// totals; every counter then takes its workgroup's offset.  (A single workgroup walking the whole
+// table, thread by thread in strided chunks, took 0.33 ms per pass at 1 M points and 0.8 ms at 4 M.)
+constexpr int kScanPerThread = 4;
+constexpr int kScanTile = kBlockThreads * kScanPerThread;
+
+__device__ __forceinline__ unsigned int blockExclusiveScan(unsigned int value, unsigned int *total) {
+  __shared__ unsigned int part[kBlockThreads];
+  part[threadIdx.x] = value;
   __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele over the 1024 chunk sums
+  for (int off = 1; off < kBlockThreads; off <<= 1) {  // Hillis-Steele, inclusive
     const unsigned int add = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0u;
     __syncthreads();
     part[threadIdx.x] += add;
     __syncthreads();
   }
-  unsigned int run = threadIdx.x == 0 ? 0u : part[threadIdx.x - 1];
-  for (long long i = lo; i < hi; ++i) {
-    const unsigned int v = data[i];
-    data[i] = run;
+  *total = part[kBlockThreads - 1];
+  return part[threadIdx.x] - value;
+}
+
+__global__ __launch_bounds__(kBlockThreads) void scanTilesKernel(unsigned int *data, long long length,
+                                                                 unsigned int *tile_totals) {
+  const long long base = (long long)blockIdx.x * kScanTile + threadIdx.x * kScanPerThread;
+  unsigned int v[kScanPerThread];
+#pragma unroll
+  for (int k = 0; k < kScanPerThread; ++k) v[k] = base + k < length ? data[base + k] : 0u;
+  const unsigned int mine = (v[0] + v[1]) + (v[2] + v[3]);
+  unsigned int total;
+  unsigned int run = blockExclusiveScan(mine, &total);
+#pragma unroll
+  for (int k = 0; k < kScanPerThread; ++k) {
+    if (base + k < length) data[base + k] = run;
+    run += v[k];
+  }
+  if (threadIdx.x == 0) tile_totals[blockIdx.x] = total;
+}
+
+// exclusive scan of the tile totals by one workgroup (chunked: any number of tiles)
+__global__ __launch_bounds__(kBlockThreads) void scanTotalsKernel(unsigned int *totals, int count) {
+  const int chunk = (count + kBlockThreads - 1) / kBlockThreads;
+  const int lo = threadIdx.x * chunk;
+  const int hi = lo + chunk < count ? lo + chunk : count;
+  unsigned int sum = 0;
+  for (int i = lo; i < hi; ++i) sum += totals[i];
+  unsigned int all;
+  unsigned int run = blockExclusiveScan(sum, &all);
+  for (int i = lo; i < hi; ++i) {
+    const unsigned int v = totals[i];
+    totals[i] = run;
     run += v;
   }
+}
+
+__global__ __launch_bounds__(kBlockThreads) void addTileOffsetsKernel(
+    unsigned int *data, long long length, const unsigned int *tile_offsets) {
+  const unsigned int offset = tile_offsets[blockIdx.x];
+  const long long base = (long long)blockIdx.x * kScanTile + threadIdx.x * kScanPerThread;
+#pragma unroll
+  for (int k = 0; k < kScanPerThread; ++k)
+    if (base + k < length) data[base + k] += offset;
 }
 
 // values_in == nullptr: the value of key i is i (first pass).
@@ -262,20 +301,25 @@ hipError_t icpSortByCell(const S *d_xyz, long long m, const double origin[3], do
   int bits = 1;
   while ((1ll << bits) < ncells) ++bits;
   const int passes = (bits + 7) / 8;
-  unsigned int *keys = nullptr, *keys_alt = nullptr, *hist = nullptr;
+  const long long table = (long long)kDigits * num_groups;  // (digit, workgroup) counters
+  const int scan_tiles = int((table + kScanTile - 1) / kScanTile);
+  unsigned int *keys = nullptr, *keys_alt = nullptr, *hist = nullptr, *tile_totals = nullptr;
   int *values_alt = nullptr;
   auto release = [&]() {
     if (keys) (void)hipFree(keys);
     if (keys_alt) (void)hipFree(keys_alt);
     if (values_alt) (void)hipFree(values_alt);
     if (hist) (void)hipFree(hist);
+    if (tile_totals) (void)hipFree(tile_totals);
   };
   hipError_t e = hipMalloc(reinterpret_cast<void **>(&keys), size_t(m) * sizeof(unsigned int));
   if (e == hipSuccess)
     e = hipMalloc(reinterpret_cast<void **>(&keys_alt), size_t(m) * sizeof(unsigned int));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&values_alt), size_t(m) * sizeof(int));
   if (e == hipSuccess)
-    e = hipMalloc(reinterpret_cast<void **>(&hist), size_t(kDigits) * num_groups * sizeof(unsigned int));
+    e = hipMalloc(reinterpret_cast<void **>(&hist), size_t(table) * sizeof(unsigned int));
+  if (e == hipSuccess)
+    e = hipMalloc(reinterpret_cast<void **>(&tile_totals), size_t(scan_tiles) * sizeof(unsigned int));
   if (e != hipSuccess) {
     release();
     return e;
@@ -290,8 +334,12 @@ hipError_t icpSortByCell(const S *d_xyz, long long m, const double origin[3], do
     int *values_out = ((passes - 1 - p) % 2 == 0) ? d_perm : values_alt;
     hipLaunchKernelGGL(radixHistogramKernel, dim3(num_groups), dim3(kBlockThreads), 0, stream,
                        keys_in, m, 8 * p, hist, num_groups);
-    hipLaunchKernelGGL(exclusiveScanKernel, dim3(1), dim3(1024), 0, stream, hist,
-                       (long long)kDigits * num_groups);
+    hipLaunchKernelGGL(scanTilesKernel, dim3(scan_tiles), dim3(kBlockThreads), 0, stream, hist,
+                       table, tile_totals);
+    hipLaunchKernelGGL(scanTotalsKernel, dim3(1), dim3(kBlockThreads), 0, stream, tile_totals,
+                       scan_tiles);
+    hipLaunchKernelGGL(addTileOffsetsKernel, dim3(scan_tiles), dim3(kBlockThreads), 0, stream, hist,
+                       table, tile_totals);
     hipLaunchKernelGGL(radixScatterKernel, dim3(num_groups), dim3(kBlockThreads), 0, stream, keys_in,
                        values_in, m, 8 * p, hist, num_groups, keys_out, values_out);
     values_in = values_out;

@@ -320,6 +320,8 @@ template <typename S>
 hipError_t icpGatherPoints(const S *d_xyz, const int *d_perm, long long m, S *d_out, bool padded,
                            hipStream_t stream);
 
+// *d_counter -> mapped host memory (as one double) + flag; the counter is left at zero
+hipError_t launchPublishCounter(unsigned int *d_counter, const HostPublish &pub, hipStream_t stream);
 // device result (count doubles) -> mapped host memory + flag (after a collective)
 hipError_t launchPublish(const double *d_values, int count, const HostPublish &pub,
                          hipStream_t stream);

@@ -1483,6 +1483,22 @@ hipError_t launchGatherTargets(const S *tiles, long long count, S *out_xyz, hipS
 template hipError_t launchGatherTargets<float>(const float *, long long, float *, hipStream_t);
 template hipError_t launchGatherTargets<double>(const double *, long long, double *, hipStream_t);
 
+// matched-source counter of the correspondence search -> mapped host memory (as a double), and
+// back to zero for the next search: no memset launch, no copy, no stream synchronisation
+__global__ void publishCounterKernel(unsigned int *counter, const HostPublish pub) {
+  double v = 0.0;
+  if (threadIdx.x == 0) {
+    v = double(*counter);
+    *counter = 0u;
+  }
+  publishToHost(pub, 1, v);
+}
+
+hipError_t launchPublishCounter(unsigned int *d_counter, const HostPublish &pub, hipStream_t stream) {
+  hipLaunchKernelGGL(publishCounterKernel, dim3(1), dim3(64), 0, stream, d_counter, pub);
+  return hipGetLastError();
+}
+
 hipError_t launchPublish(const double *d_values, int count, const HostPublish &pub,
                          hipStream_t stream) {
   if (count < 0 || count > kMaxAccumulators) return hipErrorInvalidValue;
