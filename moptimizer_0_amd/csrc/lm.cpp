@@ -72,6 +72,28 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
     if (report_out) *report_out = rep;
     return MOPT_OK;
   }
+  if (opt.lm_max_iterations == 0) {
+    // no trial point is ever formed (:77): every outer iteration linearizes at the same x0, finds
+    // the same cost, and the loop runs into its limit — unless that cost is already ~0 (:62-64)
+    double y0 = 0.0;
+    for (int k = 0; k < num_costs; ++k) {
+      double hb[mopt_detail::kResultSlots];
+      double yk = 0.0;
+      float yf = 0.f;
+      const int rck = mopt_cost_linearize(costs[k], jacobian_modes[k], x, hb, hb + 64,
+                                          lead->scalar_bytes == 8 ? static_cast<void *>(&yk)
+                                                                  : static_cast<void *>(&yf));
+      if (rck != MOPT_OK) return rck;
+      y0 += lead->scalar_bytes == 8 ? yk : double(yf);
+    }
+    const double eps = lead->scalar_bytes == 8 ? 2.220446049250313e-16 : 1.1920929e-7;
+    rep.status = std::fabs(y0) < 8.0 * eps ? MOPT_LM_CONVERGED : MOPT_LM_MAXIMUM_ITERATIONS_REACHED;
+    rep.iterations = rep.status == MOPT_LM_CONVERGED ? 0 : opt.max_iterations;
+    rep.sweeps = 1;
+    rep.cost = y0;
+    if (report_out) *report_out = rep;
+    return MOPT_OK;
+  }
   MOPT_HIP_TRY(hipSetDevice(lead->device));
   int rc = ensureWorkspace(lead);
   if (rc != MOPT_OK) return rc;
