@@ -71,3 +71,25 @@ def test_argument_validation_without_device():
     assert rc == 1 and b"scalar_bytes" in lib.mopt_last_error()
     assert lib.mopt_cost_set_loss(None, 0, 0.0) == 1
     assert lib.mopt_cost_linearize(None, 0, None, None, None, None) == 1
+
+
+def test_round2_entry_points_validate_their_arguments_without_a_device():
+    """The additive entry points (shard combines, device-resident LM, SE(3) helpers) refuse bad
+    arguments with an error code and a message — no device is needed to find that out."""
+    import moptimizer_0_amd as mo
+    lib = mo.capi.load()
+    assert lib.mopt_lm_minimize(None, 0, None, None, None, None) == 1
+    assert lib.mopt_cost_hostcomm_attach(None, b"/x", 0, 1) == 1
+    assert lib.mopt_cost_peer_export(None, 2, None) == 1
+    assert lib.mopt_cost_peer_attach(None, None, 0, 2) == 1
+    assert lib.mopt_cost_set_combine(None, 0) == 1
+    assert lib.mopt_hostcomm_unlink(None) == 1
+    assert lib.mopt_se3_plus(3, None, None, None) == 1
+    x = np.array([0.1, 0.2, 0.3, 0.0, 0.0, 0.0])
+    out = mo.capi.se3_plus(x, np.array([1.0, 2.0, 3.0, 0.0, 0.0, 0.0]))  # pure translation adds
+    assert np.allclose(out, [1.1, 2.2, 3.3, 0, 0, 0], atol=1e-15)
+    names = declared_functions()
+    for required in ("mopt_lm_minimize", "mopt_cost_hostcomm_attach", "mopt_cost_peer_export",
+                     "mopt_cost_peer_attach", "mopt_cost_set_combine", "mopt_se3_plus",
+                     "mopt_se3_from_params"):
+        assert required in names
