@@ -42,6 +42,32 @@ def main():
     usable = attach_combines(cost, rank, world, want=want, log=notes.append)
     res = {"usable": np.array(usable), "notes": np.array(notes)}
     modes = {"host": mo.COMBINE_HOST, "peer": mo.COMBINE_PEER, "rccl": mo.COMBINE_RCCL}
+    if os.environ.get("MOPT_TEST_ABSENT"):
+        # a rank that never delivers: the others' waits — on the host for the host slots, inside
+        # the finalize kernel for the peer slots — must END (MOPT_PEER_TIMEOUT_MS) with an error,
+        # not hang the caller or the GPU
+        import time
+        for name in ("host", "peer"):
+            cost.set_combine(modes[name])
+            if rank == 0:
+                t0 = time.perf_counter()
+                try:
+                    cost.linearize(ds.X_GENERIC, mo.JAC_ANALYTIC)
+                    res[name + "_absent"] = np.array([0.0, 0.0])
+                except mo.MoptError as e:
+                    res[name + "_absent"] = np.array([1.0 if "error 6" in str(e) else -1.0,
+                                                      time.perf_counter() - t0])
+            dist.barrier()
+            # the sequence numbers of this transport are out of step from here on: not used again
+        # the cost itself still works on its own
+        cost.set_combine(mo.COMBINE_NONE)
+        H, b, s = cost.linearize(ds.X_GENERIC, mo.JAC_ANALYTIC)
+        res["alone_after_timeout"] = np.array([s])
+        np.savez(os.path.join(out, "rank%d.npz" % rank), **res)
+        dist.barrier()
+        cost.close()
+        dist.destroy_process_group()
+        return
     xs = [ds.X_ZERO, ds.X_GENERIC, ds.X_GENERIC * 0.3]
     for name in usable:
         cost.set_combine(modes[name])

@@ -81,6 +81,18 @@ def test_handoffs_hold_under_uneven_load(hip_lib, tmp_path):
             assert bad.size == 0, (name, r, bad[:5], got[bad[0][0]][:3], want[bad[0][0]][:3])
 
 
+def test_a_rank_that_never_delivers_is_an_error_not_a_hang(hip_lib, tmp_path):
+    """Rank 1 attaches and then stays away: rank 0's blocking linearize returns
+    MOPT_ERR_PEER_TIMEOUT after MOPT_PEER_TIMEOUT_MS — from the host-side wait (host slots) and
+    from the bounded wait inside the finalize kernel (peer slots) — and the cost keeps working."""
+    res = run_ranks(tmp_path, 2, 50_001, extra_env={"MOPT_TEST_ABSENT": "1", "MOPT_PEER_TIMEOUT_MS": "400"})
+    for name in ("host", "peer"):
+        flag, seconds = res[0][name + "_absent"]
+        assert flag == 1.0, (name, flag)            # MoptError with code 6 (MOPT_ERR_PEER_TIMEOUT)
+        assert 0.3 < seconds < 5.0, (name, seconds)  # it waited for the limit, and not much longer
+    assert res[0]["alone_after_timeout"][0] > 0
+
+
 def test_device_resident_lm_over_sharded_cost(hip_lib, tmp_path):
     """mopt_lm_minimize on every rank with MOPT_COMBINE_PEER: all ranks return the same x, bit for
     bit, and it is the solution of the unsharded problem."""
