@@ -489,6 +489,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
+            "traffic_bytes": traffic["bytes"] if traffic else None,
             "kernel_ms": kernel_ms,
             "kernel_launches_timed": launches,
             "kernel_timing": "separate pass after the timed steps; every launch carries its "
