@@ -421,21 +421,10 @@ int scalarSweepAsync(mopt_cost *c, bool cost_only, int jac_mode, const S *x, dou
   return MOPT_OK;
 }
 
-// User-defined (hipRTC) model: same sweep shape as the built-in scalar models, full-form rows.
 template <typename S>
-int jitSweepAsync(mopt_cost *c, bool cost_only, int jac_mode, const S *x, double *d_out,
-                  hipStream_t s, const mopt::HostPublish &pub) {
-  if (!cost_only) {
-    if (jac_mode == MOPT_JAC_ANALYTIC_TST_LAYOUT || jac_mode == MOPT_JAC_ANALYTIC_LEFT)
-      return fail(MOPT_ERR_UNSUPPORTED,
-                  "the as-written layout and the left-perturbation Jacobian apply to point2point only");
-    if (jac_mode == MOPT_JAC_ANALYTIC && !c->jit.has_jacobian)
-      return fail(MOPT_ERR_UNSUPPORTED,
-                  "Non implemented non-jacobian model function `f_df` being used.");
-  }
+void fillJitArgs(const mopt_cost *c, const S *x, mopt::JitArgs<S> &args) {
   mopt::ScalarSweepArgs<S> filled;
   fillScalarArgs<S>(c, x, filled);
-  mopt::JitArgs<S> args;
   args.data = filled.data;
   args.count = filled.count;
   args.stride = filled.stride;
@@ -448,15 +437,35 @@ int jitSweepAsync(mopt_cost *c, bool cost_only, int jac_mode, const S *x, double
   }
   for (int k = 0; k < 16; ++k) args.cov[k] = filled.cov[k];
   args.partials = c->d_partials;
-  const int mode = cost_only ? 0 : (jac_mode == MOPT_JAC_NUMERIC ? 2 : 1);
-  const bool cov_symmetric = c->cov_mode != mopt::kCovGeneral;
-  const mopt::JitVariant *variant = mopt::jitVariant(c->jit, mode, cov_symmetric);
-  if (!variant) return fail(MOPT_ERR_INVALID_ARGUMENT, mopt::jitLastError());
+}
+
+int jitGrid(const mopt_cost *c) {
   const long long per_block = (long long)mopt::kBlockThreads * (16 / c->scalar_bytes);
   long long blocks = (c->count + per_block - 1) / per_block;
   if (blocks > c->num_cus * 4) blocks = c->num_cus * 4;
   if (blocks < 1) blocks = 1;
-  const int grid = int(blocks);
+  return int(blocks);
+}
+
+// User-defined (hipRTC) model: same sweep shape as the built-in scalar models, full-form rows.
+template <typename S>
+int jitSweepAsync(mopt_cost *c, bool cost_only, int jac_mode, const S *x, double *d_out,
+                  hipStream_t s, const mopt::HostPublish &pub) {
+  if (!cost_only) {
+    if (jac_mode == MOPT_JAC_ANALYTIC_TST_LAYOUT || jac_mode == MOPT_JAC_ANALYTIC_LEFT)
+      return fail(MOPT_ERR_UNSUPPORTED,
+                  "the as-written layout and the left-perturbation Jacobian apply to point2point only");
+    if (jac_mode == MOPT_JAC_ANALYTIC && !c->jit.has_jacobian)
+      return fail(MOPT_ERR_UNSUPPORTED,
+                  "Non implemented non-jacobian model function `f_df` being used.");
+  }
+  mopt::JitArgs<S> args;
+  fillJitArgs<S>(c, x, args);
+  const int mode = cost_only ? 0 : (jac_mode == MOPT_JAC_NUMERIC ? 2 : 1);
+  const bool cov_symmetric = c->cov_mode != mopt::kCovGeneral;
+  const mopt::JitVariant *variant = mopt::jitVariant(c->jit, mode, cov_symmetric);
+  if (!variant) return fail(MOPT_ERR_INVALID_ARGUMENT, mopt::jitLastError());
+  const int grid = jitGrid(c);
   const int n = c->n_params;
   SweepTimer timer(c, s);
   MOPT_HIP_TRY(mopt::jitLaunch(*variant, &args, sizeof args, grid, s));
@@ -733,6 +742,8 @@ int residentPrepare(mopt_cost *c, int jac_mode, hipStream_t s, mopt::LmCostDesc 
         return fail(MOPT_ERR_UNSUPPORTED,
                     "Non implemented non-jacobian model function `f_df` being used.");
       desc->model = mopt::kLmScalar;
+      desc->x_offset = c->scalar_bytes == 8 ? int(offsetof(mopt::ScalarSweepArgs<double>, x))
+                                            : int(offsetof(mopt::ScalarSweepArgs<float>, x));
       if (stale) {
         if (c->scalar_bytes == 8) {
           mopt::ScalarSweepArgs<double> args;
@@ -748,9 +759,37 @@ int residentPrepare(mopt_cost *c, int jac_mode, hipStream_t s, mopt::LmCostDesc 
       }
       break;
     }
+    case kModelJit: {
+      if (jac_mode == MOPT_JAC_ANALYTIC_TST_LAYOUT || jac_mode == MOPT_JAC_ANALYTIC_LEFT)
+        return fail(MOPT_ERR_UNSUPPORTED,
+                    "the as-written layout and the left-perturbation Jacobian apply to point2point only");
+      if (jac_mode == MOPT_JAC_ANALYTIC && !c->jit.has_jacobian)
+        return fail(MOPT_ERR_UNSUPPORTED,
+                    "Non implemented non-jacobian model function `f_df` being used.");
+      // compile (first use) before anything is queued: a source error must surface here
+      if (!mopt::jitVariant(c->jit, jac_mode == MOPT_JAC_NUMERIC ? 2 : 1,
+                            c->cov_mode != mopt::kCovGeneral))
+        return fail(MOPT_ERR_INVALID_ARGUMENT, mopt::jitLastError());
+      desc->model = mopt::kLmJit;
+      desc->x_offset = c->scalar_bytes == 8 ? int(offsetof(mopt::JitArgs<double>, x))
+                                            : int(offsetof(mopt::JitArgs<float>, x));
+      if (stale) {
+        if (c->scalar_bytes == 8) {
+          mopt::JitArgs<double> args;
+          const double zero[mopt::kMaxParams] = {0};
+          fillJitArgs<double>(c, zero, args);
+          rc = uploadArgs(c, args, s);
+        } else {
+          mopt::JitArgs<float> args;
+          const float zero[mopt::kMaxParams] = {0};
+          fillJitArgs<float>(c, zero, args);
+          rc = uploadArgs(c, args, s);
+        }
+      }
+      break;
+    }
     default:
-      return fail(MOPT_ERR_UNSUPPORTED,
-                  "mopt_lm_minimize: run-time compiled models are driven by the host LM loop");
+      return fail(MOPT_ERR_UNSUPPORTED, "mopt_lm_minimize: unknown model kind");
   }
   if (rc != MOPT_OK) return rc;
   c->lm_uploaded_version = c->state_version;
@@ -835,6 +874,19 @@ int residentSweep(mopt_cost *c, int jac_mode, mopt::LmControl *control, hipStrea
         MOPT_HIP_TRY(mopt::launchScalarModelResident<float>(
             static_cast<const mopt::ScalarSweepArgs<float> *>(c->d_lm_args), control,
             c->scalar_model, jac_mode, c->cov_mode, grid, s));
+      MOPT_HIP_TRY(mopt::launchFinalizeDenseResident(c->d_partials, grid, nacc, n, c->d_result,
+                                                     control, s, peers, step, own_index,
+                                                     c->scalar_bytes));
+      return MOPT_OK;
+    }
+    case kModelJit: {
+      const bool cov_symmetric = c->cov_mode != mopt::kCovGeneral;
+      const mopt::JitVariant *variant =
+          mopt::jitVariant(c->jit, jac_mode == MOPT_JAC_NUMERIC ? 2 : 1, cov_symmetric);
+      if (!variant) return fail(MOPT_ERR_INVALID_ARGUMENT, mopt::jitLastError());
+      const int grid = jitGrid(c);
+      const int nacc = cov_symmetric ? n * (n + 1) / 2 + n + 1 : n * n + n + 1;
+      MOPT_HIP_TRY(mopt::jitLaunchResident(*variant, c->d_lm_args, control, grid, s));
       MOPT_HIP_TRY(mopt::launchFinalizeDenseResident(c->d_partials, grid, nacc, n, c->d_result,
                                                      control, s, peers, step, own_index,
                                                      c->scalar_bytes));

@@ -96,7 +96,7 @@ __device__ inline void block_reduce_store(double (&acc)[NACC], double *out_row) 
   }
 }
 
-extern "C" __global__ __launch_bounds__(kBlock) void mopt_jit_sweep(const JitArgs A) {
+__device__ inline void sweep_body(const JitArgs &A) {
   // IBaseModel::setup (model.h:19-22): once per parameter vector, here once per workgroup and
   // parameter vector - x itself and, for forward differences, x + h_j e_j (the reference sets
   // up one clone of the model per perturbed vector, linearization.h:91-95).
@@ -219,6 +219,21 @@ extern "C" __global__ __launch_bounds__(kBlock) void mopt_jit_sweep(const JitArg
   }
   block_reduce_store(acc, A.partials + (size_t)blockIdx.x * NACC);
 }
+
+extern "C" __global__ __launch_bounds__(kBlock) void mopt_jit_sweep(const JitArgs A) { sweep_body(A); }
+
+// Resident form for the device-resident LM (mopt_lm_minimize): the argument block — x and the
+// forward-difference steps in it rewritten by the LM step kernel for every trial point — is read
+// from HBM, and a launch queued past the end of the minimisation returns at once.
+struct LmControl {
+  int done, trial, pad[2];
+};
+extern "C" __global__ __launch_bounds__(kBlock) void mopt_jit_sweep_resident(
+    const JitArgs *__restrict__ d_args, const LmControl *__restrict__ control) {
+  if (control->done) return;
+  const JitArgs A = *d_args;
+  sweep_body(A);
+}
 )JIT";
 
 std::string &jitError() {
@@ -267,10 +282,12 @@ bool compileVariant(JitKernel &k, int mode, bool cov_symmetric, JitVariant &out)
     jitError() = "hipModuleLoadData failed for the compiled model";
     return false;
   }
-  if (hipModuleGetFunction(&out.sweep, out.module, "mopt_jit_sweep") != hipSuccess) {
+  if (hipModuleGetFunction(&out.sweep, out.module, "mopt_jit_sweep") != hipSuccess ||
+      hipModuleGetFunction(&out.sweep_resident, out.module, "mopt_jit_sweep_resident") != hipSuccess) {
     jitError() = "compiled model has no mopt_jit_sweep";
     (void)hipModuleUnload(out.module);
     out.module = nullptr;
+    out.sweep = out.sweep_resident = nullptr;
     return false;
   }
   return true;
@@ -322,7 +339,7 @@ void jitRelease(JitKernel &k) {
   for (auto &v : k.variants) {
     if (v.module) (void)hipModuleUnload(v.module);
     v.module = nullptr;
-    v.sweep = nullptr;
+    v.sweep = v.sweep_resident = nullptr;
   }
 }
 
@@ -333,6 +350,19 @@ hipError_t jitLaunch(const JitVariant &v, const void *args, size_t args_bytes, i
                     HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
   return hipModuleLaunchKernel(v.sweep, unsigned(grid), 1, 1, kBlockThreads, 1, 1, 0, stream, nullptr,
                                config);
+}
+
+hipError_t jitLaunchResident(const JitVariant &v, const void *d_args, const LmControl *control,
+                             int grid, hipStream_t stream) {
+  struct {
+    const void *args;
+    const LmControl *control;
+  } params = {d_args, control};
+  size_t size = sizeof params;
+  void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &params, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size,
+                    HIP_LAUNCH_PARAM_END};
+  return hipModuleLaunchKernel(v.sweep_resident, unsigned(grid), 1, 1, kBlockThreads, 1, 1, 0, stream,
+                               nullptr, config);
 }
 
 }  // namespace mopt

@@ -12,6 +12,7 @@ namespace mopt {
 struct JitVariant {
   hipModule_t module = nullptr;
   hipFunction_t sweep = nullptr;
+  hipFunction_t sweep_resident = nullptr;  // arguments from HBM, early exit (device-resident LM)
 };
 
 // One user model: its assembled source and the sweeps compiled from it so far.
@@ -48,6 +49,9 @@ const JitVariant *jitVariant(JitKernel &k, int mode, bool cov_symmetric);
 void jitRelease(JitKernel &k);
 hipError_t jitLaunch(const JitVariant &v, const void *args, size_t args_bytes, int grid,
                      hipStream_t stream);
+// the resident entry point of the same module: (const JitArgs *d_args, const LmControl *control)
+hipError_t jitLaunchResident(const JitVariant &v, const void *d_args, const LmControl *control,
+                             int grid, hipStream_t stream);
 const char *jitLastError();
 
 }  // namespace mopt

@@ -376,12 +376,13 @@ __device__ void writeSweepConstants(const LmProblem &P, const S *x) {
         }
       }
       __syncthreads();
-    } else {  // scalar models: the sweep differentiates by itself, it needs x and the steps
-      ScalarSweepArgs<S> *a = static_cast<ScalarSweepArgs<S> *>(d.args);
+    } else {  // scalar / run-time compiled models: the sweep differentiates (and runs the user's
+              // setup) by itself, it needs x and the steps; d.x_offset locates them in the block
+      S *xs = reinterpret_cast<S *>(static_cast<char *>(d.args) + d.x_offset);
       if (tid < kMaxParams) {
         const S xv = tid < P.n ? x[tid] : S(0);
-        a->x[tid] = xv;
-        a->h[tid] = forwardStep<S>(xv);
+        xs[tid] = xv;
+        xs[kMaxParams + tid] = forwardStep<S>(xv);  // h[] follows x[] in both argument layouts
       }
     }
   }

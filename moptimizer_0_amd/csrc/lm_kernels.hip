@@ -12,6 +12,7 @@
 //
 // Serial logic runs on lane 0 in the reference's order of operations with multiply-add fusion off;
 // the seven transforms of a cost are formed by seven lanes.
+#include "jit_model.hpp"
 #include "lm_device.hpp"
 
 namespace mopt {
@@ -60,5 +61,9 @@ template hipError_t launchStoreArgs<ScalarSweepArgs<double>>(const ScalarSweepAr
                                                              ScalarSweepArgs<double> *,
                                                              hipStream_t);
 template hipError_t launchStoreArgs<AffineBasis>(const AffineBasis &, AffineBasis *, hipStream_t);
+template hipError_t launchStoreArgs<JitArgs<float>>(const JitArgs<float> &, JitArgs<float> *,
+                                                    hipStream_t);
+template hipError_t launchStoreArgs<JitArgs<double>>(const JitArgs<double> &, JitArgs<double> *,
+                                                     hipStream_t);
 
 }  // namespace mopt

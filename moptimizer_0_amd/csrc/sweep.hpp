@@ -170,7 +170,7 @@ struct PeerCombine {
 // finalize kernels read them — so sweeps can be queued ahead of time and the host only sees the
 // final x.  A queued kernel that finds `done` set returns at once.
 constexpr int kLmMaxCosts = 4;
-enum LmModel : int { kLmPoint2Point = 1, kLmReprojection = 2, kLmScalar = 3 };
+enum LmModel : int { kLmPoint2Point = 1, kLmReprojection = 2, kLmScalar = 3, kLmJit = 4 };
 // values of moptimizer::OptimizationStatus (include/moptimizer/types.h:6-12)
 enum LmStatus : int {
   kLmConverged = 0,
@@ -192,6 +192,8 @@ struct LmCostDesc {
   int jac_mode = 0;  // JacMode
   int n_out = 0;
   int moments = 0;   // point2point: the finalize kernel contracts moments with `basis`
+  int x_offset = 0;  // scalar / run-time compiled models: byte offset of x[8] | h[8] inside `args`
+  int pad = 0;
   void *args = nullptr;           // device: P2PSweepArgs<S> / ReprojSweepArgs / ScalarSweepArgs<S>
   AffineBasis *basis = nullptr;   // device, point2point moments
   const double *result = nullptr; // device: this cost's H | b | sum_sq (summed over the ranks)

@@ -233,3 +233,47 @@ def test_manifold_update_on_the_device(hip_lib, oracle):
     xe, repe = mo.capi.lm_minimize([cost], [mo.JAC_ANALYTIC], x0, max_iterations=200)
     assert repe["iterations"] > 2 * rep["iterations"], (repe, rep)
     cost.close()
+
+
+def test_run_time_compiled_models_under_the_device_loop(hip_lib, oracle):
+    """User-written models (mopt_jit_model_create) in mopt_lm_minimize: the curve fit of
+    tst/curve_fitting.cpp:101-147 written as source reaches the reference's known answer, and the
+    path's own point2point model written as source gives the iterates of the built-in one."""
+    mo = hip_lib
+    from tests.test_gpu_parity import P2P_JIT_JACOBIAN, P2P_JIT_RESIDUAL, P2P_JIT_SETUP
+    curve = np.load(ds.GOLDEN + "/p2p_1k_golden.npz")  # (only to make sure the fixture dir exists)
+    del curve
+    rng = np.random.default_rng(0)
+    t = np.linspace(0.0, 4.95, 67)
+    y = np.exp(0.3 * t + 0.1) + rng.normal(0, 0.2, t.shape)
+    jit = mo.JitModelCost(2, 1, "r[0] = d[1] - exp(x[0] * d[0] + x[1]);",
+                          "const S e = exp(x[0] * d[0] + x[1]); J[0] = -d[0] * e; J[1] = -e;",
+                          planes=np.stack([t, y]))
+    builtin = mo.ScalarModelCost(mo.capi.MODEL_EXP_CURVE, t, y)
+    for jac in (mo.JAC_NUMERIC, mo.JAC_ANALYTIC):
+        xj, rj = mo.capi.lm_minimize([jit], [jac], np.zeros(2), max_iterations=50)
+        xh, sh, ih = host_lm_n(jit, jac, np.zeros(2), 50)
+        assert rj["status"] == sh and abs(rj["iterations"] - ih) <= 1, (rj, sh, ih)
+        assert np.abs(xj - xh).max() < 1e-6
+        assert np.abs(xj - np.array([0.3, 0.1])).max() < 0.1  # near the generating parameters
+    xb, rb = mo.capi.lm_minimize([builtin], [mo.JAC_NUMERIC], np.zeros(2), max_iterations=50)
+    xj, rj = mo.capi.lm_minimize([jit], [mo.JAC_NUMERIC], np.zeros(2), max_iterations=50)
+    assert np.abs(xb - xj).max() < 1e-6
+    # point2point as source, analytic Jacobian: same iterates as the hand-written sweep
+    src, tgt = ds.synthetic_pair(30_000, seed=3, noise=0.01)
+    planes = np.concatenate([src.T, tgt.T])
+    p2p_jit = mo.JitModelCost(6, 3, P2P_JIT_RESIDUAL, P2P_JIT_JACOBIAN, planes=planes, n_aux=12,
+                              setup_body=P2P_JIT_SETUP)
+    p2p = mo.Point2PointCost(src, tgt)
+    for k in (1, 3, 15):
+        xa, ra = mo.capi.lm_minimize([p2p_jit], [mo.JAC_ANALYTIC], np.zeros(6), max_iterations=k)
+        xb, rb = mo.capi.lm_minimize([p2p], [mo.JAC_ANALYTIC], np.zeros(6), max_iterations=k)
+        assert (ra["status"], ra["iterations"]) == (rb["status"], rb["iterations"])
+        assert np.abs(xa - xb).max() < 1e-9 * 11
+    for c in (jit, builtin, p2p_jit, p2p):
+        c.close()
+
+
+def host_lm_n(cost, jac_mode, x0, max_iter):
+    """host_lm for any parameter count."""
+    return host_lm(cost, jac_mode, x0, max_iter=max_iter)
