@@ -338,8 +338,10 @@ MOPT_API int mopt_cost_get_combine(const mopt_cost *cost, int *combine_mode, int
  *
  * costs / jacobian_modes: the costs of Optimizer::addCost (optimizer.h:58) with the Jacobian mode
  * of each (the cost class the caller would have used), at most 4, same device / scalar type / n;
- * point2point, reprojection, the built-in scalar models and run-time compiled models (not ICP
- * costs, whose update(x) step is driven from the host).  x: n scalars, in: x0, out: the result.
+ * point2point (also ICP costs: their update(x), the correspondence search, then runs inside the
+ * loop, at the top of every outer iteration as in :54, and an accepted point is searched and
+ * linearized again), reprojection, the built-in scalar models and run-time compiled models.
+ * x: n scalars, in: x0, out: the result.
  * For sharded costs select MOPT_COMBINE_PEER first: every rank then runs the identical loop on
  * bit-identical sums (collective call).
  * report->status takes the values of moptimizer::OptimizationStatus (types.h:6-12). */

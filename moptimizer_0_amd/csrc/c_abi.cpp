@@ -699,10 +699,6 @@ bool usesMoments(const mopt_cost *c) { return c->variant != MOPT_KERNEL_LITERAL;
 int residentPrepare(mopt_cost *c, int jac_mode, hipStream_t s, mopt::LmCostDesc *desc) {
   if (jac_mode < MOPT_JAC_ANALYTIC || jac_mode > MOPT_JAC_ANALYTIC_LEFT)
     return fail(MOPT_ERR_INVALID_ARGUMENT, "unknown jacobian_mode");
-  if (c->matcher)
-    return fail(MOPT_ERR_UNSUPPORTED,
-                "mopt_lm_minimize: an ICP cost re-matches on the host side of update(x); drive it "
-                "with the host LM loop");
   desc->jac_mode = jac_mode;
   desc->n_out = c->n_out;
   desc->moments = 0;
@@ -818,6 +814,21 @@ int residentSweep(mopt_cost *c, int jac_mode, mopt::LmControl *control, hipStrea
   site.stream = s;
   const size_t bytes = size_t(c->count) * 6 * size_t(c->scalar_bytes);
   site.streaming = bytes > (size_t(32) << 20);
+  if (c->matcher) {
+    // the model's update(x): re-search the correspondences at the point the step kernel has just
+    // proposed, when it says so (a linearization point), before that point is swept
+    if (c->scalar_bytes == 8) {
+      mopt::IcpMatchArgs<double> a;
+      fillIcpArgs<double>(c, a);
+      MOPT_HIP_TRY(mopt::launchIcpMatchResident<double>(
+          a, static_cast<const mopt::P2PSweepArgs<double> *>(c->d_lm_args), control, s));
+    } else {
+      mopt::IcpMatchArgs<float> a;
+      fillIcpArgs<float>(c, a);
+      MOPT_HIP_TRY(mopt::launchIcpMatchResident<float>(
+          a, static_cast<const mopt::P2PSweepArgs<float> *>(c->d_lm_args), control, s));
+    }
+  }
   switch (c->model) {
     case kModelPoint2Point: {
       if (usesMoments(c)) {

@@ -216,6 +216,9 @@ int residentSweep(mopt_cost *c, int jac_mode, mopt::LmControl *control, hipStrea
                   unsigned long long base_sequence, const mopt::LmProblem *step = nullptr,
                   int own_index = 0);
 void releaseResident(mopt_cost *c);
+// icp.cpp: the pose-independent part of a correspondence search over this cost's grid
+template <typename S>
+void fillIcpArgs(const mopt_cost *c, mopt::IcpMatchArgs<S> &a);
 void destroyCost(mopt_cost *c);
 // enqueue one linearization / cost sweep + its finalize on `s`; results to d_result (+ optional
 // hand-over to mapped host memory)

@@ -77,10 +77,13 @@ int buildIcpGrid(const S *src, long long n, const S *tgt, long long m, double ma
   return MOPT_OK;
 }
 
+}  // namespace
+
+namespace mopt_detail {
+// everything of a search that does not depend on the pose
 template <typename S>
-int icpUpdate(mopt_cost *c, const S *x, int64_t *num_matched) {
+void fillIcpArgs(const mopt_cost *c, mopt::IcpMatchArgs<S> &a) {
   const IcpMatcher &mt = *c->matcher;
-  mopt::IcpMatchArgs<S> a;
   a.tiles = static_cast<S *>(c->d_tiles);
   a.count = c->count;
   a.num_tiles = c->num_tiles;
@@ -93,6 +96,19 @@ int icpUpdate(mopt_cost *c, const S *x, int64_t *num_matched) {
   a.inv_cell = S(1.0 / mt.cell);
   a.cell = S(mt.cell);
   a.max_dist2 = S(mt.max_dist * mt.max_dist);
+  for (int k = 0; k < 12; ++k) a.T[k] = S(k % 5 == 0 ? 1 : 0);
+  a.matched = nullptr;
+}
+template void fillIcpArgs<float>(const mopt_cost *, mopt::IcpMatchArgs<float> &);
+template void fillIcpArgs<double>(const mopt_cost *, mopt::IcpMatchArgs<double> &);
+}  // namespace mopt_detail
+
+namespace {
+template <typename S>
+int icpUpdate(mopt_cost *c, const S *x, int64_t *num_matched) {
+  const IcpMatcher &mt = *c->matcher;
+  mopt::IcpMatchArgs<S> a;
+  fillIcpArgs<S>(c, a);
   const auto T = moptimizer::so3::rigidFrom6DOF<S>(x);
   std::memcpy(a.T, T.m, sizeof T.m);
   a.matched = num_matched ? mt.d_matched : nullptr;  // zero between searches (publishCounterKernel)

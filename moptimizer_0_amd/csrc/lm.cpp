@@ -112,6 +112,10 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
     rc = residentPrepare(costs[k], jacobian_modes[k], s, &problem.cost[k]);
     if (rc != MOPT_OK) return rc;
     costs[k]->cache.valid = false;
+    if (costs[k]->matcher) {
+      problem.rematch = 1;               // its update(x) runs on the device, inside the loop
+      costs[k]->state_version += 1;      // the correspondences will have changed
+    }
   }
   unsigned long long base_sequence[mopt::kLmMaxCosts];
   for (int k = 0; k < num_costs; ++k) base_sequence[k] = costs[k]->combine.sequence + 1;
@@ -126,8 +130,10 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
   // One sweep per evaluated point: the linearization at x0, then at most lm_max_iterations trial
   // points per outer iteration.  The host stays `window` points ahead of the device; whatever is
   // still queued when the step kernel stops finds control->done set and returns at once.
+  // (with an ICP cost an accepted point is searched and swept again before it is linearized)
   const long long max_points =
-      1 + (long long)opt.max_iterations * (opt.lm_max_iterations > 0 ? opt.lm_max_iterations : 1);
+      1 + (long long)opt.max_iterations *
+              ((opt.lm_max_iterations > 0 ? opt.lm_max_iterations : 1) + (problem.rematch ? 1 : 0));
   static const int default_window = envInt("MOPT_LM_WINDOW", 3);
   const int window = opt.window > 0 ? opt.window : default_window;
   long long enqueued = 0;

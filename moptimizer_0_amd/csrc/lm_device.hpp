@@ -449,7 +449,7 @@ __device__ void lmStepBody(const LmProblem &P, bool init, const LmStart<S> &star
   __syncthreads();
   MOPT_TICK(1);
 
-  __shared__ int adopt_sums;
+  __shared__ int adopt_sums, rematch_next;
   if (tid == 0) {
 #pragma clang fp contract(off)
     // The decision runs on one lane, so what it costs is a chain of dependent operations: the
@@ -460,6 +460,7 @@ __device__ void lmStepBody(const LmProblem &P, bool init, const LmStart<S> &star
     propose = 0;
     finished = 0;
     adopt_sums = 0;
+    rematch_next = init ? P.rematch : 0;
     S x0[kMaxParams], xi[kMaxParams], delta[kMaxParams], bcur[kMaxParams];
 #pragma unroll
     for (int i = 0; i < kMaxParams; ++i) {
@@ -584,9 +585,23 @@ __device__ void lmStepBody(const LmProblem &P, bool init, const LmStart<S> &star
           const double shrink = fmax(1.0 / 3.0, 1.0 - t * t * t);  // :113
           lambda = S(double(lambda) * shrink);
           it += 1;
-          adopt();  // the trial sweep WAS the linearization at the new x0
-          if (it >= P.max_iterations) finish(kLmMaxIterations);
-          else beginOuter();
+          if (it >= P.max_iterations) {
+            adopt();
+            finish(kLmMaxIterations);
+          } else if (P.rematch) {
+            // a cost re-searches its correspondences at the top of the next outer iteration
+            // (cost->update(x0), :54): the sums of this sweep belong to the old ones — search, then
+            // linearize again at the new x0
+            y0 = ys;
+            st.awaiting_x0 = 1;
+            rematch_next = 1;
+#pragma unroll
+            for (int i = 0; i < kMaxParams; ++i) next_x[i] = x0[i];
+            propose = 1;
+          } else {
+            adopt();  // the trial sweep WAS the linearization at the new x0
+            beginOuter();
+          }
         }
       }
     }
@@ -618,11 +633,9 @@ __device__ void lmStepBody(const LmProblem &P, bool init, const LmStart<S> &star
   for (int i = tid; i < kStateWords; i += blockDim.x)
     reinterpret_cast<unsigned int *>(stored)[i] = reinterpret_cast<const unsigned int *>(&st)[i];
   if (tid == 0) {
-    if (init) {
-      ctl->pad[0] = 0;
-      ctl->pad[1] = 0;
-    }
+    if (init) ctl->pad[0] = 0;
     ctl->trial = st.trials;
+    ctl->pad[1] = rematch_next;
     ctl->done = finished;
   }
   MOPT_TICK(3);

@@ -184,8 +184,9 @@ enum LmStatus : int {
 struct LmControl {  // device memory; written by the step kernel only
   int done;         // 0 while iterating; queued sweeps / finalizes return at once when set
   int trial;        // sweeps evaluated so far = offset of the next peer-combine sequence number
-  int pad[2];
-};
+  int pad[2];       // [0]: a peer-combine status (kStatusPeerTimeout) seen by a finalize kernel
+};                  // [1]: the next point is a linearization point whose correspondences are to
+                    //      be re-searched first (ICP costs: the model's update(x))
 
 struct LmCostDesc {
   int model = 0;     // LmModel
@@ -219,7 +220,8 @@ struct LmProblem {
   int max_iterations = 15;    // optimizer.h:19
   int lm_max_iterations = 3;  // levenberg_marquadt_dyn.cpp:9
   int manifold = 0;           // 1: x (+) delta composed on SE(3) instead of added (n = 6 only)
-  int pad = 0;
+  int rematch = 0;            // 1: some cost re-searches its correspondences in update(x): an accepted
+                              //    point is re-linearized after the search instead of adopted
   LmCostDesc cost[kLmMaxCosts];
   LmControl *control = nullptr;  // device
   void *state = nullptr;         // device, LmState<S> (lm_kernels.hip)
@@ -302,6 +304,11 @@ hipError_t launchScalarModel(const ScalarSweepArgs<S> &args, int model, bool cos
 // (NaN marker when there is none).
 template <typename S>
 hipError_t launchIcpMatch(const IcpMatchArgs<S> &args, hipStream_t stream);
+// the same search with the pose read from the cost's resident sweep constants, run only when the LM
+// step kernel asked for it (control->pad[1])
+template <typename S>
+hipError_t launchIcpMatchResident(const IcpMatchArgs<S> &args, const P2PSweepArgs<S> *d_args,
+                                  const LmControl *control, hipStream_t stream);
 // target planes of the tile layout -> packed xyz (NaN where unmatched); for inspection / tests
 template <typename S>
 hipError_t launchGatherTargets(const S *tiles, long long count, S *out_xyz, hipStream_t stream);

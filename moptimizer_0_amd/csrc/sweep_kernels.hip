@@ -785,7 +785,7 @@ __global__ __launch_bounds__(kBlockThreads) void scalarModelResidentKernel(
 // and ships no implementation, so semantics are defined here: exact nearest neighbour in the
 // Euclidean metric, ties resolved to the first candidate in (cell z, y, x; original index) order.
 template <typename S>
-__global__ __launch_bounds__(kBlockThreads) void icpMatchKernel(const IcpMatchArgs<S> A) {
+__device__ __forceinline__ void icpMatchBody(const IcpMatchArgs<S> &A, const S (&T)[12]) {
   constexpr int TP = TileShape<S>::kPoints;
   const long long i = (long long)blockIdx.x * kBlockThreads + threadIdx.x;
   if (i >= (long long)A.num_tiles * TP) return;
@@ -798,7 +798,7 @@ __global__ __launch_bounds__(kBlockThreads) void icpMatchKernel(const IcpMatchAr
     bool inside = true;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      w[a] = ((A.T[a * 4 + 0] * p[0] + A.T[a * 4 + 1] * p[1]) + A.T[a * 4 + 2] * p[2]) + A.T[a * 4 + 3];
+      w[a] = ((T[a * 4 + 0] * p[0] + T[a * 4 + 1] * p[1]) + T[a * 4 + 2] * p[2]) + T[a * 4 + 3];
       g[a] = floor((w[a] - A.origin[a]) * A.inv_cell);
       inside = inside && g[a] >= S(-1) && g[a] <= S(A.dims[a]);
     }
@@ -886,6 +886,26 @@ __global__ __launch_bounds__(kBlockThreads) void icpMatchKernel(const IcpMatchAr
     const int in_block = __syncthreads_count(found ? 1 : 0);
     if (threadIdx.x == 0 && in_block > 0) atomicAdd(A.matched, (unsigned int)in_block);
   }
+}
+
+template <typename S>
+__global__ __launch_bounds__(kBlockThreads) void icpMatchKernel(const IcpMatchArgs<S> A) {
+  icpMatchBody<S>(A, A.T);
+}
+
+// Resident form for the device-resident LM: the pose comes from the cost's sweep constants in HBM
+// (T at the point the step kernel has just proposed), and the search only runs when the step
+// kernel asked for it — the model's update(x) at the top of an outer iteration
+// (levenberg_marquadt_dyn.cpp:54) — or not at all once the loop has stopped.
+template <typename S>
+__global__ __launch_bounds__(kBlockThreads) void icpMatchResidentKernel(
+    const IcpMatchArgs<S> A, const P2PSweepArgs<S> *__restrict__ d_args,
+    const LmControl *__restrict__ control) {
+  if (control->done || !control->pad[1]) return;
+  S T[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) T[k] = d_args->T[0][k];
+  icpMatchBody<S>(A, T);
 }
 
 template <typename S>
@@ -1484,6 +1504,23 @@ hipError_t launchIcpMatch(const IcpMatchArgs<S> &args, hipStream_t stream) {
 }
 template hipError_t launchIcpMatch<float>(const IcpMatchArgs<float> &, hipStream_t);
 template hipError_t launchIcpMatch<double>(const IcpMatchArgs<double> &, hipStream_t);
+
+template <typename S>
+hipError_t launchIcpMatchResident(const IcpMatchArgs<S> &args, const P2PSweepArgs<S> *d_args,
+                                  const LmControl *control, hipStream_t stream) {
+  const long long padded = (long long)args.num_tiles * TileShape<S>::kPoints;
+  if (padded == 0) return hipSuccess;
+  const unsigned blocks = unsigned((padded + kBlockThreads - 1) / kBlockThreads);
+  hipLaunchKernelGGL((icpMatchResidentKernel<S>), dim3(blocks), dim3(kBlockThreads), 0, stream, args,
+                     d_args, control);
+  return hipGetLastError();
+}
+template hipError_t launchIcpMatchResident<float>(const IcpMatchArgs<float> &,
+                                                  const P2PSweepArgs<float> *, const LmControl *,
+                                                  hipStream_t);
+template hipError_t launchIcpMatchResident<double>(const IcpMatchArgs<double> &,
+                                                   const P2PSweepArgs<double> *, const LmControl *,
+                                                   hipStream_t);
 
 template <typename S>
 hipError_t launchGatherTargets(const S *tiles, long long count, S *out_xyz, hipStream_t stream) {

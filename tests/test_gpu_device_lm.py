@@ -30,6 +30,8 @@ def host_lm(cost, jac_mode, x0, max_iter=15, lm_iter=3):
     lam, eps, sweeps = -1.0, np.finfo(np.float64).eps, 0
     it = 0
     while it < max_iter:
+        if hasattr(cost, "update"):
+            cost.update(x, count_matches=False)  # cost->update(x0), levenberg_marquadt_dyn.cpp:54
         H, b, y0 = cost.linearize(x, jac_mode)
         if abs(y0) < 8 * eps:
             return x, CONVERGED, it
@@ -277,3 +279,39 @@ def test_run_time_compiled_models_under_the_device_loop(hip_lib, oracle):
 def host_lm_n(cost, jac_mode, x0, max_iter):
     """host_lm for any parameter count."""
     return host_lm(cost, jac_mode, x0, max_iter=max_iter)
+
+
+def test_icp_cost_with_the_search_inside_the_device_loop(hip_lib):
+    """An ICP cost under mopt_lm_minimize: its update(x) — the nearest-neighbour search — runs on
+    the device at the top of every outer iteration, as the reference's loop calls it
+    (levenberg_marquadt_dyn.cpp:54).  Same status, iteration count and pose as the host loop that
+    calls update / linearize / computeCost through the boundary."""
+    mo = hip_lib
+    rng = np.random.default_rng(4)
+    tgt = rng.random((40_000, 3)) * 20.0
+    x_true = np.array([0.15, -0.1, 0.2, 0.02, -0.03, 0.025])
+    th = np.linalg.norm(x_true[3:])
+    a = x_true[3:] / th
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    R = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+    # sources = targets moved by the inverse pose (+ noise), shuffled: registration must undo it
+    src = (tgt - x_true[:3]) @ R + rng.normal(0, 0.002, tgt.shape)
+    src = src[rng.permutation(len(src))][:30_000]
+    for jac in (mo.JAC_ANALYTIC, mo.JAC_ANALYTIC_LEFT):
+        dev = mo.IcpCost(src, tgt, max_distance=0.6)
+        ref = mo.IcpCost(src, tgt, max_distance=0.6)
+        xd, rep = mo.capi.lm_minimize([dev], [jac], np.zeros(6), max_iterations=40,
+                                      manifold=(jac == mo.JAC_ANALYTIC_LEFT))
+        if jac == mo.JAC_ANALYTIC:
+            xh, sh, ih = host_lm(ref, jac, np.zeros(6), max_iter=40)
+            assert (rep["status"], rep["iterations"]) == (sh, ih), (rep, sh, ih)
+            assert np.abs(xd - xh).max() < 1e-9, (xd, xh)
+            # the correspondences the two loops ended with are the same
+            assert np.array_equal(np.isnan(dev.matches()), np.isnan(ref.matches()))
+            assert np.nanmax(np.abs(dev.matches() - ref.matches())) == 0.0
+        assert np.abs(xd - x_true).max() < 2e-3, (jac, xd)
+        # ... and the blocking calls continue from that state
+        n_matched = dev.update(xd)
+        assert n_matched > 0.95 * len(src)
+        dev.close()
+        ref.close()
