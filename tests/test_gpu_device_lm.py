@@ -297,21 +297,30 @@ def test_icp_cost_with_the_search_inside_the_device_loop(hip_lib):
     # sources = targets moved by the inverse pose (+ noise), shuffled: registration must undo it
     src = (tgt - x_true[:3]) @ R + rng.normal(0, 0.002, tgt.shape)
     src = src[rng.permutation(len(src))][:30_000]
-    for jac in (mo.JAC_ANALYTIC, mo.JAC_ANALYTIC_LEFT):
+    # iterate for iterate the host loop's answer (the poses agree to 1e-16 all the way; only the
+    # noise-level stop at the very end — rho < 0 with |delta| < sqrt eps, decided by the last bits
+    # of two differently summed costs — may come at a different iteration)
+    for k in (3, 12, 27):
         dev = mo.IcpCost(src, tgt, max_distance=0.6)
         ref = mo.IcpCost(src, tgt, max_distance=0.6)
-        xd, rep = mo.capi.lm_minimize([dev], [jac], np.zeros(6), max_iterations=40,
+        xd, rep = mo.capi.lm_minimize([dev], [mo.JAC_ANALYTIC], np.zeros(6), max_iterations=k)
+        xh, sh, ih = host_lm(ref, mo.JAC_ANALYTIC, np.zeros(6), max_iter=k)
+        assert (rep["status"], rep["iterations"]) == (sh, ih), (k, rep, sh, ih)
+        assert rep["sweeps"] == 2 * k  # search + linearization, then one accepted trial, per iteration
+        assert np.abs(xd - xh).max() < 1e-9, (k, xd, xh)
+        # the correspondences the two loops ended with are the same
+        md, mr = dev.matches(), ref.matches()
+        assert np.array_equal(np.isnan(md), np.isnan(mr))
+        assert np.nanmax(np.abs(md - mr)) == 0.0
+        dev.close()
+        ref.close()
+    for jac in (mo.JAC_ANALYTIC, mo.JAC_ANALYTIC_LEFT):
+        dev = mo.IcpCost(src, tgt, max_distance=0.6)
+        xd, rep = mo.capi.lm_minimize([dev], [jac], np.zeros(6), max_iterations=60,
                                       manifold=(jac == mo.JAC_ANALYTIC_LEFT))
-        if jac == mo.JAC_ANALYTIC:
-            xh, sh, ih = host_lm(ref, jac, np.zeros(6), max_iter=40)
-            assert (rep["status"], rep["iterations"]) == (sh, ih), (rep, sh, ih)
-            assert np.abs(xd - xh).max() < 1e-9, (xd, xh)
-            # the correspondences the two loops ended with are the same
-            assert np.array_equal(np.isnan(dev.matches()), np.isnan(ref.matches()))
-            assert np.nanmax(np.abs(dev.matches() - ref.matches())) == 0.0
+        assert rep["status"] in (CONVERGED, SMALL_DELTA, MAX_ITERATIONS)
         assert np.abs(xd - x_true).max() < 2e-3, (jac, xd)
         # ... and the blocking calls continue from that state
         n_matched = dev.update(xd)
         assert n_matched > 0.95 * len(src)
         dev.close()
-        ref.close()
