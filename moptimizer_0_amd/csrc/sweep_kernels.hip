@@ -728,6 +728,11 @@ __device__ __forceinline__ void scalarModelBody(const ScalarSweepArgs<S> &A) {
   double acc[NACC];
 #pragma unroll
   for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+  // (r+ - r) / h_j (linearization.h:105) as a product with 1 / h_j formed once per sweep, like the
+  // hand-written point2point sweeps: an fp64 division per Jacobian entry and element otherwise
+  S inv_h[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) inv_h[j] = S(1) / A.h[j];
   for (long long i = (long long)blockIdx.x * kBlockThreads + threadIdx.x; i < A.count;
        i += (long long)gridDim.x * kBlockThreads) {
     S d[D > 0 ? D : 1];
@@ -752,7 +757,7 @@ __device__ __forceinline__ void scalarModelBody(const ScalarSweepArgs<S> &A) {
           S rp[M];
           Model::residual(xp, d, rp);
 #pragma unroll
-          for (int a = 0; a < M; ++a) J[a][j] = (rp[a] - r[a]) / A.h[j];  // :105
+          for (int a = 0; a < M; ++a) J[a][j] = (rp[a] - r[a]) * inv_h[j];  // :105
         }
       } else {
         Model::jacobian(A.x, d, J);
