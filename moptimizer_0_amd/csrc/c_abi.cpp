@@ -673,10 +673,11 @@ int uploadArgs(mopt_cost *c, const Args &host_value, hipStream_t s) {
 }
 
 template <typename S>
-int residentPrepareP2P(mopt_cost *c, int jac_mode, bool moments, hipStream_t s) {
+int residentPrepareP2P(mopt_cost *c, int jac_mode, bool moments, double *partials, hipStream_t s) {
   mopt::P2PSweepArgs<S> args;
   const S zero[kNumParams] = {0, 0, 0, 0, 0, 0};
   fillP2PArgs<S>(c, zero, false, args);  // data, loss, covariance; the step kernel writes T, 1/h
+  args.partials = partials;
   int rc = uploadArgs(c, args, s);
   if (rc != MOPT_OK) return rc;
   if (moments) {
@@ -696,7 +697,43 @@ int residentPrepareP2P(mopt_cost *c, int jac_mode, bool moments, hipStream_t s) 
 bool usesMoments(const mopt_cost *c) { return c->variant != MOPT_KERNEL_LITERAL; }
 }  // namespace
 
-int residentPrepare(mopt_cost *c, int jac_mode, hipStream_t s, mopt::LmCostDesc *desc) {
+int residentGrid(const mopt_cost *c) {
+  switch (c->model) {
+    case kModelPoint2Point:
+      return gridFor(c, blocksPerCu(usesMoments(c) ? 1 : 2));
+    case kModelReprojection:
+      return gridFor(c, blocksPerCu(2));
+    case kModelScalar: {
+      long long blocks = (c->count + mopt::kBlockThreads - 1) / mopt::kBlockThreads;
+      if (blocks > c->num_cus * 2) blocks = c->num_cus * 2;
+      return blocks < 1 ? 1 : int(blocks);
+    }
+    case kModelJit:
+      return jitGrid(c);
+    default:
+      return 1;
+  }
+}
+
+int residentDenseRow(const mopt_cost *c) {
+  const int n = c->n_params;
+  switch (c->model) {
+    case kModelPoint2Point:
+      if (usesMoments(c)) return 0;  // rows of moments, contracted by their own finalize kernel
+      return c->cov_mode == mopt::kCovGeneral ? mopt::kAccFull : mopt::kAccSym;
+    case kModelReprojection:
+      return c->cov_mode == mopt::kCovGeneral ? mopt::kAccFull : mopt::kAccSym;
+    case kModelScalar:
+    case kModelJit:
+      return c->cov_mode == mopt::kCovGeneral ? n * n + n + 1 : n * (n + 1) / 2 + n + 1;
+    default:
+      return 0;
+  }
+}
+
+int residentPrepare(mopt_cost *c, int jac_mode, hipStream_t s, mopt::LmCostDesc *desc,
+                    double *partials_override) {
+  double *const partials = partials_override ? partials_override : c->d_partials;
   if (jac_mode < MOPT_JAC_ANALYTIC || jac_mode > MOPT_JAC_ANALYTIC_LEFT)
     return fail(MOPT_ERR_INVALID_ARGUMENT, "unknown jacobian_mode");
   desc->jac_mode = jac_mode;
@@ -704,15 +741,17 @@ int residentPrepare(mopt_cost *c, int jac_mode, hipStream_t s, mopt::LmCostDesc 
   desc->moments = 0;
   desc->result = c->d_result;
   int rc = MOPT_OK;
-  const bool stale =
-      c->lm_uploaded_version != c->state_version || c->lm_uploaded_mode != jac_mode || !c->d_lm_args;
+  const bool stale = c->lm_uploaded_version != c->state_version ||
+                     c->lm_uploaded_mode != jac_mode || c->lm_uploaded_partials != partials ||
+                     !c->d_lm_args;
   switch (c->model) {
     case kModelPoint2Point: {
       desc->model = mopt::kLmPoint2Point;
       desc->moments = usesMoments(c) ? 1 : 0;
       if (stale)
-        rc = c->scalar_bytes == 8 ? residentPrepareP2P<double>(c, jac_mode, desc->moments, s)
-                                  : residentPrepareP2P<float>(c, jac_mode, desc->moments, s);
+        rc = c->scalar_bytes == 8
+                 ? residentPrepareP2P<double>(c, jac_mode, desc->moments, partials, s)
+                 : residentPrepareP2P<float>(c, jac_mode, desc->moments, partials, s);
       break;
     }
     case kModelReprojection: {
@@ -726,6 +765,7 @@ int residentPrepare(mopt_cost *c, int jac_mode, hipStream_t s, mopt::LmCostDesc 
         mopt::ReprojSweepArgs args;
         const double zero[kNumParams] = {0, 0, 0, 0, 0, 0};
         fillReprojArgs(c, zero, false, args);
+        args.partials = partials;
         rc = uploadArgs(c, args, s);
       }
       break;
@@ -745,11 +785,13 @@ int residentPrepare(mopt_cost *c, int jac_mode, hipStream_t s, mopt::LmCostDesc 
           mopt::ScalarSweepArgs<double> args;
           const double zero[mopt::kMaxParams] = {0};
           fillScalarArgs<double>(c, zero, args);
+          args.partials = partials;
           rc = uploadArgs(c, args, s);
         } else {
           mopt::ScalarSweepArgs<float> args;
           const float zero[mopt::kMaxParams] = {0};
           fillScalarArgs<float>(c, zero, args);
+          args.partials = partials;
           rc = uploadArgs(c, args, s);
         }
       }
@@ -774,11 +816,13 @@ int residentPrepare(mopt_cost *c, int jac_mode, hipStream_t s, mopt::LmCostDesc 
           mopt::JitArgs<double> args;
           const double zero[mopt::kMaxParams] = {0};
           fillJitArgs<double>(c, zero, args);
+          args.partials = partials;
           rc = uploadArgs(c, args, s);
         } else {
           mopt::JitArgs<float> args;
           const float zero[mopt::kMaxParams] = {0};
           fillJitArgs<float>(c, zero, args);
+          args.partials = partials;
           rc = uploadArgs(c, args, s);
         }
       }
@@ -790,13 +834,48 @@ int residentPrepare(mopt_cost *c, int jac_mode, hipStream_t s, mopt::LmCostDesc 
   if (rc != MOPT_OK) return rc;
   c->lm_uploaded_version = c->state_version;
   c->lm_uploaded_mode = jac_mode;
+  c->lm_uploaded_partials = partials;
   desc->args = c->d_lm_args;
   desc->basis = c->d_lm_basis;
   return MOPT_OK;
 }
 
+int residentFinalizeMerged(mopt_cost *last, int rows, int row_length, mopt::LmControl *control,
+                           hipStream_t s, const mopt::LmProblem *step, int own_index) {
+  MOPT_HIP_TRY(mopt::launchFinalizeDenseResident(last->d_partials, rows, row_length, last->n_params,
+                                                 last->d_result, control, s, nullptr, step,
+                                                 own_index, last->scalar_bytes));
+  return MOPT_OK;
+}
+
+bool residentSetSupported(mopt_cost *const *costs, int num_costs) {
+  for (int k = 0; k < num_costs; ++k)
+    if (costs[k]->model != kModelReprojection || costs[k]->cov_mode != costs[0]->cov_mode)
+      return false;
+  return num_costs > 1;
+}
+
+int residentSweepSet(mopt_cost *const *costs, int num_costs, const int *first_row,
+                     mopt::LmControl *control, hipStream_t s) {
+  mopt::ResidentSweepSet set;
+  set.num_costs = num_costs;
+  size_t bytes = 0;
+  for (int k = 0; k < num_costs; ++k) {
+    set.args[k] = costs[k]->d_lm_args;
+    set.first_block[k] = first_row[k];
+    bytes += size_t(costs[k]->count) * 40;
+  }
+  set.first_block[num_costs] = first_row[num_costs];
+  mopt::LaunchSite site;
+  site.stream = s;
+  site.streaming = bytes > (size_t(32) << 20);
+  MOPT_HIP_TRY(mopt::launchReprojResidentSet(set, control, costs[0]->cov_mode, site));
+  return MOPT_OK;
+}
+
 int residentSweep(mopt_cost *c, int jac_mode, mopt::LmControl *control, hipStream_t s,
-                  unsigned long long base_sequence, const mopt::LmProblem *step, int own_index) {
+                  unsigned long long base_sequence, const mopt::LmProblem *step, int own_index,
+                  bool finalize) {
   mopt::PeerCombine pc;
   const mopt::PeerCombine *peers = nullptr;
   if (c->combine.mode == MOPT_COMBINE_PEER) {
@@ -832,7 +911,7 @@ int residentSweep(mopt_cost *c, int jac_mode, mopt::LmControl *control, hipStrea
   switch (c->model) {
     case kModelPoint2Point: {
       if (usesMoments(c)) {
-        const int grid = gridFor(c, blocksPerCu(1));
+        const int grid = residentGrid(c);
         if (c->scalar_bytes == 8)
           MOPT_HIP_TRY(mopt::launchP2PMomentsResident<double>(
               static_cast<const double *>(c->d_tiles), c->num_tiles,
@@ -841,12 +920,13 @@ int residentSweep(mopt_cost *c, int jac_mode, mopt::LmControl *control, hipStrea
           MOPT_HIP_TRY(mopt::launchP2PMomentsResident<float>(
               static_cast<const float *>(c->d_tiles), c->num_tiles,
               static_cast<const mopt::P2PSweepArgs<float> *>(c->d_lm_args), control, grid, site));
-        MOPT_HIP_TRY(mopt::launchFinalizeMomentsResident(c->d_partials, grid, c->d_lm_basis,
+        if (finalize)
+          MOPT_HIP_TRY(mopt::launchFinalizeMomentsResident(c->d_partials, grid, c->d_lm_basis,
                                                          c->d_result, control, s, peers, step,
                                                          own_index, c->scalar_bytes));
       } else {
-        const int grid = gridFor(c, blocksPerCu(2));
-        const int nacc = c->cov_mode == mopt::kCovGeneral ? mopt::kAccFull : mopt::kAccSym;
+        const int grid = residentGrid(c);
+        const int nacc = residentDenseRow(c);
         if (c->scalar_bytes == 8)
           MOPT_HIP_TRY(mopt::launchP2PLiteralResident<double>(
               static_cast<const mopt::P2PSweepArgs<double> *>(c->d_lm_args), control, jac_mode,
@@ -855,28 +935,27 @@ int residentSweep(mopt_cost *c, int jac_mode, mopt::LmControl *control, hipStrea
           MOPT_HIP_TRY(mopt::launchP2PLiteralResident<float>(
               static_cast<const mopt::P2PSweepArgs<float> *>(c->d_lm_args), control, jac_mode,
               c->cov_mode, grid, site));
-        MOPT_HIP_TRY(mopt::launchFinalizeDenseResident(c->d_partials, grid, nacc, kNumParams,
-                                                       c->d_result, control, s, peers, step,
-                                                       own_index, c->scalar_bytes));
+        if (finalize)
+          MOPT_HIP_TRY(mopt::launchFinalizeDenseResident(c->d_partials, grid, nacc, kNumParams,
+                                                         c->d_result, control, s, peers, step,
+                                                         own_index, c->scalar_bytes));
       }
       return MOPT_OK;
     }
     case kModelReprojection: {
-      const int grid = gridFor(c, blocksPerCu(2));
-      const int nacc = c->cov_mode == mopt::kCovGeneral ? mopt::kAccFull : mopt::kAccSym;
+      const int grid = residentGrid(c);
+      const int nacc = residentDenseRow(c);
       MOPT_HIP_TRY(mopt::launchReprojResident(
           static_cast<const mopt::ReprojSweepArgs *>(c->d_lm_args), control, c->cov_mode, grid, site));
-      MOPT_HIP_TRY(mopt::launchFinalizeDenseResident(c->d_partials, grid, nacc, kNumParams,
+      if (finalize)
+        MOPT_HIP_TRY(mopt::launchFinalizeDenseResident(c->d_partials, grid, nacc, kNumParams,
                                                      c->d_result, control, s, peers, step, own_index,
                                                      c->scalar_bytes));
       return MOPT_OK;
     }
     case kModelScalar: {
-      long long blocks = (c->count + mopt::kBlockThreads - 1) / mopt::kBlockThreads;
-      if (blocks > c->num_cus * 2) blocks = c->num_cus * 2;
-      if (blocks < 1) blocks = 1;
-      const int grid = int(blocks);
-      const int nacc = c->cov_mode == mopt::kCovGeneral ? n * n + n + 1 : n * (n + 1) / 2 + n + 1;
+      const int grid = residentGrid(c);
+      const int nacc = residentDenseRow(c);
       if (c->scalar_bytes == 8)
         MOPT_HIP_TRY(mopt::launchScalarModelResident<double>(
             static_cast<const mopt::ScalarSweepArgs<double> *>(c->d_lm_args), control,
@@ -885,7 +964,8 @@ int residentSweep(mopt_cost *c, int jac_mode, mopt::LmControl *control, hipStrea
         MOPT_HIP_TRY(mopt::launchScalarModelResident<float>(
             static_cast<const mopt::ScalarSweepArgs<float> *>(c->d_lm_args), control,
             c->scalar_model, jac_mode, c->cov_mode, grid, s));
-      MOPT_HIP_TRY(mopt::launchFinalizeDenseResident(c->d_partials, grid, nacc, n, c->d_result,
+      if (finalize)
+        MOPT_HIP_TRY(mopt::launchFinalizeDenseResident(c->d_partials, grid, nacc, n, c->d_result,
                                                      control, s, peers, step, own_index,
                                                      c->scalar_bytes));
       return MOPT_OK;
@@ -895,10 +975,11 @@ int residentSweep(mopt_cost *c, int jac_mode, mopt::LmControl *control, hipStrea
       const mopt::JitVariant *variant =
           mopt::jitVariant(c->jit, jac_mode == MOPT_JAC_NUMERIC ? 2 : 1, cov_symmetric);
       if (!variant) return fail(MOPT_ERR_INVALID_ARGUMENT, mopt::jitLastError());
-      const int grid = jitGrid(c);
-      const int nacc = cov_symmetric ? n * (n + 1) / 2 + n + 1 : n * n + n + 1;
+      const int grid = residentGrid(c);
+      const int nacc = residentDenseRow(c);
       MOPT_HIP_TRY(mopt::jitLaunchResident(*variant, c->d_lm_args, control, grid, s));
-      MOPT_HIP_TRY(mopt::launchFinalizeDenseResident(c->d_partials, grid, nacc, n, c->d_result,
+      if (finalize)
+        MOPT_HIP_TRY(mopt::launchFinalizeDenseResident(c->d_partials, grid, nacc, n, c->d_result,
                                                      control, s, peers, step, own_index,
                                                      c->scalar_bytes));
       return MOPT_OK;
@@ -1012,6 +1093,7 @@ int commonCreate(mopt_cost *c, int device) {
 hipError_t quiesceCost(mopt_cost *c) {
   hipError_t first = hipSuccess;
   if (c->stream) first = hipStreamSynchronize(c->stream);
+  c->own_async_pending = false;
   if (c->foreign_pending && c->foreign_done) {
     const hipError_t e = hipEventSynchronize(c->foreign_done);
     if (first == hipSuccess) first = e;
@@ -1429,7 +1511,10 @@ namespace {
 // A sweep went onto a stream this cost does not own: leave a marker behind it, so that
 // destroy / set_data can wait for it before the cost's buffers go back to the pool.
 int markForeignStream(mopt_cost *c, hipStream_t s) {
-  if (s == c->stream) return MOPT_OK;
+  if (s == c->stream) {
+    c->own_async_pending = true;
+    return MOPT_OK;
+  }
   if (!c->foreign_done)
     MOPT_HIP_TRY(hipEventCreateWithFlags(&c->foreign_done, hipEventDisableTiming));
   MOPT_HIP_TRY(hipEventRecord(c->foreign_done, s));
@@ -1603,6 +1688,7 @@ int mopt_cost_synchronize(mopt_cost *c) {
   if (!c) return fail(MOPT_ERR_INVALID_ARGUMENT, "cost is NULL");
   MOPT_HIP_TRY(hipSetDevice(c->device));
   MOPT_HIP_TRY(hipStreamSynchronize(c->stream));
+  c->own_async_pending = false;
   return MOPT_OK;
 }
 

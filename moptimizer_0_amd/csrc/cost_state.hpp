@@ -165,6 +165,7 @@ struct mopt_cost {
   mopt::AffineBasis *d_lm_basis = nullptr;
   unsigned long long lm_uploaded_version = ~0ull;
   int lm_uploaded_mode = -1;
+  const double *lm_uploaded_partials = nullptr;  // where the uploaded constants send the rows
   mopt::LmControl *d_lm_control = nullptr;
   void *d_lm_state = nullptr;
   mopt::LmReport *h_lm_report = nullptr;      // mapped host memory
@@ -174,6 +175,7 @@ struct mopt_cost {
   // not be recycled before that work has finished, and only an event on that stream can tell.
   hipEvent_t foreign_done = nullptr;
   bool foreign_pending = false;
+  bool own_async_pending = false;  // an asynchronous sweep was queued on this cost's own stream
 
   int profiling = 0;  // 0 off, N > 0: bracket every N-th sweep launch with events
   long long profiling_tick = 0;
@@ -210,11 +212,24 @@ void releaseCombine(mopt_cost *c);  // combine.cpp: unmaps / closes whatever was
 // c_abi.cpp: the next (host_result, flag, sequence) of this cost's mapped host block, and the wait
 mopt::HostPublish nextHostPublish(mopt_cost *c, int offset);
 int waitHostPublished(mopt_cost *c, unsigned long long sequence);
-int residentPrepare(mopt_cost *c, int jac_mode, hipStream_t s, mopt::LmCostDesc *desc);
+// `partials_override`: write this cost's partial rows there instead of into its own buffer (the
+// rows of several costs behind one another, reduced by one finalize kernel)
+int residentPrepare(mopt_cost *c, int jac_mode, hipStream_t s, mopt::LmCostDesc *desc,
+                    double *partials_override = nullptr);
+int residentGrid(const mopt_cost *c);      // workgroups (= partial rows) of a resident sweep
+int residentDenseRow(const mopt_cost *c);  // values per partial row; 0: rows of moments
+// one finalize (+ LM step) over `rows` rows of `row_length` values in last->d_partials
+int residentFinalizeMerged(mopt_cost *last, int rows, int row_length, mopt::LmControl *control,
+                           hipStream_t s, const mopt::LmProblem *step, int own_index);
 // `step` non-NULL: this is the last cost of the problem, its finalize kernel also runs the LM step
+// the resident sweeps of all costs in one launch, where a kernel for that exists (reprojection
+// costs with one covariance form); first_row[k] = where cost k's partial rows start
+bool residentSetSupported(mopt_cost *const *costs, int num_costs);
+int residentSweepSet(mopt_cost *const *costs, int num_costs, const int *first_row,
+                     mopt::LmControl *control, hipStream_t s);
 int residentSweep(mopt_cost *c, int jac_mode, mopt::LmControl *control, hipStream_t s,
                   unsigned long long base_sequence, const mopt::LmProblem *step = nullptr,
-                  int own_index = 0);
+                  int own_index = 0, bool finalize = true);
 void releaseResident(mopt_cost *c);
 // icp.cpp: the pose-independent part of a correspondence search over this cost's grid
 template <typename S>

@@ -108,8 +108,30 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
   problem.control = lead->d_lm_control;
   problem.state = lead->d_lm_state;
   problem.report = lead->h_lm_report_dev;
+  // Several costs whose sweeps leave rows of the same H | b | sum_sq form: the rows go behind one
+  // another into the last cost's buffer and one finalize kernel — the one that takes the LM step —
+  // reduces them all, instead of one finalize launch per cost.  (Not for sharded costs, whose
+  // sums are exchanged per cost, nor for rows of moments, which each cost contracts itself.)
+  mopt_cost *last = costs[num_costs - 1];
+  const int row_length = residentDenseRow(last);
+  static const bool merge_enabled = [] {  // MOPT_LM_MERGE=0: one finalize per cost (for comparison)
+    const char *v = std::getenv("MOPT_LM_MERGE");
+    return !(v && v[0] == '0');
+  }();
+  bool merged = merge_enabled && num_costs > 1 && row_length > 0;
+  int row_offset[mopt::kLmMaxCosts + 1] = {0};
   for (int k = 0; k < num_costs; ++k) {
-    rc = residentPrepare(costs[k], jacobian_modes[k], s, &problem.cost[k]);
+    merged = merged && residentDenseRow(costs[k]) == row_length && !costs[k]->matcher &&
+             costs[k]->combine.mode == MOPT_COMBINE_NONE;
+    row_offset[k + 1] = row_offset[k] + residentGrid(costs[k]);
+    for (int j = 0; j < k; ++j) merged = merged && costs[j] != costs[k];
+  }
+  merged = merged && row_offset[num_costs] <= last->max_grid;
+  problem.merged = merged ? 1 : 0;
+  const bool one_launch = merged && residentSetSupported(costs, num_costs);
+  for (int k = 0; k < num_costs; ++k) {
+    rc = residentPrepare(costs[k], jacobian_modes[k], s, &problem.cost[k],
+                         merged ? last->d_partials + size_t(row_offset[k]) * row_length : nullptr);
     if (rc != MOPT_OK) return rc;
     costs[k]->cache.valid = false;
     if (costs[k]->matcher) {
@@ -117,6 +139,14 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
       costs[k]->state_version += 1;      // the correspondences will have changed
     }
   }
+  // The loop of all costs runs on the lead cost's stream.  Sweeps a caller queued asynchronously
+  // for another cost (its own stream, or the caller's) write the same partial rows: wait for them.
+  // (Running each cost's sweeps on its own stream instead, joined by events, was measured and
+  // dropped: a cross-queue dependency costs 7-13 us on this runtime, more than the sweeps that
+  // would overlap — DESIGN.md section 3.)
+  for (int k = 0; k < num_costs; ++k)
+    if (costs[k]->foreign_pending || (costs[k]->own_async_pending && costs[k]->stream != s))
+      MOPT_HIP_TRY(quiesceCost(costs[k]));
   unsigned long long base_sequence[mopt::kLmMaxCosts];
   for (int k = 0; k < num_costs; ++k) base_sequence[k] = costs[k]->combine.sequence + 1;
 
@@ -147,10 +177,19 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
     bool queued = false;
     while (enqueued < max_points && enqueued - completed < window) {
       // per point: every cost's sweep + finalize; the last finalize also takes the LM step
-      for (int k = 0; k < num_costs; ++k) {
-        const bool last = k == num_costs - 1;
+      if (one_launch) {
+        rc = residentSweepSet(costs, num_costs, row_offset, problem.control, s);
+        if (rc != MOPT_OK) return rc;
+      }
+      for (int k = 0; k < num_costs && !one_launch; ++k) {
+        const bool is_last = k == num_costs - 1;
         rc = residentSweep(costs[k], jacobian_modes[k], problem.control, s, base_sequence[k],
-                           last ? &problem : nullptr, k);
+                           is_last ? &problem : nullptr, k, !merged);
+        if (rc != MOPT_OK) return rc;
+      }
+      if (merged) {
+        rc = residentFinalizeMerged(last, row_offset[num_costs], row_length, problem.control, s,
+                                    &problem, num_costs - 1);
         if (rc != MOPT_OK) return rc;
       }
       ++enqueued;

@@ -441,8 +441,12 @@ __device__ void lmStepBody(const LmProblem &P, bool init, const LmStart<S> &star
     // sums over the costs, accumulated in Scalar in cost order (:48-60, :86)
     if (tid < nn + n + 1) {
       S v = S(0);
-      for (int ci = 0; ci < P.num_costs; ++ci)
-        v += S((own_result && ci == own_index) ? own_result[tid] : P.cost[ci].result[tid]);
+      if (P.merged && own_result) {
+        v = S(own_result[tid]);  // already the sum over the costs (one reduction over all rows)
+      } else {
+        for (int ci = 0; ci < P.num_costs; ++ci)
+          v += S((own_result && ci == own_index) ? own_result[tid] : P.cost[ci].result[tid]);
+      }
       sums[tid] = v;
     }
   }

@@ -222,6 +222,9 @@ struct LmProblem {
   int manifold = 0;           // 1: x (+) delta composed on SE(3) instead of added (n = 6 only)
   int rematch = 0;            // 1: some cost re-searches its correspondences in update(x): an accepted
                               //    point is re-linearized after the search instead of adopted
+  int merged = 0;             // 1: the partial rows of all costs lie behind one another and the last
+                              //    cost's finalize reduces them all: its result is the sum over the costs
+  int pad = 0;
   LmCostDesc cost[kLmMaxCosts];
   LmControl *control = nullptr;  // device
   void *state = nullptr;         // device, LmState<S> (lm_kernels.hip)
@@ -243,6 +246,14 @@ hipError_t launchP2PMomentsResident(const S *tiles, int num_tiles, const P2PSwee
 template <typename S>
 hipError_t launchP2PLiteralResident(const P2PSweepArgs<S> *d_args, const LmControl *control,
                                     int jac_mode, int cov_mode, int grid, const LaunchSite &site);
+// several costs' resident sweeps in one launch (their partial rows behind one another)
+struct ResidentSweepSet {
+  const void *args[kLmMaxCosts] = {};   // device: each cost's resident argument block
+  int first_block[kLmMaxCosts + 1] = {};  // workgroups [first_block[k], first_block[k+1]) -> cost k
+  int num_costs = 0;
+};
+hipError_t launchReprojResidentSet(const ResidentSweepSet &set, const LmControl *control,
+                                   int cov_mode, const LaunchSite &site);
 hipError_t launchReprojResident(const ReprojSweepArgs *d_args, const LmControl *control,
                                 int cov_mode, int grid, const LaunchSite &site);
 template <typename S>

@@ -609,14 +609,16 @@ __device__ __forceinline__ void reprojResidual(const double (&Mx)[12], const dou
   r[1] = v - (o[1] / o[2]);  // :39
 }
 
+// block / num_blocks: this workgroup's place among those sweeping this cost (a launch may carry
+// the workgroups of several costs: reprojResidentSetKernel)
 template <int COV, bool COST_ONLY>
-__device__ __forceinline__ void reprojBody(const ReprojSweepArgs &A) {
+__device__ __forceinline__ void reprojBody(const ReprojSweepArgs &A, int block, int num_blocks) {
   constexpr int NACC = COST_ONLY ? 1 : ((COV == kCovGeneral) ? kAccFull : kAccSym);
   double acc[NACC];
 #pragma unroll
   for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
 
-  for (int tile = blockIdx.x; tile < A.num_tiles; tile += gridDim.x) {
+  for (int tile = block; tile < A.num_tiles; tile += num_blocks) {
     const unsigned char *tb = A.tiles + size_t(tile) * kReprojTileBytes;
     const double *planes = reinterpret_cast<const double *>(tb) + threadIdx.x * 2;
     Pack<double> pk[4];
@@ -651,12 +653,12 @@ __device__ __forceinline__ void reprojBody(const ReprojSweepArgs &A) {
       }
     }
   }
-  blockReduceStore<NACC>(acc, A.partials + size_t(blockIdx.x) * NACC);
+  blockReduceStore<NACC>(acc, A.partials + size_t(block) * NACC);
 }
 
 template <int COV, bool COST_ONLY>
 __global__ __launch_bounds__(kBlockThreads) void reprojKernel(const ReprojSweepArgs A) {
-  reprojBody<COV, COST_ONLY>(A);
+  reprojBody<COV, COST_ONLY>(A, blockIdx.x, gridDim.x);
 }
 
 template <int COV>
@@ -664,7 +666,21 @@ __global__ __launch_bounds__(kBlockThreads) void reprojResidentKernel(
     const ReprojSweepArgs *__restrict__ d_args, const LmControl *__restrict__ control) {
   if (control->done) return;
   const ReprojSweepArgs A = *d_args;
-  reprojBody<COV, false>(A);
+  reprojBody<COV, false>(A, blockIdx.x, gridDim.x);
+}
+
+// The sweeps of several reprojection costs of one problem in one launch: workgroups
+// [first_block[k], first_block[k + 1]) sweep cost k.  Each cost alone fills part of the chip
+// (100 k elements: 196 tiles), behind one another they would also pay a launch boundary each.
+template <int COV>
+__global__ __launch_bounds__(kBlockThreads) void reprojResidentSetKernel(
+    const ResidentSweepSet set, const LmControl *__restrict__ control) {
+  if (control->done) return;
+  int k = 0;
+  while (k + 1 < set.num_costs && int(blockIdx.x) >= set.first_block[k + 1]) ++k;
+  const ReprojSweepArgs A = *static_cast<const ReprojSweepArgs *>(set.args[k]);
+  reprojBody<COV, false>(A, int(blockIdx.x) - set.first_block[k],
+                         set.first_block[k + 1] - set.first_block[k]);
 }
 
 // ---- small parametric models over per-element scalar data ------------------------------------
@@ -1647,6 +1663,23 @@ hipError_t launchReprojResident(const ReprojSweepArgs *d_args, const LmControl *
       break;
     default:
       hipLaunchKernelGGL((reprojResidentKernel<kCovGeneral>), g, b, 0, site.stream, d_args, control);
+      break;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launchReprojResidentSet(const ResidentSweepSet &set, const LmControl *control,
+                                   int cov_mode, const LaunchSite &site) {
+  const dim3 g(set.first_block[set.num_costs]), b(kBlockThreads);
+  switch (cov_mode) {
+    case kCovIdentity:
+      hipLaunchKernelGGL((reprojResidentSetKernel<kCovIdentity>), g, b, 0, site.stream, set, control);
+      break;
+    case kCovSymmetric:
+      hipLaunchKernelGGL((reprojResidentSetKernel<kCovSymmetric>), g, b, 0, site.stream, set, control);
+      break;
+    default:
+      hipLaunchKernelGGL((reprojResidentSetKernel<kCovGeneral>), g, b, 0, site.stream, set, control);
       break;
   }
   return hipGetLastError();

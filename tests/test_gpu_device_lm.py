@@ -324,3 +324,81 @@ def test_icp_cost_with_the_search_inside_the_device_loop(hip_lib):
         n_matched = dev.update(xd)
         assert n_matched > 0.95 * len(src)
         dev.close()
+
+
+def host_lm_sum(costs, jac_modes, x0, max_iter=15, lm_iter=3):
+    """The same loop over several HIP costs: H, b and the cost summed in cost order (:48-60, :86)."""
+    class Sum:
+        def linearize(self, x, _):
+            H, b, y = 0.0, 0.0, 0.0
+            for c, jac in zip(costs, jac_modes):
+                Hc, bc, yc = c.linearize(x, jac)
+                H, b, y = H + Hc, b + bc, y + yc
+            return H, b, y
+
+        def compute_cost(self, x):
+            return sum(c.compute_cost(x) for c in costs)
+    return host_lm(Sum(), None, x0, max_iter, lm_iter)
+
+
+def test_several_costs_in_every_combination_of_sweep_kinds(hip_lib):
+    """Costs whose sweeps leave rows of one form are reduced by ONE finalize kernel (and swept by one
+    launch where a kernel for that exists: reprojection); rows of moments and mixed forms keep one
+    finalize per cost.  Every form against the host loop summing the same costs through the blocking
+    boundary; then each cost again on its own (its resident constants point at its own rows again)."""
+    mo = hip_lib
+    rng = np.random.default_rng(5)
+    # (a) three reprojection costs: one sweep launch + one finalize per point
+    pts, pix = ds.synthetic_camera(30_000, seed=3)
+    cuts = [0, 7000, 18_000, 30_000]
+    cams = [mo.ReprojectionCost(pts[a:b], pix[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    for c in cams:
+        c.set_loss(mo.LOSS_GEMAN_MCCLURE, 100.0)
+    x, rep = mo.capi.lm_minimize(cams, [mo.JAC_NUMERIC] * 3, np.zeros(6), max_iterations=25)
+    xh, sh, ih = host_lm_sum(cams, [mo.JAC_NUMERIC] * 3, np.zeros(6), max_iter=25)
+    assert rep["status"] == sh and abs(rep["iterations"] - ih) <= 1, (rep, sh, ih)
+    assert np.abs(x - xh).max() < 1e-6, (x, xh)
+    x1, rep1 = mo.capi.lm_minimize(cams[:1], [mo.JAC_NUMERIC], np.zeros(6), max_iterations=25)
+    xh1, sh1, _ = host_lm(cams[0], mo.JAC_NUMERIC, np.zeros(6), max_iter=25)
+    assert rep1["status"] == sh1 and np.abs(x1 - xh1).max() < 1e-6, (x1, xh1)
+    for c in cams:
+        c.close()
+
+    # (b) two exp-curve costs (tst/multiple_objectives.cpp:81-98): one finalize, a sweep each
+    t = np.linspace(0.0, 5.0, 4000)
+    y = np.exp(0.3 * t + 0.1) + 0.01 * rng.standard_normal(t.size)
+    curves = [mo.ScalarModelCost(mo.capi.MODEL_EXP_CURVE, t[:1500], y[:1500]),
+              mo.ScalarModelCost(mo.capi.MODEL_EXP_CURVE, t[1500:], y[1500:])]
+    for jac in (mo.JAC_NUMERIC,):  # the model has no f_df (numeric only, like the reference's)
+        x, rep = mo.capi.lm_minimize(curves, [jac] * 2, np.zeros(2), max_iterations=50)
+        xh, sh, ih = host_lm_sum(curves, [jac] * 2, np.zeros(2), max_iter=50)
+        assert rep["status"] == sh and abs(rep["iterations"] - ih) <= 1, (jac, rep, sh, ih)
+        assert np.abs(x - xh).max() < 1e-8, (jac, x, xh)
+    for c in curves:
+        c.close()
+
+    # (c) point2point costs: literal + literal (one finalize), moments + literal and
+    #     moments + moments (a finalize each: rows of moments are contracted by their own kernel)
+    src, tgt = ds.synthetic_pair(60_000, seed=21, noise=0.02)
+    halves = [mo.Point2PointCost(src[:25_000], tgt[:25_000]), mo.Point2PointCost(src[25_000:], tgt[25_000:])]
+    whole = mo.Point2PointCost(src, tgt)
+    xw, repw = mo.capi.lm_minimize([whole], [mo.JAC_ANALYTIC], np.zeros(6))
+    for variants in ((mo.KERNEL_LITERAL, mo.KERNEL_LITERAL), (mo.KERNEL_MOMENTS, mo.KERNEL_LITERAL),
+                     (mo.KERNEL_MOMENTS, mo.KERNEL_MOMENTS)):
+        for c, v in zip(halves, variants):
+            c.set_kernel_variant(v)
+        x, rep = mo.capi.lm_minimize(halves, [mo.JAC_ANALYTIC] * 2, np.zeros(6))
+        xh, sh, ih = host_lm_sum(halves, [mo.JAC_ANALYTIC] * 2, np.zeros(6))
+        assert rep["status"] == sh and rep["iterations"] == ih, (variants, rep, sh, ih)
+        assert np.abs(x - xh).max() < 1e-9, (variants, x, xh)
+        # two halves of a cloud = the whole cloud
+        assert rep["status"] == repw["status"] and np.abs(x - xw).max() < 1e-9, (variants, x, xw)
+    # a cost that shared a finalize goes back to its own rows for the blocking calls and alone
+    H, b, y0 = halves[0].linearize(xw, mo.JAC_ANALYTIC)
+    x0, rep0 = mo.capi.lm_minimize(halves[:1], [mo.JAC_ANALYTIC], np.zeros(6))
+    xh0, sh0, ih0 = host_lm(halves[0], mo.JAC_ANALYTIC, np.zeros(6))
+    assert rep0["status"] == sh0 and np.abs(x0 - xh0).max() < 1e-9
+    H2, b2, y2 = halves[0].linearize(xw, mo.JAC_ANALYTIC)
+    assert np.array_equal(H, H2) and np.array_equal(b, b2) and y0 == y2
+    for c in halves + [whole]:
+        c.close()
