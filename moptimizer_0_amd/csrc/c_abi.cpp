@@ -439,7 +439,31 @@ void fillJitArgs(const mopt_cost *c, const S *x, mopt::JitArgs<S> &args) {
   args.partials = c->d_partials;
 }
 
+template <typename S>
+void fillJitWideArgs(const mopt_cost *c, const S *x, mopt::JitWideArgs<S> &args) {
+  args.data = static_cast<const S *>(c->d_tiles);
+  args.count = c->count;
+  args.stride = c->data_stride;
+  args.loss_kind = c->loss_kind;
+  args.pad_[0] = args.pad_[1] = args.pad_[2] = 0;
+  args.loss_param = S(c->loss_param);
+  const S min_step = std::sqrt(std::numeric_limits<S>::epsilon());  // linearization.h:78
+  for (int j = 0; j < mopt::kMaxWideParams; ++j) {
+    args.x[j] = j < c->n_params ? x[j] : S(0);
+    S h = min_step * std::fabs(args.x[j]);  // :85
+    if (h == S(0)) h = min_step;            // :87
+    args.h[j] = h;
+  }
+  for (int k = 0; k < mopt::kMaxWideOutputs * mopt::kMaxWideOutputs; ++k) args.cov[k] = S(c->cov_m[k]);
+  args.partials = c->d_partials;
+}
+
 int jitGrid(const mopt_cost *c) {
+  if (c->jit.wide) {
+    long long blocks = (c->count + mopt::kJitWideElementsPerBlock - 1) / mopt::kJitWideElementsPerBlock;
+    if (blocks > c->num_cus * 2) blocks = c->num_cus * 2;  // rows of up to 273 doubles
+    return blocks < 1 ? 1 : int(blocks);
+  }
   const long long per_block = (long long)mopt::kBlockThreads * (16 / c->scalar_bytes);
   long long blocks = (c->count + per_block - 1) / per_block;
   if (blocks > c->num_cus * 4) blocks = c->num_cus * 4;
@@ -459,16 +483,25 @@ int jitSweepAsync(mopt_cost *c, bool cost_only, int jac_mode, const S *x, double
       return fail(MOPT_ERR_UNSUPPORTED,
                   "Non implemented non-jacobian model function `f_df` being used.");
   }
-  mopt::JitArgs<S> args;
-  fillJitArgs<S>(c, x, args);
   const int mode = cost_only ? 0 : (jac_mode == MOPT_JAC_NUMERIC ? 2 : 1);
-  const bool cov_symmetric = c->cov_mode != mopt::kCovGeneral;
+  const bool cov_symmetric = !c->jit.wide && c->cov_mode != mopt::kCovGeneral;
   const mopt::JitVariant *variant = mopt::jitVariant(c->jit, mode, cov_symmetric);
   if (!variant) return fail(MOPT_ERR_INVALID_ARGUMENT, mopt::jitLastError());
   const int grid = jitGrid(c);
   const int n = c->n_params;
   SweepTimer timer(c, s);
-  MOPT_HIP_TRY(mopt::jitLaunch(*variant, &args, sizeof args, grid, s));
+  if (c->jit.wide) {
+    if (c->combine.mode == MOPT_COMBINE_HOST || c->combine.mode == MOPT_COMBINE_PEER)
+      return fail(MOPT_ERR_UNSUPPORTED,
+                  "the host / peer combine slots hold the sums of models with n <= 8");
+    mopt::JitWideArgs<S> args;
+    fillJitWideArgs<S>(c, x, args);
+    MOPT_HIP_TRY(mopt::jitLaunch(*variant, &args, sizeof args, grid, s));
+  } else {
+    mopt::JitArgs<S> args;
+    fillJitArgs<S>(c, x, args);
+    MOPT_HIP_TRY(mopt::jitLaunch(*variant, &args, sizeof args, grid, s));
+  }
   timer.stop();
   if (cost_only) {
     MOPT_HIP_TRY(mopt::launchFinalizeCost(c->d_partials, grid, d_out, pub, s, c->launch_peers));
@@ -804,6 +837,10 @@ int residentPrepare(mopt_cost *c, int jac_mode, hipStream_t s, mopt::LmCostDesc 
       if (jac_mode == MOPT_JAC_ANALYTIC && !c->jit.has_jacobian)
         return fail(MOPT_ERR_UNSUPPORTED,
                     "Non implemented non-jacobian model function `f_df` being used.");
+      if (c->jit.wide)
+        return fail(MOPT_ERR_UNSUPPORTED,
+                    "mopt_lm_minimize keeps its state for n <= 8: drive a wide model (n > 8 or m > 4) "
+                    "through the blocking calls");
       // compile (first use) before anything is queued: a source error must surface here
       if (!mopt::jitVariant(c->jit, jac_mode == MOPT_JAC_NUMERIC ? 2 : 1,
                             c->cov_mode != mopt::kCovGeneral))
@@ -1077,7 +1114,7 @@ int commonCreate(mopt_cost *c, int device) {
   c->max_grid = c->num_cus * 16;
   MOPT_HIP_TRY(acquireStream(device, &c->stream));
   MOPT_HIP_TRY(deviceAlloc(reinterpret_cast<void **>(&c->d_partials),
-                         size_t(c->max_grid) * kResultSlots * sizeof(double)));
+                         size_t(c->max_grid) * kPartialRowSlots * sizeof(double)));
   MOPT_HIP_TRY(deviceAlloc(reinterpret_cast<void **>(&c->d_result), kResultSlots * sizeof(double)));
   // results (43) + padding + flag word in one mapped, coherent host allocation
   MOPT_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_result),
@@ -1446,7 +1483,9 @@ int mopt_cost_destroy(mopt_cost *cost) {
 int mopt_cost_set_covariance(mopt_cost *c, const void *cov_colmajor) {
   if (!c) return fail(MOPT_ERR_INVALID_ARGUMENT, "cost is NULL");
   const int m = c->n_out;
-  double dense[16];  // row-major m x m
+  constexpr int kCovSlots = mopt::kMaxWideOutputs * mopt::kMaxWideOutputs;
+  if (m < 1 || m * m > kCovSlots) return fail(MOPT_ERR_INVALID_ARGUMENT, "output dimension out of range");
+  double dense[kCovSlots];  // row-major m x m
   for (int a = 0; a < m; ++a)
     for (int b = 0; b < m; ++b) {
       double v = (a == b) ? 1.0 : 0.0;
@@ -1455,9 +1494,9 @@ int mopt_cost_set_covariance(mopt_cost *c, const void *cov_colmajor) {
                                  : double(static_cast<const float *>(cov_colmajor)[b * m + a]);
       dense[a * m + b] = v;
     }
-  double previous[16];
+  double previous[kCovSlots];
   std::memcpy(previous, c->cov_m, sizeof previous);
-  for (int k = 0; k < 16; ++k) c->cov_m[k] = 0.0;
+  for (int k = 0; k < kCovSlots; ++k) c->cov_m[k] = 0.0;
   for (int k = 0; k < m * m; ++k) c->cov_m[k] = dense[k];
   for (int k = 0; k < 9; ++k) c->cov[k] = (k % 4 == 0) ? 1.0 : 0.0;
   if (m <= 3)

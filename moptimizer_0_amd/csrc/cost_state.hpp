@@ -38,8 +38,11 @@ int fail(int code, const std::string &msg);
   } while (0)
 
 enum ModelKind { kModelPoint2Point = 1, kModelReprojection = 2, kModelScalar = 3, kModelJit = 4 };
-constexpr int kMaxParamBytes = mopt::kMaxParams * 8;
-constexpr int kResultSlots = 96;  // >= n*n + n + 1 for n <= 8 (73)
+constexpr int kMaxParamBytes = mopt::kMaxWideParams * 8;
+// results of one sweep: >= n*n + n + 1 for n <= 16 (273: run-time compiled wide models; every other
+// model has n <= 8, 73 values, and the combine slots of sweep.hpp hold those)
+constexpr int kResultSlots = 288;
+constexpr int kPartialRowSlots = 96;  // the partial-row buffer is max_grid rows of this many doubles
 
 inline int envInt(const char *name, int fallback) {
   const char *v = std::getenv(name);
@@ -122,7 +125,7 @@ struct mopt_cost {
   const mopt::PeerCombine *launch_peers = nullptr;
 
   double cov[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // row-major, stride 3 (m <= 3), as double
-  double cov_m[16] = {1};                        // row-major m x m compact (scalar models, m <= 4)
+  double cov_m[mopt::kMaxWideOutputs * mopt::kMaxWideOutputs] = {1};  // row-major m x m compact (generic models)
   int cov_mode = mopt::kCovIdentity;
   int loss_kind = MOPT_LOSS_NONE;
   double loss_param = 0.0;

@@ -244,6 +244,169 @@ extern "C" __global__ __launch_bounds__(kBlock) void mopt_jit_sweep_resident(
 }
 )JIT";
 
+
+// ---- wide models: 8 < n <= 16 or 4 < m <= 16 ---------------------------------------------------
+// The per-thread sweep above keeps the m x n Jacobian and n(n+1)/2 + n + 1 sums of an element in
+// one lane's registers; at n = m = 15 (tst/state_model.cpp:83-112) that is 225 + 136 values.  Here
+// an element is worked on by 16 lanes, lane j owning column j: it evaluates the residual at x and
+// at x + h_j e_j (or reads its column of the supplied Jacobian, which one lane of the element wrote
+// to LDS), forms S J(:, j), and accumulates H(:, j) = sum_a (w J(a, :))^T (S J)(a, j) against the
+// other lanes' columns in LDS, plus b(j) — the same products, in the same order, as above
+// (linearization.h:105-115, :144-152).  256 threads = 16 elements x 16 lanes; rows are always the
+// full form (n*n + n + 1).  These models come with a handful of residuals (a state prior, an IMU
+// term): the layout is for register pressure, not for bandwidth.
+const char *const kJitWidePrologue = R"JIT(
+#define kBlock 256
+typedef MOPT_S S;
+#define N MOPT_N
+#define M MOPT_M
+#define D MOPT_D
+#define AUX MOPT_A
+#define MODE MOPT_MODE       /* 0 cost only, 1 supplied Jacobian, 2 forward differences */
+#define COLS 16
+#define EPB (kBlock / COLS)
+#define NACC (MODE == 0 ? 1 : N * N + N + 1)
+
+struct JitArgs {
+  const S *data;       // planes: data[p * stride + i]
+  long long count;
+  long long stride;
+  int loss_kind;       // 0 none, 1 Geman-McClure
+  int pad_[3];
+  S loss_param;
+  S x[16];
+  S h[16];
+  S cov[256];          // row-major M x M
+  double *partials;    // [grid][NACC]
+};
+)JIT";
+
+const char *const kJitWideSweep = R"JIT(
+extern "C" __global__ __launch_bounds__(kBlock) void mopt_jit_sweep(const JitArgs A) {
+  __shared__ S aux[(N + 1) * (AUX > 0 ? AUX : 1)];
+  // Jacobians of the 16 elements in flight (row-major M x N each); afterwards the lanes' sums
+  __shared__ double pool[kBlock * (N + 2)];
+  S *ldsJ = (S *)pool;
+  if (AUX > 0) {
+    const int variants = MODE == 2 ? N + 1 : 1;
+    if ((int)threadIdx.x < variants) {
+      S xs[N];
+#pragma unroll
+      for (int k = 0; k < N; ++k) xs[k] = A.x[k] + ((int)threadIdx.x == k + 1 ? A.h[k] : S(0));
+      user_setup(xs, aux + threadIdx.x * AUX);
+    }
+    __syncthreads();
+  }
+  const int e = threadIdx.x / COLS, j = threadIdx.x % COLS;
+  const int jc = j < N ? j : 0;   // lanes beyond the last column repeat column 0 and add nothing
+  const bool owner = j < N;
+  double acc[N], acc_b = 0.0, acc_s = 0.0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) acc[k] = 0.0;
+#if MODE == 2
+  S xj[N], inv_h = S(0);   // this lane's perturbed vector x + h_j e_j (linearization.h:89) and 1 / h_j
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    xj[k] = A.x[k] + (k == jc ? A.h[k] : S(0));
+    inv_h = k == jc ? S(1) / A.h[k] : inv_h;
+  }
+#endif
+  S *Je = ldsJ + e * (M * N);
+  for (long long base = (long long)blockIdx.x * EPB; base < A.count;
+       base += (long long)gridDim.x * EPB) {
+    const long long i = base + e;
+    const bool valid = i < A.count;   // the padding slots repeat the last element with weight zero
+    const long long at = valid ? i : A.count - 1;
+    S d[D > 0 ? D : 1];
+#pragma unroll
+    for (int p = 0; p < D; ++p) d[p] = A.data[p * A.stride + at];
+    S r[M];
+    user_residual(A.x, aux, d, r);
+    S rr = 0;
+#pragma unroll
+    for (int a = 0; a < M; ++a) rr += r[a] * r[a];
+    rr = valid ? rr : S(0);
+#if MODE == 0
+    if (j == 0) acc_s += (double)rr;
+#else
+    S Jc[M];
+#if MODE == 2
+    {
+      S rp[M];
+      user_residual(xj, aux + (1 + jc) * AUX, d, rp);
+#pragma unroll
+      for (int a = 0; a < M; ++a) Jc[a] = (rp[a] - r[a]) * inv_h;   // :105
+      if (owner) {
+#pragma unroll
+        for (int a = 0; a < M; ++a) Je[a * N + j] = Jc[a];
+      }
+    }
+    __syncthreads();
+#else
+    if (j == 0) user_jacobian(A.x, aux, d, Je);   // row-major M x N, as IBaseModel::f_df fills it
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < M; ++a) Jc[a] = Je[a * N + jc];
+#endif
+    S w = 1;
+    if (A.loss_kind == 1) {
+      const S den = rr + A.loss_param;
+      w = (A.loss_param * A.loss_param) / (den * den);
+    }
+    w = valid ? w : S(0);
+    S SJc[M], Sr[M];
+#pragma unroll
+    for (int a = 0; a < M; ++a) {
+      S v = 0, u = 0;
+#pragma unroll
+      for (int c = 0; c < M; ++c) {
+        v += A.cov[a * M + c] * Jc[c];
+        u += A.cov[a * M + c] * r[c];
+      }
+      SJc[a] = v;
+      Sr[a] = u;
+    }
+    if (owner) {
+#pragma unroll
+      for (int i2 = 0; i2 < N; ++i2) {
+        S v = 0;
+#pragma unroll
+        for (int a = 0; a < M; ++a) v += (w * Je[a * N + i2]) * SJc[a];
+        acc[i2] += (double)v;   // H(i2, j)
+      }
+      S v = 0;
+#pragma unroll
+      for (int a = 0; a < M; ++a) v += (w * Jc[a]) * Sr[a];
+      acc_b += (double)v;       // b(j)
+    }
+    if (j == 0) acc_s += (double)rr;
+    __syncthreads();            // the Jacobians are rewritten by the next step
+#endif
+  }
+  __syncthreads();
+  double *mine = pool + (size_t)threadIdx.x * (N + 2);
+#pragma unroll
+  for (int k = 0; k < N; ++k) mine[k] = acc[k];
+  mine[N] = acc_b;
+  mine[N + 1] = acc_s;
+  __syncthreads();
+  double *out_row = A.partials + (size_t)blockIdx.x * NACC;
+  for (int t = threadIdx.x; t < NACC; t += kBlock) {
+    int col = 0, k = N + 1;             // the sum of squares: lane 0 of every element
+#if MODE != 0
+    if (t < N * N) {
+      col = t / N; k = t % N;            // H(k, col), column-major
+    } else if (t < N * N + N) {
+      col = t - N * N; k = N;            // b(col)
+    }
+#endif
+    double v = 0.0;
+    for (int s = 0; s < EPB; ++s) v += pool[(size_t)(s * COLS + col) * (N + 2) + k];
+    out_row[t] = v;
+  }
+}
+)JIT";
+
 std::string &jitError() {
   static thread_local std::string e;
   return e;
@@ -291,7 +454,8 @@ bool compileVariant(JitKernel &k, int mode, bool cov_symmetric, JitVariant &out)
     return false;
   }
   if (hipModuleGetFunction(&out.sweep, out.module, "mopt_jit_sweep") != hipSuccess ||
-      hipModuleGetFunction(&out.sweep_resident, out.module, "mopt_jit_sweep_resident") != hipSuccess) {
+      (!k.wide && hipModuleGetFunction(&out.sweep_resident, out.module, "mopt_jit_sweep_resident") !=
+                      hipSuccess)) {
     jitError() = "compiled model has no mopt_jit_sweep";
     (void)hipModuleUnload(out.module);
     out.module = nullptr;
@@ -308,19 +472,21 @@ const char *jitLastError() { return jitError().c_str(); }
 bool jitCreate(int scalar_bytes, int n_params, int n_outputs, int n_planes, int n_aux,
                const char *setup_body, const char *residual_body, const char *jacobian_body,
                JitKernel &out) {
-  if (!residual_body || n_params < 1 || n_params > kMaxParams || n_outputs < 1 || n_outputs > 4 ||
-      n_planes < 0 || n_planes > 16 || n_aux < 0 || n_aux > 64 || (n_aux > 0 && !setup_body)) {
-    jitError() = "bad model shape (1 <= n <= 8, 1 <= m <= 4, planes <= 16, aux <= 64 with a setup "
+  if (!residual_body || n_params < 1 || n_params > kMaxWideParams || n_outputs < 1 ||
+      n_outputs > kMaxWideOutputs || n_planes < 0 || n_planes > 16 || n_aux < 0 || n_aux > 64 ||
+      (n_aux > 0 && !setup_body)) {
+    jitError() = "bad model shape (1 <= n <= 16, 1 <= m <= 16, planes <= 16, aux <= 64 with a setup "
                  "source) or no residual source";
     return false;
   }
+  out.wide = n_params > kMaxParams || n_outputs > 4;
   out.scalar_bytes = scalar_bytes;
   out.n_params = n_params;
   out.n_outputs = n_outputs;
   out.n_planes = n_planes;
   out.n_aux = n_aux;
   out.has_jacobian = jacobian_body && *jacobian_body;
-  out.source = kJitPrologue;
+  out.source = out.wide ? kJitWidePrologue : kJitPrologue;
   out.source += "__device__ inline void user_setup(const S *x, S *a) {\n";
   out.source += (n_aux > 0 && setup_body) ? setup_body : "";
   out.source += "\n}\n__device__ inline void user_residual(const S *x, const S *a, const S *d, S *r) {\n";
@@ -328,7 +494,7 @@ bool jitCreate(int scalar_bytes, int n_params, int n_outputs, int n_planes, int 
   out.source += "\n}\n__device__ inline void user_jacobian(const S *x, const S *a, const S *d, S *J) {\n";
   out.source += jacobian_body ? jacobian_body : "";
   out.source += "\n}\n";
-  out.source += kJitSweep;
+  out.source += out.wide ? kJitWideSweep : kJitSweep;
   // Errors in the user's text must surface at construction: build the sweeps that touch each
   // body now (cost only: setup + residual; supplied Jacobian); the others on first use.
   if (!jitVariant(out, 0, true)) return false;
@@ -337,6 +503,7 @@ bool jitCreate(int scalar_bytes, int n_params, int n_outputs, int n_planes, int 
 }
 
 const JitVariant *jitVariant(JitKernel &k, int mode, bool cov_symmetric) {
+  if (k.wide) cov_symmetric = false;  // one row form
   const int key = mode * 2 + (mode != 0 && cov_symmetric ? 1 : 0);
   JitVariant &v = k.variants[key];
   if (!v.sweep && !compileVariant(k, mode, mode == 0 || cov_symmetric, v)) return nullptr;

@@ -20,6 +20,7 @@ struct JitKernel {
   std::string source;
   int scalar_bytes = 8, n_params = 0, n_outputs = 0, n_planes = 0, n_aux = 0;
   bool has_jacobian = false;
+  bool wide = false;  // n > 8 or m > 4: the column-per-lane sweep (JitWideArgs, rows of n*n + n + 1)
   JitVariant variants[6];  // [mode * 2 + cov_symmetric]; mode 0 (cost only) uses slot 0
 };
 
@@ -38,6 +39,22 @@ struct JitArgs {
   S cov[16];
   double *partials;
 };
+
+// The wide sweep's argument block (n <= 16, m <= 16; no resident form).
+template <typename S>
+struct JitWideArgs {
+  const S *data;
+  long long count;
+  long long stride;
+  int loss_kind;
+  int pad_[3];
+  S loss_param;
+  S x[kMaxWideParams];
+  S h[kMaxWideParams];
+  S cov[kMaxWideOutputs * kMaxWideOutputs];  // row-major M x M
+  double *partials;
+};
+constexpr int kJitWideElementsPerBlock = 16;  // 256 threads = 16 elements x 16 column lanes
 
 // Validates the shape, assembles the source and compiles the sweeps that exercise every user body.
 bool jitCreate(int scalar_bytes, int n_params, int n_outputs, int n_planes, int n_aux,

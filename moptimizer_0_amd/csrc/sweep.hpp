@@ -10,6 +10,8 @@ namespace mopt {
 constexpr int kBlockThreads = 256;  // 4 wavefronts of 64
 constexpr int kNumParams = 6;       // (t, w) of SE(3)
 constexpr int kMaxParams = 8;       // small parametric models (scalarModelKernel)
+constexpr int kMaxWideParams = 16;  // run-time compiled models with n > 8 or m > 4 (jit_model.cpp,
+constexpr int kMaxWideOutputs = 16; // "wide" sweep: tst/state_model.cpp is n = m = 15)
 
 // ---- HBM layout ----------------------------------------------------------------------------
 // Correspondences live in HBM as *tiled structure-of-arrays*: a tile holds kBlockThreads * V

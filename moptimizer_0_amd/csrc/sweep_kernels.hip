@@ -981,7 +981,7 @@ __global__ void relayoutReprojKernel(const double *__restrict__ pts, const int *
 // independent and in flight together — the kernel costs about one memory round trip, not one
 // per row.  Column totals are then formed in a fixed order (bitwise reproducible).
 constexpr int kFinalThreads = 1024;
-constexpr int kMaxAccumulators = 128;  // n <= 8: n*n + n + 1 <= 73
+constexpr int kMaxAccumulators = 288;  // n <= 16 (run-time compiled wide models): n*n + n + 1 <= 273
 
 // Write-through store at system scope (sc0 sc1): straight to mapped host memory, nothing left
 // dirty in L2, so publishing needs no L2 write-back (a system-scope release fence costs two).
@@ -1441,8 +1441,9 @@ hipError_t launchReprojCost(const ReprojSweepArgs &args, int grid, const LaunchS
 hipError_t launchFinalizeDense(const double *partials, int grid, int nacc, int n, double *result,
                                const HostPublish &pub, hipStream_t stream,
                                const PeerCombine *peers) {
-  if (n < 1 || n > kMaxParams || (nacc != n * (n + 1) / 2 + n + 1 && nacc != n * n + n + 1))
+  if (n < 1 || n > kMaxWideParams || (nacc != n * (n + 1) / 2 + n + 1 && nacc != n * n + n + 1))
     return hipErrorInvalidValue;
+  if (peers && peers->num_ranks > 0 && n * n + n + 1 > kSlotData) return hipErrorInvalidValue;
   hipLaunchKernelGGL(finalizeDenseKernel, dim3(1), dim3(kFinalThreads), 0, stream, partials, grid,
                      nacc, n, result, pub, peers ? *peers : PeerCombine());
   return hipGetLastError();
@@ -1573,7 +1574,7 @@ hipError_t launchPublishCounter(unsigned int *d_counter, const HostPublish &pub,
 hipError_t launchPublish(const double *d_values, int count, const HostPublish &pub,
                          hipStream_t stream) {
   if (count < 0 || count > kMaxAccumulators) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(publishKernel, dim3(1), dim3(kMaxAccumulators), 0, stream, d_values, count, pub);
+  hipLaunchKernelGGL(publishKernel, dim3(1), dim3((kMaxAccumulators + 63) / 64 * 64), 0, stream, d_values, count, pub);
   return hipGetLastError();
 }
 

@@ -333,6 +333,47 @@ int oracle_se3_from_x(const double *x, double *T16, double *T16_plus /* 6*16 or 
   return 0;
 }
 
+// tst/state_model.cpp:83-112: StateModel(x_init) under CostFunctionNumericalDynamic(model, 15, 15, 1).
+// cov: 15 x 15 column-major or NULL.  H: 225 column-major, b: 15.
+int oracle_state_linearize(const double *x_init, const double *x, const double *cov, int loss_kind,
+                           double loss_param, double *H, double *b, double *cost) {
+  try {
+    auto c = makeCost<double>(kNumericDyn, std::make_shared<oracle::StateModel>(x_init), 15, 15, 1, cov,
+                              loss_kind, loss_param);
+    *cost = c->linearize(x, H, b);
+    return 0;
+  } catch (...) {
+    return -2;
+  }
+}
+
+int oracle_state_cost(const double *x_init, const double *x, double *cost) {
+  try {
+    auto c = makeCost<double>(kNumericDyn, std::make_shared<oracle::StateModel>(x_init), 15, 15, 1,
+                              nullptr, 0, 0.0);
+    *cost = c->computeCost(x);
+    return 0;
+  } catch (...) {
+    return -2;
+  }
+}
+
+// LevenbergMarquadtDynamic<double> lm(15); lm.addCost(&cost); lm.minimize(x)  (:99, :108-109)
+int oracle_state_minimize(const double *x_init, double *x, int max_iter, int *status, int *iterations) {
+  try {
+    auto c = makeCost<double>(kNumericDyn, std::make_shared<oracle::StateModel>(x_init), 15, 15, 1,
+                              nullptr, 0, 0.0);
+    moptimizer::LevenbergMarquadtDynamic<double> lm(15);
+    lm.setMaximumIterations(max_iter);
+    lm.addCost(c.get());
+    *status = int(lm.minimize(x));
+    *iterations = int(lm.getExecutedIterations());
+    return 0;
+  } catch (...) {
+    return -2;
+  }
+}
+
 int oracle_hardware_threads(void) { return int(std::thread::hardware_concurrency()); }
 
 }  // extern "C"

@@ -14,6 +14,8 @@
 //   Differentiation.SimpleModel/PowellModel tst/differentiation.cpp:47-77,134-161
 //   testCovariance.set*Covariance           tst/covariance.cpp:26-63
 //   ParallelCostTest.ComputeCost            tst/parallel.cpp:70-94
+//   StateModel.Optimize                     tst/state_model.cpp:83-112 (asserts nothing there; the
+//                                           residual is x (-) x_init, so x_init is the answer)
 // The point2point cases (tst/point2point.cpp:142-217) need the façade cloud and are replayed
 // from tests/test_oracle_golden.py through oracle_capi.cpp.
 //
@@ -273,7 +275,23 @@ void parallelCost() {
 
 }  // namespace
 
+void stateModel() {
+  double x_init[15] = {0.6, 0.8, 0.3, -0.4, 0.11, -0.9};  // :88
+  double x[15] = {0.1, 0.2, 0.3, 0.4, 0.5, 0.6};           // :89
+  auto model = std::make_shared<oracle::StateModel>(x_init);
+  LevenbergMarquadtDynamic<double> lm(15);                                  // :99
+  oracle::CostFunctionNumericalDynamic<double> cost(model, 15, 15, 1);      // :101
+  lm.addCost(&cost);
+  lm.minimize(x);                                                           // :109
+  for (int i = 0; i < 15; ++i) {
+    char label[64];
+    std::snprintf(label, sizeof label, "StateModel.Optimize x[%d]", i);
+    expectNear(label, x[i], x_init[i], 1e-8);
+  }
+}
+
 int main() {
+  stateModel();
   curveFitting();
   powell();
   simpleModelFloat();

@@ -4,6 +4,7 @@
 // product's closed-form include/moptimizer_amd/so3.hpp so that each checks the other:
 //   so3::convert6DOFParameterToMatrix   /root/reference/src/so3.cpp:7-19
 //   so3::Exp(Ref, Ref)                  /root/reference/src/so3.cpp:43-57
+//   so3::Log                            /root/reference/src/so3.cpp:94-105
 //   SKEW_SYMMETRIC_FROM                 /root/reference/include/moptimizer/so3.h:4
 #pragma once
 
@@ -87,6 +88,17 @@ ORACLE_SO3_EXACT inline Mat3<Scalar> Exp(const Scalar delta[3]) {
       for (int j = 0; j < 3; ++j) R.v[i][j] = (i == j) ? Scalar(1) : Scalar(0);  // :54
   }
   return R;
+}
+
+// so3::Log (/root/reference/src/so3.cpp:94-105): theta = 0 when trace > 3 - 1e-6, else
+// acos((trace - 1) / 2); delta = K / 2 for |theta| < 1e-3, else theta / (2 sin theta) K.
+template <typename Scalar>
+inline void Log(const Mat3<Scalar> &R, Scalar delta[3]) {
+  const Scalar trace = R.v[0][0] + R.v[1][1] + R.v[2][2];
+  const Scalar theta = (trace > 3.0 - 1e-6) ? Scalar(0.0) : std::acos(Scalar(0.5) * (trace - 1));  // :97
+  const Scalar K[3] = {R.v[2][1] - R.v[1][2], R.v[0][2] - R.v[2][0], R.v[1][0] - R.v[0][1]};      // :98
+  const Scalar k = (std::fabs(theta) < 0.001) ? Scalar(0.5) : Scalar(0.5) * theta / std::sin(theta);
+  for (int i = 0; i < 3; ++i) delta[i] = k * K[i];  // :100, :102
 }
 
 // Column-major 4x4, as Eigen::Matrix<Scalar,4,4>::data().

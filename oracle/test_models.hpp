@@ -9,6 +9,7 @@
 //   RationalModel      /root/reference/tst/test_models.h:7-20 (`Model`), with the Jacobian of
 //                      SimpleModel, tst/differentiation.cpp:15-41
 //   Point2PointDist    /root/reference/tst/parallel.cpp:12-34
+//   StateModel         /root/reference/tst/state_model.cpp:14-80 (n = m = 15, one residual block)
 // Point data are packed xyz triples (what std::vector<Eigen::Vector3d>::data() is).
 #pragma once
 
@@ -265,6 +266,47 @@ class Point2PointDist : public moptimizer::BaseModel<double, Point2PointDist> {
  private:
   const double *src_;
   const double *tgt_;
+};
+
+// tst/state_model.cpp:14-80: a state made of a rotation (x[0..2], through Exp) and twelve linear
+// components (x[3..14]); the residual is the difference to a fixed state, x_k (-) x_k0:
+// Log(R0^T R) for the rotation (:40-45), lin - lin0 for the rest (:38).  One residual block of 15
+// values over 15 parameters; the test drives it through CostFunctionNumericalDynamic (:101) — its
+// f_df fills no Jacobian (:69-77), which is kept.
+class StateModel : public moptimizer::BaseModelJacobian<double, StateModel> {
+ public:
+  explicit StateModel(const double *x_init) { compose(x_init, rot0_, lin0_); }  // :15-20, :55
+
+  void setup(const double *) override {}  // :56
+
+  bool f(const double *x, double *f_x, unsigned int) const override {  // :58-68
+    so3::Mat3<double> rot;
+    double lin[12];
+    compose(x, rot, lin);
+    so3::Mat3<double> rel;  // rhs.rot_^T * this->rot_ (:41)
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        double v = 0;
+        for (int k = 0; k < 3; ++k) v += rot0_.v[k][i] * rot.v[k][j];
+        rel.v[i][j] = v;
+      }
+    so3::Log<double>(rel, f_x);                                // :43-44
+    for (int i = 0; i < 12; ++i) f_x[3 + i] = lin[i] - lin0_[i];  // :39
+    return true;
+  }
+
+  bool f_df(const double *x, double *f_x, double *, unsigned int index) const override {  // :69-77
+    return f(x, f_x, index);
+  }
+
+ private:
+  static void compose(const double *x, so3::Mat3<double> &rot, double lin[12]) {  // :15-20
+    const double w[3] = {x[0], x[1], x[2]};
+    rot = so3::Exp<double>(w);
+    for (int i = 0; i < 12; ++i) lin[i] = x[i + 3];
+  }
+  so3::Mat3<double> rot0_;
+  double lin0_[12];
 };
 
 }  // namespace oracle

@@ -1,7 +1,7 @@
 // Drop-in check, C++ side, for the reference's remaining known-answer tests: the same programs
 // as tst/curve_fitting.cpp:101-147, tst/powell.cpp:62-136, tst/simple_model.cpp:28-82,
 // tst/loss_function.cpp:45-60, tst/covariance.cpp:26-63, tst/multiple_objectives.cpp:102-132 and
-// tst/differentiation.cpp:47-77,134-161, with `moptimizer::hip::` cost classes and device models
+// tst/differentiation.cpp:47-77,134-161 and tst/state_model.cpp:83-112, with `moptimizer::hip::` cost classes and device models
 // in place of the CPU ones and the LM loop unchanged.  Expected values and tolerances are the
 // reference's.  (curve_data.inc is the reference tests' data table; oracle/ is only its holder.)
 #include <cmath>
@@ -227,8 +227,62 @@ static void userDefinedModel() {
   expectNear("UserModel(jit) source error surfaces as moptimizer::Exception", threw ? 1 : 0, 1, 0);
 }
 
+// tst/state_model.cpp:83-112: StateModel (n = m = 15, one residual block: x (-) x_init with the
+// rotation part through Exp / Log) under CostFunctionNumericalDynamic(model, 15, 15, 1) and
+// LevenbergMarquadtDynamic<double> lm(15).  The reference's test asserts nothing; the residual
+// vanishes at x_init and nowhere else, so that is what the solve must return.
+static void stateModel() {
+  const char *residual = R"SRC(
+  auto Exp = [](const S *w, S (&R)[9]) {
+    const S t = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    for (int k = 0; k < 9; ++k) R[k] = (k % 4 == 0) ? S(1) : S(0);
+    if (t > S(10) * S(2.220446049250313e-16)) {
+      const S a[3] = {w[0] / t, w[1] / t, w[2] / t};
+      const S K[9] = {0, -a[2], a[1], a[2], 0, -a[0], -a[1], a[0], 0};
+      const S s = sin(t), c1 = S(1) - cos(t);
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+          S kk = 0;
+          for (int k = 0; k < 3; ++k) kk += K[i * 3 + k] * K[k * 3 + j];
+          R[i * 3 + j] = ((i == j ? S(1) : S(0)) + s * K[i * 3 + j]) + c1 * kk;
+        }
+    }
+  };
+  S R0[9], R[9], rel[9];
+  Exp(d, R0);
+  Exp(x, R);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      S v = 0;
+      for (int k = 0; k < 3; ++k) v += R0[k * 3 + i] * R[k * 3 + j];
+      rel[i * 3 + j] = v;
+    }
+  const S trace = rel[0] + rel[4] + rel[8];
+  const S theta = (trace > S(3.0 - 1e-6)) ? S(0) : acos(S(0.5) * (trace - S(1)));
+  const S K[3] = {rel[7] - rel[5], rel[2] - rel[6], rel[3] - rel[1]};
+  const S k = (fabs(theta) < S(0.001)) ? S(0.5) : S(0.5) * theta / sin(theta);
+  for (int i = 0; i < 3; ++i) r[i] = k * K[i];
+  for (int i = 0; i < 12; ++i) r[3 + i] = x[3 + i] - d[3 + i];
+)SRC";
+  double x_init[15] = {0.6, 0.8, 0.3, -0.4, 0.11, -0.9};  // :88
+  double x[15] = {0.1, 0.2, 0.3, 0.4, 0.5, 0.6};           // :89
+  std::vector<const double *> planes;
+  for (int p = 0; p < 15; ++p) planes.push_back(&x_init[p]);
+  auto model = std::make_shared<mh::JitDeviceModel<double>>(15, 15, residual, "", planes);
+  LevenbergMarquadtDynamic<double> lm(15);                                // :99
+  mh::CostFunctionNumericalDynamic<double> cost(model, 15, 15, 1);        // :101
+  lm.addCost(&cost);                                                      // :108
+  lm.minimize(x);                                                         // :109
+  for (int i = 0; i < 15; ++i) {
+    char label[64];
+    std::snprintf(label, sizeof label, "StateModel.Optimize x[%d]", i);
+    expectNear(label, x[i], x_init[i], 1e-7);
+  }
+}
+
 int main() {
   try {
+    stateModel();
     curveFitting();
     userDefinedModel();
     powell();

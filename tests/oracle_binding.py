@@ -167,6 +167,41 @@ class Oracle:
         assert rc == 0, rc
         return H, b, s[0]
 
+    def state_linearize(self, x_init, x, cov=None, loss_kind=0, loss_param=0.0):
+        """tst/state_model.cpp: StateModel(x_init), n = m = 15, one residual block, numeric cost class."""
+        x_init = np.ascontiguousarray(x_init, dtype=np.float64)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        cov = None if cov is None else np.asfortranarray(np.asarray(cov, dtype=np.float64))
+        H = np.zeros((15, 15), order="F")
+        b = np.zeros(15)
+        s = np.zeros(1)
+        self.lib.oracle_state_linearize.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                    ctypes.c_int, ctypes.c_double, ctypes.c_void_p,
+                                                    ctypes.c_void_p, ctypes.c_void_p]
+        rc = self.lib.oracle_state_linearize(_p(x_init), _p(x), _p(cov), loss_kind, loss_param,
+                                             _p(H), _p(b), _p(s))
+        assert rc == 0, rc
+        return H, b, s[0]
+
+    def state_cost(self, x_init, x):
+        x_init = np.ascontiguousarray(x_init, dtype=np.float64)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        s = np.zeros(1)
+        self.lib.oracle_state_cost.argtypes = [ctypes.c_void_p] * 3
+        assert self.lib.oracle_state_cost(_p(x_init), _p(x), _p(s)) == 0
+        return s[0]
+
+    def state_minimize(self, x_init, x0, max_iter=15):
+        x_init = np.ascontiguousarray(x_init, dtype=np.float64)
+        x = np.array(x0, dtype=np.float64)
+        status, iters = ctypes.c_int(0), ctypes.c_int(0)
+        self.lib.oracle_state_minimize.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                                   ctypes.c_void_p, ctypes.c_void_p]
+        rc = self.lib.oracle_state_minimize(_p(x_init), _p(x), max_iter, ctypes.byref(status),
+                                            ctypes.byref(iters))
+        assert rc == 0, rc
+        return x, status.value, iters.value
+
     def se3_from_x(self, x, with_steps=False):
         x = np.ascontiguousarray(x, dtype=np.float64)
         T = np.zeros(16)

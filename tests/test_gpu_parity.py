@@ -1117,3 +1117,151 @@ def test_numeric_mode_meets_the_bar_at_every_step_size(hip_lib, oracle):
             cost.set_kernel_variant(mo.KERNEL_MOMENTS)
             check(cost.linearize(x, mo.JAC_NUMERIC), want, tol=fd_tolerance(x, 2))
     cost.close()
+
+
+# ---- wide run-time compiled models (8 < n <= 16 or 4 < m <= 16) -------------------------------------
+STATE_RESIDUAL = r"""
+  // tst/state_model.cpp:58-68: f(x) = x_k (-) x_k0, x_k0 in the element's 15 data values
+  auto Exp = [](const S *w, S (&R)[9]) {              // src/so3.cpp:43-57
+    const S t = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    for (int k = 0; k < 9; ++k) R[k] = (k % 4 == 0) ? S(1) : S(0);
+    if (t > S(10) * (sizeof(S) == 8 ? S(2.220446049250313e-16) : S(1.1920929e-7))) {
+      const S a[3] = {w[0] / t, w[1] / t, w[2] / t};
+      const S K[9] = {0, -a[2], a[1], a[2], 0, -a[0], -a[1], a[0], 0};
+      const S s = sin(t), c1 = S(1) - cos(t);
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+          S kk = 0;
+          for (int k = 0; k < 3; ++k) kk += K[i * 3 + k] * K[k * 3 + j];
+          R[i * 3 + j] = ((i == j ? S(1) : S(0)) + s * K[i * 3 + j]) + c1 * kk;
+        }
+    }
+  };
+  S R0[9], R[9], rel[9];
+  Exp(d, R0);
+  Exp(x, R);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      S v = 0;
+      for (int k = 0; k < 3; ++k) v += R0[k * 3 + i] * R[k * 3 + j];   // R0^T R  (:41)
+      rel[i * 3 + j] = v;
+    }
+  const S trace = rel[0] + rel[4] + rel[8];                              // src/so3.cpp:94-105
+  const S theta = (trace > S(3.0 - 1e-6)) ? S(0) : acos(S(0.5) * (trace - S(1)));
+  const S K[3] = {rel[7] - rel[5], rel[2] - rel[6], rel[3] - rel[1]};
+  const S k = (fabs(theta) < S(0.001)) ? S(0.5) : S(0.5) * theta / sin(theta);
+  for (int i = 0; i < 3; ++i) r[i] = k * K[i];
+  for (int i = 0; i < 12; ++i) r[3 + i] = x[3 + i] - d[3 + i];            // :39
+"""
+
+
+def test_state_model_of_the_reference_n15_m15(hip_lib, oracle):
+    """tst/state_model.cpp:83-112: a 15-parameter, 15-output model with ONE residual block under
+    CostFunctionNumericalDynamic and LevenbergMarquadtDynamic(15).  The reference's test asserts
+    nothing; here the sums are held to the CPU restatement and the solve must return the fixed
+    state (the residual is x (-) x_init)."""
+    mo = hip_lib
+    x_init = np.zeros(15)
+    x_init[:6] = [0.6, 0.8, 0.3, -0.4, 0.11, -0.9]   # :88
+    x = np.zeros(15)
+    x[:6] = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6]           # :89
+    cost = mo.JitModelCost(15, 15, STATE_RESIDUAL, planes=x_init.reshape(15, 1))
+    rng = np.random.default_rng(15)
+    points = [x, x_init + 0.01 * rng.standard_normal(15), rng.uniform(-0.9, 0.9, 15)]
+    for xk in points:
+        want = oracle.state_linearize(x_init, xk)
+        got = cost.linearize(xk, mo.JAC_NUMERIC)
+        check(got, want)
+        c, cw = cost.compute_cost(xk), oracle.state_cost(x_init, xk)
+        assert abs(c - cw) <= REL * abs(cw)
+    A = rng.standard_normal((15, 15))
+    cov = A @ A.T / 15 + np.eye(15)
+    cost.set_covariance(cov)
+    cost.set_loss(mo.LOSS_GEMAN_MCCLURE, 2.0)
+    check(cost.linearize(x, mo.JAC_NUMERIC),
+          oracle.state_linearize(x_init, x, cov=cov, loss_kind=1, loss_param=2.0))
+    cost.set_covariance(None)
+    cost.set_loss(mo.LOSS_NONE, 0.0)
+    with pytest.raises(mo.capi.MoptError):   # no f_df, as the reference's BaseModel throws (model.h:29-33)
+        cost.linearize(x, mo.JAC_ANALYTIC)
+    with pytest.raises(mo.capi.MoptError):   # the device-resident loop keeps its state for n <= 8
+        mo.capi.lm_minimize([cost], [mo.JAC_NUMERIC], x)
+
+    # lm.addCost(&cost); lm.minimize(x) (:108-109) as the host loop over the HIP cost
+    def host_loop(x0, max_iter=15, lm_iter=3):
+        xc, lam, eps = np.array(x0), -1.0, np.finfo(np.float64).eps
+        for it in range(max_iter):
+            H, b, y0 = cost.linearize(xc, mo.JAC_NUMERIC)
+            if abs(y0) < 8 * eps:
+                return xc, 0, it
+            if lam < 0:
+                lam = 1e-9 * np.abs(np.diag(H)).max()
+            nu = 2.0
+            for _ in range(lm_iter):
+                delta = np.linalg.solve(H + lam * np.diag(np.diag(H)), -b)
+                xi = xc + delta
+                yi = cost.compute_cost(xi)
+                rho = (y0 - yi) / delta.dot(lam * delta - b)
+                if rho < 0:
+                    if np.abs(delta).max() < np.sqrt(eps):
+                        return xc, 2, it
+                    lam *= nu
+                    nu *= 2
+                    continue
+                xc = xi
+                lam *= max(1.0 / 3.0, 1 - (2 * rho - 1) ** 3)
+                break
+        return xc, 1, max_iter
+    xs, status, iters = host_loop(x)
+    xo, so, io = oracle.state_minimize(x_init, x)
+    assert status == so and abs(iters - io) <= 1, (status, iters, so, io)
+    assert np.abs(xs - x_init).max() < 1e-7 and np.abs(xs - xo).max() < 1e-7, (xs, xo)
+    cost.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_wide_model_with_supplied_jacobian_against_numpy(hip_lib, dtype):
+    """n = 12, m = 6 over many elements: r_a = sum_k cos((a + 1)(k + 1) t) x_k - y_a, Jacobian supplied;
+    ragged counts around the 16 elements a workgroup takes per step; covariance and robust loss."""
+    mo = hip_lib
+    n, m = 12, 6
+    residual = """
+  for (int a = 0; a < 6; ++a) {
+    S v = 0;
+    for (int k = 0; k < 12; ++k) v += cos(S((a + 1) * (k + 1)) * d[0]) * x[k];
+    r[a] = v - d[1 + a];
+  }"""
+    jacobian = """
+  for (int a = 0; a < 6; ++a)
+    for (int k = 0; k < 12; ++k) J[a * 12 + k] = cos(S((a + 1) * (k + 1)) * d[0]);"""
+    rng = np.random.default_rng(12)
+    x_true = rng.uniform(-1, 1, n)
+    A0 = rng.standard_normal((m, m))
+    cov = A0 @ A0.T / m + np.eye(m)
+    tol = REL if dtype == np.float64 else 2e-3
+    for count in (1, 15, 16, 17, 5000):
+        t = rng.uniform(0.0, 3.0, count)
+        a_idx, k_idx = np.arange(1, m + 1)[:, None], np.arange(1, n + 1)[None, :]
+        J = np.cos((a_idx * k_idx)[None, :, :] * t[:, None, None])          # count x m x n
+        y = J @ x_true + 0.05 * rng.standard_normal((count, m))
+        planes = np.vstack([t[None, :], y.T]).astype(dtype)
+        cost = mo.JitModelCost(n, m, residual, jacobian_body=jacobian, planes=planes, dtype=dtype)
+        x = (x_true + 0.1 * rng.standard_normal(n)).astype(dtype)
+        Jd = np.cos((a_idx * k_idx)[None, :, :] * planes[0].astype(np.float64)[:, None, None])
+        r = Jd @ x.astype(np.float64) - planes[1:].T.astype(np.float64)
+        for use_cov, loss in ((False, 0.0), (True, 5.0)):
+            S = cov if use_cov else np.eye(m)
+            cost.set_covariance(cov.astype(dtype) if use_cov else None)
+            cost.set_loss(mo.LOSS_GEMAN_MCCLURE if loss else mo.LOSS_NONE, loss)
+            rr = (r * r).sum(axis=1)
+            w = (loss * loss) / (rr + loss) ** 2 if loss else np.ones(count)
+            Hw = np.einsum("i,iam,ab,ibn->mn", w, Jd, S, Jd)
+            bw = np.einsum("i,iam,ab,ib->m", w, Jd, S, r)
+            for jac in (mo.JAC_ANALYTIC, mo.JAC_NUMERIC):
+                H, b, s = cost.linearize(x, jac)
+                jt = tol if jac == mo.JAC_ANALYTIC or dtype == np.float64 else 5e-2  # fp32 differences
+                assert np.abs(H - Hw).max() <= jt * np.abs(Hw).max(), (count, use_cov, jac)
+                assert np.abs(b - bw).max() <= jt * max(np.abs(bw).max(), np.abs(Hw).max() * 1e-3), (count, jac)
+                assert abs(s - rr.sum()) <= tol * rr.sum()
+            assert abs(cost.compute_cost(x) - rr.sum()) <= tol * rr.sum()
+        cost.close()
