@@ -1219,27 +1219,29 @@ def test_state_model_of_the_reference_n15_m15(hip_lib, oracle):
     cost.close()
 
 
-@pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_wide_model_with_supplied_jacobian_against_numpy(hip_lib, dtype):
-    """n = 12, m = 6 over many elements: r_a = sum_k cos((a + 1)(k + 1) t) x_k - y_a, Jacobian supplied;
-    ragged counts around the 16 elements a workgroup takes per step; covariance and robust loss."""
+@pytest.mark.parametrize("dtype,n,m", [(np.float64, 12, 6), (np.float32, 12, 6), (np.float64, 3, 7),
+                                       (np.float64, 16, 15), (np.float64, 9, 1)])
+def test_wide_model_with_supplied_jacobian_against_numpy(hip_lib, dtype, n, m):
+    """Models beyond n = 8 or m = 4 over many elements: r_a = sum_k cos((a + 1)(k + 1) t) x_k - y_a with
+    the Jacobian supplied; ragged counts around the 16 elements a workgroup takes per step; covariance
+    and robust loss.  Shapes: wide in n, wide in m only, both at the limit, and n = 9 with one output."""
     mo = hip_lib
-    n, m = 12, 6
     residual = """
-  for (int a = 0; a < 6; ++a) {
+  for (int a = 0; a < %d; ++a) {
     S v = 0;
-    for (int k = 0; k < 12; ++k) v += cos(S((a + 1) * (k + 1)) * d[0]) * x[k];
+    for (int k = 0; k < %d; ++k) v += cos(S((a + 1) * (k + 1)) * d[0]) * x[k];
     r[a] = v - d[1 + a];
-  }"""
+  }""" % (m, n)
     jacobian = """
-  for (int a = 0; a < 6; ++a)
-    for (int k = 0; k < 12; ++k) J[a * 12 + k] = cos(S((a + 1) * (k + 1)) * d[0]);"""
+  for (int a = 0; a < %d; ++a)
+    for (int k = 0; k < %d; ++k) J[a * %d + k] = cos(S((a + 1) * (k + 1)) * d[0]);""" % (m, n, n)
     rng = np.random.default_rng(12)
     x_true = rng.uniform(-1, 1, n)
     A0 = rng.standard_normal((m, m))
     cov = A0 @ A0.T / m + np.eye(m)
     tol = REL if dtype == np.float64 else 2e-3
-    for count in (1, 15, 16, 17, 5000):
+    # (each count compiles its own model: the full set of ragged counts for the first shape only)
+    for count in ((1, 15, 16, 17, 5000) if (n, m) == (12, 6) and dtype == np.float64 else (17, 700)):
         t = rng.uniform(0.0, 3.0, count)
         a_idx, k_idx = np.arange(1, m + 1)[:, None], np.arange(1, n + 1)[None, :]
         J = np.cos((a_idx * k_idx)[None, :, :] * t[:, None, None])          # count x m x n
