@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <initializer_list>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -300,6 +301,21 @@ class DeviceCostAccess {
   virtual int deviceJacobianMode() const = 0;
   virtual void syncDeviceState() = 0;  // forward the current loss / covariance to the device
 };
+
+// The costs an optimizer is going to hold (`optimizer.addCost(&a); optimizer.addCost(&b);`): its loop
+// asks them one after the other at the same x (levenberg_marquadt_dyn.cpp:52-59, :86).  Linked, the
+// first one asked queues the others' sweeps as well (mopt_costs_link): one launch path per evaluated
+// point instead of one per cost.  The loop itself is unchanged.  Costs that are not HIP costs, or
+// are sharded over a device group, are left out.
+template <class Scalar>
+inline void linkCosts(std::initializer_list<CostFunctionBase<Scalar> *> costs) {
+  std::vector<mopt_cost *> handles;
+  for (CostFunctionBase<Scalar> *c : costs) {
+    auto *access = dynamic_cast<DeviceCostAccess *>(c);
+    if (access && access->deviceCost()) handles.push_back(access->deviceCost());
+  }
+  throwOnError(mopt_costs_link(handles.data(), int(handles.size())), "mopt_costs_link");
+}
 
 // Shared implementation; JacobianMode selects what linearize() means.
 template <class Scalar, int JacobianMode>

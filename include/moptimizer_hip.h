@@ -243,6 +243,22 @@ MOPT_API int mopt_cost_set_speculation(mopt_cost *cost, int enabled);
 /* sweeps launched and calls answered from the kept result since creation */
 MOPT_API int mopt_cost_stats(const mopt_cost *cost, int64_t *sweeps, int64_t *cache_hits);
 
+/* Costs of one problem.  The optimizer asks the costs it holds one after the other at the same x:
+ * `for (cost : costs_) { cost->update(x0); y0 += cost->linearize(x0, H, b); ... }` and the same for
+ * the trial cost (src/levenberg_marquadt_dyn.cpp:52-59, :86) — with blocking calls that is one launch
+ * path per cost, back to back.  After mopt_costs_link(costs, n) the first of them asked at some x also
+ * queues the sweep each of the others is going to be asked for at that x (its linearization in the
+ * mode it was last linearized in, or what its mopt_cost_compute would run), each on its own stream;
+ * the others' calls find their sweep in flight and only wait for it.  Results are those of the
+ * unlinked calls, bit for bit (the same kernels on the same inputs); a cost asked at a different x
+ * than was guessed simply runs its sweep, the queued one is discarded.  Linked costs are used from
+ * one thread.  Not queued ahead: sharded costs (their sums need every rank's call) and ICP costs
+ * (their update(x) must run first).  num_costs <= 1 (or costs == NULL with 0) unlinks.
+ * BASELINE config 5 (two reprojection costs): 49.3 -> 32.7 us per linearization of both. */
+MOPT_API int mopt_costs_link(mopt_cost *const *costs, int num_costs);
+/* blocking calls of this cost that were answered by a sweep a linked cost had queued */
+MOPT_API int mopt_cost_link_stats(const mopt_cost *cost, int64_t *answered_ahead);
+
 /* ---- asynchronous sweeps (shard partials stay in HBM) -------------------------------------- */
 
 /* Enqueue on `hip_stream` and return at once.  hip_stream is a hipStream_t passed as a pointer;

@@ -99,6 +99,8 @@ def load():
         "mopt_cost_stream": [ctypes.c_void_p, c_void_pp],
         "mopt_cost_synchronize": [ctypes.c_void_p],
         "mopt_cost_set_speculation": [ctypes.c_void_p, ctypes.c_int],
+        "mopt_costs_link": [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int],
+        "mopt_cost_link_stats": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)],
         "mopt_cost_stats": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64),
                             ctypes.POINTER(ctypes.c_int64)],
         "mopt_comm_unique_id": [ctypes.c_void_p, ctypes.c_int],
@@ -188,6 +190,13 @@ def se3_plus(x, delta, dtype=np.float64):
     return out
 
 
+def link_costs(costs):
+    """mopt_costs_link: the costs of one problem, asked one after the other at the same x by the
+    optimizer's loop — the first one asked queues the others' sweeps too.  [] or one cost unlinks."""
+    handles = (ctypes.c_void_p * max(len(costs), 1))(*[c._h for c in costs])
+    check(load().mopt_costs_link(handles, len(costs)))
+
+
 def lm_minimize(costs, jac_modes, x0, max_iterations=15, lm_max_iterations=3, window=0,
                 manifold=False):
     """Device-resident LevenbergMarquadtDynamic::minimize over `costs` (mopt_lm_minimize).
@@ -239,6 +248,12 @@ class _CostBase:
 
     def set_speculation(self, enabled):
         check(load().mopt_cost_set_speculation(self._h, 1 if enabled else 0))
+
+    def answered_ahead(self):
+        """blocking calls answered by a sweep a linked cost had queued (mopt_costs_link)"""
+        hits = ctypes.c_int64(0)
+        check(load().mopt_cost_link_stats(self._h, ctypes.byref(hits)))
+        return hits.value
 
     def stats(self):
         sweeps, hits = ctypes.c_int64(0), ctypes.c_int64(0)

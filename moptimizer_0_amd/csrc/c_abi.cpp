@@ -4,6 +4,7 @@
 // HIP cannot run the work the call returns an error code.
 #include "cost_state.hpp"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -1141,6 +1142,9 @@ hipError_t quiesceCost(mopt_cost *c) {
 
 void destroyCost(mopt_cost *c) {
   if (!c) return;
+  for (mopt_cost *s : c->siblings)
+    s->siblings.erase(std::remove(s->siblings.begin(), s->siblings.end(), c), s->siblings.end());
+  c->siblings.clear();
   (void)hipSetDevice(c->device);
   (void)quiesceCost(c);
   if (c->foreign_done) (void)hipEventDestroy(c->foreign_done);
@@ -1620,7 +1624,99 @@ void cacheStore(mopt_cost *c, const void *x, int mode) {
   std::memcpy(c->cache.x, x, size_t(c->n_params) * c->scalar_bytes);
   std::memcpy(c->cache.result, c->h_result, resultCount(c) * sizeof(double));
 }
+
+// ---- linked costs: the sweeps of one problem's costs at one x, in flight together ---------------
+bool prefetchable(const mopt_cost *c) { return c->combine.mode == MOPT_COMBINE_NONE && !c->matcher; }
+
+bool prefetchMatches(const mopt_cost *c, const void *x, bool cost_only, int mode) {
+  const auto &p = c->prefetch;
+  return p.pending && p.version == c->state_version && p.cost_only == cost_only &&
+         (cost_only || p.mode == mode) &&
+         std::memcmp(p.x, x, size_t(c->n_params) * c->scalar_bytes) == 0;
+}
+
+// What mopt_cost_compute runs for this cost: the linearization sweep when its result is likely
+// to be asked for next (speculation), else the cost sweep.
+bool computeRunsLinearization(const mopt_cost *c) {
+  return c->speculate && c->last_jac_mode >= 0 && speculationPays(c);
+}
+
+// `c` has just been asked at x (`linearize_call`: for a linearization, else for a cost): queue for
+// every linked cost the sweep its own call at this x is going to want.  A guess that turns out
+// wrong costs one unused sweep; failures here are left for the sibling's own call to report.
+void prefetchSiblings(mopt_cost *c, bool linearize_call, const void *x) {
+  for (mopt_cost *s : c->siblings) {
+    if (s == c || !prefetchable(s) || s->scalar_bytes != c->scalar_bytes ||
+        s->n_params != c->n_params)
+      continue;
+    bool cost_only = false;
+    int mode = s->last_jac_mode;
+    if (linearize_call) {
+      if (mode < 0 || (s->speculate && cacheMatches(s, x, mode))) continue;
+    } else {
+      if (s->speculate && cacheMatches(s, x, -1)) continue;
+      cost_only = !computeRunsLinearization(s);
+      if (cost_only) mode = 0;
+    }
+    if (prefetchMatches(s, x, cost_only, mode)) continue;  // already in flight
+    if (hipSetDevice(s->device) != hipSuccess) continue;
+    unsigned long long sequence = 0;
+    if (launchPublishedSweep(s, cost_only, mode, x, &sequence) != MOPT_OK) {
+      s->prefetch.pending = false;
+      continue;
+    }
+    s->prefetch.pending = true;
+    s->prefetch.cost_only = cost_only;
+    s->prefetch.mode = mode;
+    s->prefetch.version = s->state_version;
+    s->prefetch.sequence = sequence;
+    std::memcpy(s->prefetch.x, x, size_t(s->n_params) * s->scalar_bytes);
+  }
+}
+
+// One blocking sweep of `c`, answered by the sweep a linked cost queued for it when that matches;
+// otherwise launched now, together with the linked costs' sweeps at the same x.
+int sweepWithSiblings(mopt_cost *c, bool cost_only, int mode, const void *x, bool linearize_call) {
+  if (prefetchMatches(c, x, cost_only, mode)) {
+    c->prefetch.pending = false;
+    c->stat_prefetch_hits += 1;
+    return waitPublishedSweep(c, c->prefetch.sequence);
+  }
+  c->prefetch.pending = false;  // whatever was queued is superseded (same stream: ordered before)
+  if (c->siblings.empty() || !prefetchable(c)) return blockingSweep(c, cost_only, mode, x);
+  unsigned long long sequence = 0;
+  const int rc = launchPublishedSweep(c, cost_only, mode, x, &sequence);
+  if (rc != MOPT_OK) return rc;
+  prefetchSiblings(c, linearize_call, x);
+  MOPT_HIP_TRY(hipSetDevice(c->device));
+  return waitPublishedSweep(c, sequence);
+}
 }  // namespace
+
+int mopt_costs_link(mopt_cost *const *costs, int num_costs) {
+  if (num_costs < 0 || (num_costs > 0 && !costs))
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "bad cost list");
+  for (int k = 0; k < num_costs; ++k)
+    if (!costs[k]) return fail(MOPT_ERR_INVALID_ARGUMENT, "a cost is NULL");
+  for (int k = 0; k < num_costs; ++k) {
+    mopt_cost *c = costs[k];
+    for (mopt_cost *old : c->siblings)  // leave the group it was in
+      old->siblings.erase(std::remove(old->siblings.begin(), old->siblings.end(), c), old->siblings.end());
+    c->siblings.clear();
+  }
+  for (int k = 0; k < num_costs; ++k)
+    for (int j = 0; j < num_costs; ++j)
+      if (costs[j] != costs[k] &&
+          std::find(costs[k]->siblings.begin(), costs[k]->siblings.end(), costs[j]) == costs[k]->siblings.end())
+        costs[k]->siblings.push_back(costs[j]);
+  return MOPT_OK;
+}
+
+int mopt_cost_link_stats(const mopt_cost *c, int64_t *answered_ahead) {
+  if (!c) return fail(MOPT_ERR_INVALID_ARGUMENT, "cost is NULL");
+  if (answered_ahead) *answered_ahead = c->stat_prefetch_hits;
+  return MOPT_OK;
+}
 
 int mopt_cost_linearize(mopt_cost *c, int jacobian_mode, const void *x, void *hessian, void *b,
                         void *sum_sq) {
@@ -1639,7 +1735,7 @@ int mopt_cost_linearize(mopt_cost *c, int jacobian_mode, const void *x, void *he
   }
   noteKeptResultUnused(c);
   MOPT_HIP_TRY(hipSetDevice(c->device));
-  const int rc = blockingSweep(c, false, jacobian_mode, x);
+  const int rc = sweepWithSiblings(c, false, jacobian_mode, x, true);
   if (rc != MOPT_OK) return rc;
   c->last_jac_mode = jacobian_mode;
   if (c->speculate) cacheStore(c, x, jacobian_mode);
@@ -1656,14 +1752,14 @@ int mopt_cost_compute(mopt_cost *c, const void *x, void *sum_sq) {
   }
   MOPT_HIP_TRY(hipSetDevice(c->device));
   noteKeptResultUnused(c);
-  if (c->speculate && c->last_jac_mode >= 0 && speculationPays(c)) {
+  if (computeRunsLinearization(c)) {
     // the linearization sweep also yields sum r^T r; keep all of it for the linearize that follows
-    const int rc = blockingSweep(c, false, c->last_jac_mode, x);
+    const int rc = sweepWithSiblings(c, false, c->last_jac_mode, x, false);
     if (rc != MOPT_OK) return rc;
     cacheStore(c, x, c->last_jac_mode);
     c->spec_kept_unused = true;
   } else {
-    const int rc = blockingSweep(c, true, 0, x);
+    const int rc = sweepWithSiblings(c, true, 0, x, false);
     if (rc != MOPT_OK) return rc;
   }
   storeResult(c, c->h_result, nullptr, nullptr, sum_sq);

@@ -177,6 +177,18 @@ struct mopt_cost {
   // Sweeps enqueued on a caller's stream (the *_async entry points): the buffers of this cost must
   // not be recycled before that work has finished, and only an event on that stream can tell.
   hipEvent_t foreign_done = nullptr;
+  // Costs of one problem: the caller's loop asks them one after the other at the same x
+  // (levenberg_marquadt_dyn.cpp:52-59, :86).  Once linked (mopt_costs_link), the first one asked
+  // queues the others' sweeps at that x too, each on its own stream; their own calls then only wait.
+  std::vector<mopt_cost *> siblings;
+  struct {
+    bool pending = false;
+    bool cost_only = false;
+    int mode = 0;
+    unsigned long long version = 0, sequence = 0;
+    unsigned char x[mopt_detail::kMaxParamBytes] = {0};
+  } prefetch;
+  long long stat_prefetch_hits = 0;
   bool foreign_pending = false;
   bool own_async_pending = false;  // an asynchronous sweep was queued on this cost's own stream
 

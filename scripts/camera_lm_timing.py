@@ -35,8 +35,17 @@ def host_loop(x0, max_iter=25, lm_iter=3):
     return x, max_iter
 
 
+def linked_host_loop(x0):
+    mo.capi.link_costs(costs)   # mopt_costs_link: the first cost asked queues the other's sweep too
+    try:
+        return host_loop(x0)
+    finally:
+        mo.capi.link_costs([])
+
+
 for name, run in (("device-resident loop", lambda: mo.capi.lm_minimize(costs, [mo.JAC_NUMERIC] * 2, np.zeros(6), max_iterations=25)),
-                  ("host loop (python) ", lambda: host_loop(np.zeros(6)))):
+                  ("host loop (python) ", lambda: host_loop(np.zeros(6))),
+                  ("host loop, costs linked", lambda: linked_host_loop(np.zeros(6)))):
     best, out = 1e9, None
     for _ in range(7):
         t0 = time.perf_counter(); out = run(); best = min(best, time.perf_counter() - t0)

@@ -114,6 +114,17 @@ static void multipleObjectives() {
   expectNear("MultipleObjectives.SplitCost multi==single x[1]", x_multi[1], x_single[1], 1e-8);
   expectNear("MultipleObjectives.SplitCost x[0]", x_multi[0], 0.291861, 5e-5);
   expectNear("MultipleObjectives.SplitCost x[1]", x_multi[1], 0.131439, 5e-5);
+  // the same program with the two costs linked (the first one asked at an x queues the other's
+  // sweep too): the loop is unchanged and so is every number
+  mh::linkCosts<double>({&first, &rest});
+  LevenbergMarquadtDynamic<double> linked(2);
+  double x_linked[] = {0.0, 0.0};
+  linked.addCost(&first);
+  linked.addCost(&rest);
+  linked.minimize(x_linked);
+  expectNear("MultipleObjectives.SplitCost linked==unlinked x[0]", x_linked[0], x_multi[0], 0.0);
+  expectNear("MultipleObjectives.SplitCost linked==unlinked x[1]", x_linked[1], x_multi[1], 0.0);
+  mh::linkCosts<double>({});
 }
 
 template <typename S>

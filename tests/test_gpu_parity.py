@@ -1267,3 +1267,62 @@ def test_wide_model_with_supplied_jacobian_against_numpy(hip_lib, dtype, n, m):
                 assert abs(s - rr.sum()) <= tol * rr.sum()
             assert abs(cost.compute_cost(x) - rr.sum()) <= tol * rr.sum()
         cost.close()
+
+
+def test_linked_costs_sweep_together_and_return_the_same_numbers(hip_lib, oracle):
+    """mopt_costs_link: the optimizer's loop asks the costs of a problem one after the other at the same
+    x (levenberg_marquadt_dyn.cpp:52-59, :86); linked, the first call queues the others' sweeps too.  The
+    numbers are those of the unlinked calls bit for bit; a cost asked somewhere else than guessed still
+    answers correctly; changing a cost's state discards what was queued for it."""
+    mo = hip_lib
+    pts, pix = ds.synthetic_camera(30_000, seed=5)
+    cuts = [0, 9000, 20_000, 30_000]
+    linked = [mo.ReprojectionCost(pts[a:b], pix[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    plain = [mo.ReprojectionCost(pts[a:b], pix[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    for c in linked + plain:
+        c.set_loss(mo.LOSS_GEMAN_MCCLURE, 100.0)
+    mo.capi.link_costs(linked)
+    rng = np.random.default_rng(3)
+    xs = [rng.uniform(-0.05, 0.05, 6) for _ in range(12)]
+    for k, x in enumerate(xs):          # the loop's pattern: linearize all at x0, cost of all at xi
+        for a, b in zip(linked, plain):
+            Ha, ba, sa = a.linearize(x, mo.JAC_NUMERIC)
+            Hb, bb, sb = b.linearize(x, mo.JAC_NUMERIC)
+            assert np.array_equal(Ha, Hb) and np.array_equal(ba, bb) and sa == sb, k
+        xi = x + 1e-3
+        for a, b in zip(linked, plain):
+            assert a.compute_cost(xi) == b.compute_cost(xi), k
+    # from the second x on, every call of the 2nd and 3rd cost was answered by a queued sweep
+    assert linked[0].answered_ahead() == 0
+    assert linked[1].answered_ahead() >= 2 * (len(xs) - 1) and linked[2].answered_ahead() >= 2 * (len(xs) - 1)
+    # a different x than guessed, a different order, a state change in between
+    Hq, bq, sq = linked[2].linearize(xs[0], mo.JAC_NUMERIC)      # queues 0 and 1 at xs[0]
+    Hw, bw, sw = linked[1].linearize(xs[1], mo.JAC_NUMERIC)      # ... but 1 is asked at xs[1]
+    Hr, br, sr = plain[1].linearize(xs[1], mo.JAC_NUMERIC)
+    assert np.array_equal(Hw, Hr) and np.array_equal(bw, br) and sw == sr
+    linked[0].set_loss(mo.LOSS_NONE, 0.0)                         # what was queued for 0 is stale now
+    plain[0].set_loss(mo.LOSS_NONE, 0.0)
+    H0, b0, s0 = linked[0].linearize(xs[1], mo.JAC_NUMERIC)
+    Hp, bp, sp = plain[0].linearize(xs[1], mo.JAC_NUMERIC)
+    assert np.array_equal(H0, Hp) and np.array_equal(b0, bp) and s0 == sp
+    # a mixed group: point2point (speculating moments sweep) + reprojection
+    src, tgt = ds.synthetic_pair(20_000, seed=4, noise=0.01)
+    p2p_l, p2p_p = mo.Point2PointCost(src, tgt), mo.Point2PointCost(src, tgt)
+    mo.capi.link_costs([p2p_l, linked[1]])
+    for x in xs[:6]:
+        for (a, ja), (b, jb) in zip(((p2p_l, mo.JAC_ANALYTIC), (linked[1], mo.JAC_NUMERIC)),
+                                    ((p2p_p, mo.JAC_ANALYTIC), (plain[1], mo.JAC_NUMERIC))):
+            Ha, ba, sa = a.linearize(x, ja)
+            Hb, bb, sb = b.linearize(x, jb)
+            assert np.array_equal(Ha, Hb) and np.array_equal(ba, bb) and sa == sb
+        xi = x * 0.5
+        assert p2p_l.compute_cost(xi) == p2p_p.compute_cost(xi)
+        assert linked[1].compute_cost(xi) == plain[1].compute_cost(xi)
+    # destroying a linked cost leaves the others usable
+    linked[1].close()
+    H, b, s = p2p_l.linearize(xs[0], mo.JAC_ANALYTIC)
+    Hp, bp, sp = p2p_p.linearize(xs[0], mo.JAC_ANALYTIC)
+    assert np.array_equal(H, Hp) and s == sp
+    mo.capi.link_costs([])
+    for c in [linked[0], linked[2], p2p_l, p2p_p] + plain:
+        c.close()
