@@ -108,6 +108,11 @@ def run(args):
                 mo.ReprojectionCost(pts[8000:], pix[8000:]), [mo.JAC_NUMERIC]),
         Subject("jit/p2p", jit_p2p(), jit_p2p(), [mo.JAC_NUMERIC]),
     ]
+    # an ICP cost: its correspondences are a function of the last update(x); never queued ahead
+    tgt_cloud = tgt[rng.permutation(len(tgt))[:12_000]]
+    icp = Subject("icp", mo.IcpCost(src[:6000], tgt_cloud, 2.0), mo.IcpCost(src[:6000], tgt_cloud, 2.0),
+                  [mo.JAC_ANALYTIC, mo.JAC_NUMERIC])
+    subjects.append(icp)
     subjects[1].cost.set_kernel_variant(mo.KERNEL_LITERAL)
     subjects[1].twin.set_kernel_variant(mo.KERNEL_LITERAL)
     curve = Subject("curve", mo.ScalarModelCost(mo.capi.MODEL_EXP_CURVE, t, y),
@@ -182,7 +187,7 @@ def run(args):
             # costs of one kind per problem (a camera pose and a cloud alignment share no minimum: their
             # sum is an ill-conditioned problem whose iterates amplify forward-difference noise)
             cameras = rng.random() < 0.4
-            family = [g for g in pose if g.name.startswith("camera") == cameras]
+            family = [g for g in pose if g.name.startswith("camera") == cameras and g.name != "icp"]
             group = [family[i] for i in rng.permutation(len(family))[:rng.integers(1, len(family) + 1)]]
             modes = [g.jac_modes[-1] if g.name.startswith("camera") else g.jac_modes[0] for g in group]
             modes = [m if m != mo.JAC_ANALYTIC_LEFT else mo.JAC_ANALYTIC for m in modes]
@@ -206,6 +211,13 @@ def run(args):
                 ([(g.name, g.loss, None if g.cov is None else g.cov.tolist()) for g in group], modes,
                  x0.tolist(), k, rep, x_dev, x_host)
             note("lm_minimize")
+        elif op < 0.945:
+            xu = pick_x()
+            xu[:3] += np.array([10.5, 10.2, 0.1]) * rng.random()   # towards the fixture pose: real matches
+            na = icp.cost.update(xu)
+            nb = icp.twin.update(xu)
+            assert na == nb, ("icp update", xu, na, nb)
+            note("icp update")
         elif op < 0.96 and s.name.startswith("p2p"):
             n = int(rng.integers(100, 9000))
             a, b = ds.synthetic_pair(n, seed=int(rng.integers(1 << 30)), noise=0.02)
