@@ -46,3 +46,35 @@ for scale in (1e-8, 1e-6, 1e-4, 1e-3, 1e-2, 1e-1, 1.0):
             wH, wb = max(wH, rel(H, Hr)), max(wb, rel(b, br))
         print("| %.0e | %.1e | %s | %.1e | %.1e |" % (scale, 1.49e-8 * scale, vname, wH, wb), flush=True)
 cost.close()
+
+print()
+print("Other models against the CPU restatement (forward differences; the device evaluates exp / sin / cos / acos")
+print("with its own libm, so a last-bit difference in a residual is amplified by eps / h_j):")
+print()
+print("| model | n, m | elements | x | max|dH|/max|H| | max|db|/max|b| | |dcost|/cost |")
+print("|---|---|---|---|---|---|---|")
+pts, pix = ds.synthetic_camera(100_000, seed=17)
+cam = mo.ReprojectionCost(pts, pix)
+for x, xname in ((np.zeros(6), "0"), (np.array([-0.01, 0.02, -0.058, 0.018, -0.0013, 0.027]), "near the optimum")):
+    H, b, s = cam.linearize(x, 2)
+    Hr, br, sr = o.camera_linearize(pts, pix, x)
+    print("| reprojection (tst/camera_calibration.cpp) | 6, 2 | 100000 | %s | %.1e | %.1e | %.1e |" % (xname, rel(H, Hr), rel(b, br), abs(s - sr) / sr))
+cam.close()
+t = np.linspace(0.0, 5.0, 50_000)
+y = np.exp(0.3 * t + 0.1) + 0.01 * np.random.default_rng(2).standard_normal(t.size)
+curve = mo.ScalarModelCost(mo.capi.MODEL_EXP_CURVE, t, y)
+for x in (np.zeros(2), np.array([0.29, 0.13])):
+    H, b, s = curve.linearize(x, 2)
+    Hr, br, sr = o.scalar_linearize(1, t, y, x, numeric=True)
+    print("| exp curve (tst/curve_fitting.cpp) | 2, 1 | 50000 | %s | %.1e | %.1e | %.1e |" % (np.array2string(x), rel(H, Hr), rel(b, br), abs(s - sr) / sr))
+curve.close()
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from test_gpu_parity import STATE_RESIDUAL  # the 15-state model's residual as HIP source
+x_init = np.zeros(15); x_init[:6] = [0.6, 0.8, 0.3, -0.4, 0.11, -0.9]
+state = mo.JitModelCost(15, 15, STATE_RESIDUAL, planes=x_init.reshape(15, 1))
+xs = np.zeros(15); xs[:6] = [0.1, 0.2, 0.3, 0.4, 0.5, 0.6]
+for x, xname in ((xs, "the test's start"), (x_init + 0.01, "near the optimum")):
+    H, b, s = state.linearize(x, 2)
+    Hr, br, sr = o.state_linearize(x_init, x)
+    print("| state model (tst/state_model.cpp), wide sweep | 15, 15 | 1 | %s | %.1e | %.1e | %.1e |" % (xname, rel(H, Hr), rel(b, br), abs(s - sr) / sr))
+state.close()
