@@ -600,6 +600,9 @@ struct alignas(16) Int4Pack {
 
 __device__ __forceinline__ void reprojResidual(const double (&Mx)[12], const double (&P)[4],
                                                double u, double v, double (&r)[2]) {
+  // as written, no fused multiply-adds: the CPU restatement evaluates the same four products and
+  // three sums, and forward differences amplify a last-bit difference of a residual by eps / h_j
+#pragma clang fp contract(off)
   double o[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a)

@@ -136,7 +136,10 @@ class CameraModel : public moptimizer::BaseModel<double, CameraModel> {
     rebuildProjection();
   }
 
-  bool f(const double *, double *residual, unsigned int index) const override {
+  // evaluated as written, without contraction into fused multiply-adds: forward differences amplify
+  // a last-bit difference of a residual by eps / h_j, so checker and device sweep use one arithmetic
+  ORACLE_SO3_EXACT bool f(const double *, double *residual, unsigned int index) const override {
+    ORACLE_SO3_EXACT_BODY
     const double *P = points_ + 4 * std::size_t(index);
     double o[3];
     for (int r = 0; r < 3; ++r) {
