@@ -698,6 +698,7 @@ struct ExpCurve {
   static constexpr int N = 2, M = 1, D = 2;
   static constexpr bool kHasJacobian = false;
   __device__ static void residual(const S *x, const S *d, S (&r)[M]) {
+#pragma clang fp contract(off)  // as written: the checker's arithmetic (forward differences amplify an ulp)
     r[0] = d[1] - exp(x[0] * d[0] + x[1]);
   }
   __device__ static void jacobian(const S *, const S *, S (&)[M][N]) {}
@@ -708,6 +709,7 @@ struct Rational {
   static constexpr int N = 2, M = 1, D = 2;
   static constexpr bool kHasJacobian = true;
   __device__ static void residual(const S *x, const S *d, S (&r)[M]) {
+#pragma clang fp contract(off)  // as written: the checker's arithmetic (forward differences amplify an ulp)
     r[0] = d[1] - (x[0] * d[0]) / (x[1] + d[0]);
   }
   __device__ static void jacobian(const S *x, const S *d, S (&J)[M][N]) {
@@ -722,6 +724,7 @@ struct Powell {
   static constexpr int N = 4, M = 4, D = 0;
   static constexpr bool kHasJacobian = true;
   __device__ static void residual(const S *x, const S *, S (&r)[M]) {
+#pragma clang fp contract(off)  // as written: the checker's arithmetic (forward differences amplify an ulp)
     r[0] = x[0] + 10 * x[1];
     r[1] = sqrt(S(5)) * (x[2] - x[3]);
     r[2] = (x[1] - 2 * x[2]) * (x[1] - 2 * x[2]);

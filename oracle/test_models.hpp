@@ -187,7 +187,8 @@ class CameraModel : public moptimizer::BaseModel<double, CameraModel> {
 class CurveFittingModel : public moptimizer::BaseModel<double, CurveFittingModel> {
  public:
   explicit CurveFittingModel(const double *dataset) : dataset_(dataset) {}
-  bool f(const double *x, double *f_x, unsigned int index) const override {
+  ORACLE_SO3_EXACT bool f(const double *x, double *f_x, unsigned int index) const override {
+    ORACLE_SO3_EXACT_BODY  // as written, no fused multiply-adds (see CameraModel::f)
     const double x_ = dataset_[2 * index];
     const double y_ = dataset_[2 * index + 1];
     f_x[0] = y_ - std::exp(x[0] * x_ + x[1]);
@@ -201,7 +202,8 @@ class CurveFittingModel : public moptimizer::BaseModel<double, CurveFittingModel
 // Powell's singular function, 4 outputs, analytic row-major Jacobian.
 class PowellModel : public moptimizer::BaseModelJacobian<double, PowellModel> {
  public:
-  bool f(const double *x, double *f_x, unsigned int) const override {
+  ORACLE_SO3_EXACT bool f(const double *x, double *f_x, unsigned int) const override {
+    ORACLE_SO3_EXACT_BODY
     f_x[0] = x[0] + 10 * x[1];
     f_x[1] = std::sqrt(5.0) * (x[2] - x[3]);
     f_x[2] = (x[1] - 2 * x[2]) * (x[1] - 2 * x[2]);
@@ -240,7 +242,8 @@ template <typename Scalar>
 class RationalModel : public moptimizer::BaseModelJacobian<Scalar, RationalModel<Scalar>> {
  public:
   RationalModel(const Scalar *xs, const Scalar *ys) : data_x_(xs), data_y_(ys) {}
-  bool f(const Scalar *x, Scalar *residual, unsigned int index) const override {
+  ORACLE_SO3_EXACT bool f(const Scalar *x, Scalar *residual, unsigned int index) const override {
+    ORACLE_SO3_EXACT_BODY
     residual[0] = data_y_[index] - (x[0] * data_x_[index]) / (x[1] + data_x_[index]);
     return true;
   }

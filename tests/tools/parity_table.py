@@ -78,3 +78,16 @@ for x, xname in ((xs, "the test's start"), (x_init + 0.01, "near the optimum")):
     Hr, br, sr = o.state_linearize(x_init, x)
     print("| state model (tst/state_model.cpp), wide sweep | 15, 15 | 1 | %s | %.1e | %.1e | %.1e |" % (xname, rel(H, Hr), rel(b, br), abs(s - sr) / sr))
 state.close()
+xr = np.array([0.038, 0.194, 0.425, 0.626, 1.253, 2.5, 3.70]); yr = np.array([0.05, 0.127, 0.094, 0.2122, 0.2729, 0.2665, 0.3317])
+rat = mo.ScalarModelCost(mo.capi.MODEL_RATIONAL, xr, yr)
+for x in (np.array([0.9, 0.2]), np.array([0.362, 0.556])):
+    H, b, s = rat.linearize(x, 2)
+    Hr, br, sr = o.scalar_linearize(2, xr, yr, x, numeric=True)
+    print("| rational model (tst/test_models.h) | 2, 1 | 7 | %s | %.1e | %.1e | %.1e |" % (np.array2string(x), rel(H, Hr), rel(b, br), abs(s - sr) / sr))
+rat.close()
+pw = mo.ScalarModelCost(mo.capi.MODEL_POWELL)
+for x in (np.array([3.0, -1.0, 0.0, 4.0]), np.array([0.3, -0.1, 0.07, 0.4])):
+    H, b, s = pw.linearize(x, 2)
+    Hr, br, sr = o.scalar_linearize(3, None, None, x, numeric=True)
+    print("| Powell (tst/powell.cpp) | 4, 4 | 1 | %s | %.1e | %.1e | %.1e |" % (np.array2string(x), rel(H, Hr), rel(b, br), abs(s - sr) / sr))
+pw.close()
