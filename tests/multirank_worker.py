@@ -68,6 +68,71 @@ def main():
         cost.close()
         dist.destroy_process_group()
         return
+    if os.environ.get("MOPT_TEST_FUZZ"):
+        # every rank walks the same seeded sequence: blocking calls with and without speculation,
+        # the transport switched in between (all ranks at the same point, as the contract asks),
+        # loss changes, device-resident solves over the peer slots.  Each call's numbers must be the
+        # same words on every rank and equal the unsharded cost's (rank 0 holds one) to rounding.
+        rng = np.random.default_rng(int(os.environ["MOPT_TEST_FUZZ"]))
+        whole = mo.Point2PointCost(src, tgt, device=device) if rank == 0 else None
+        if whole:
+            whole.set_loss(mo.LOSS_GEMAN_MCCLURE, 50.0)
+            whole.set_speculation(False)
+        got, want, ops = [], [], []
+        recent = [rng.uniform(-0.3, 0.3, 6) for _ in range(3)]
+        current = usable[0]
+        cost.set_combine(modes[current])
+        for step in range(int(os.environ.get("MOPT_TEST_FUZZ_STEPS", "1500"))):
+            op = rng.random()
+            x = recent[rng.integers(3)].copy() if rng.random() < 0.5 else rng.uniform(-0.4, 0.4, 6)
+            if rng.random() < 0.3:
+                recent[rng.integers(3)] = x.copy()
+            if op < 0.40:
+                jm = [mo.JAC_ANALYTIC, mo.JAC_NUMERIC, mo.JAC_ANALYTIC_LEFT][rng.integers(3)]
+                H, b, s = cost.linearize(x, jm)
+                got.append(np.concatenate([H.ravel(order="F"), b, [s]]))
+                if whole:
+                    Hw, bw, sw = whole.linearize(x, jm)
+                    want.append(np.concatenate([Hw.ravel(order="F"), bw, [sw]]))
+                ops.append(0)
+            elif op < 0.70:
+                c = cost.compute_cost(x)
+                got.append(np.full(43, c))
+                if whole:
+                    want.append(np.full(43, whole.compute_cost(x)))
+                ops.append(1)
+            elif op < 0.80:
+                current = usable[rng.integers(len(usable))]
+                cost.set_combine(modes[current])
+            elif op < 0.86:
+                kind = int(rng.integers(2))
+                param = float(rng.uniform(1.0, 80.0)) if kind else 0.0
+                cost.set_loss(kind, param)
+                if whole:
+                    whole.set_loss(kind, param)
+            elif op < 0.90:
+                cost.set_speculation(bool(rng.integers(2)))
+            elif "peer" in usable:
+                cost.set_combine(mo.COMBINE_PEER)
+                k = int(rng.integers(1, 4))
+                xs0 = x * 0.2
+                xd, rep = mo.capi.lm_minimize([cost], [mo.JAC_ANALYTIC], xs0, max_iterations=k)
+                got.append(np.concatenate([xd, np.zeros(37)]))
+                if whole:
+                    xw, _ = mo.capi.lm_minimize([whole], [mo.JAC_ANALYTIC], xs0, max_iterations=k)
+                    want.append(np.concatenate([xw, np.zeros(37)]))
+                ops.append(2)
+                cost.set_combine(modes[current])
+        res["fuzz_got"] = np.array(got)
+        res["fuzz_ops"] = np.array(ops)
+        if whole:
+            res["fuzz_want"] = np.array(want)
+            whole.close()
+        np.savez(os.path.join(out, "rank%d.npz" % rank), **res)
+        dist.barrier()
+        cost.close()
+        dist.destroy_process_group()
+        return
     xs = [ds.X_ZERO, ds.X_GENERIC, ds.X_GENERIC * 0.3]
     for name in usable:
         cost.set_combine(modes[name])

@@ -128,6 +128,24 @@ def test_sharded_sums_match_the_unsharded_cost(hip_lib, tmp_path, oracle):
             assert abs(s[0] - sr) <= 1e-6 * sr and abs(s[1] - sr) <= 1e-6 * sr
 
 
+@pytest.mark.parametrize("world,seed", [(2, 7), (3, 8)])
+def test_random_call_sequences_over_sharded_costs(hip_lib, tmp_path, world, seed):
+    """Every rank walks the same seeded sequence of calls — blocking sweeps with and without
+    speculation, the transport switched between the host and the peer slots along the way, loss
+    changes, device-resident solves over the peer slots: the numbers are the same words on every rank
+    and equal the unsharded cost's to rounding (the shards' sums are added in another order)."""
+    res = run_ranks(tmp_path, world, 150_001, {"MOPT_TEST_FUZZ": str(seed)})
+    got0, want, ops = res[0]["fuzz_got"], res[0]["fuzz_want"], res[0]["fuzz_ops"]
+    assert len(got0) == len(want) == len(ops) and len(got0) > 900
+    for r in range(1, world):
+        assert res[r]["fuzz_got"].tobytes() == got0.tobytes(), r
+    scale = np.abs(want).max(axis=1, keepdims=True)
+    err = np.abs(got0 - want) / scale
+    assert err[ops != 2].max() < 1e-11, err[ops != 2].max()   # sums: rounding only
+    assert err[ops == 2].max() < 1e-9, err[ops == 2].max()    # iterates of up to three LM iterations
+    assert (ops == 2).sum() > 30
+
+
 def test_bench_launches_its_own_ranks(hip_lib):
     """`python bench.py --gpus 2` without a launcher (as the driver calls it), rehearsed on however
     many GPUs this box has: one JSON line, n_gpus = 2, a fused combine selected."""
