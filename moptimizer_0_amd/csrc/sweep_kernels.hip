@@ -835,6 +835,8 @@ __device__ __forceinline__ void icpMatchBody(const IcpMatchArgs<S> &A, const S (
       // Ties go to the candidate stored first — (cell z, y, x; original index) order — whatever
       // order the rows are visited in: the position k is part of the comparison.
       int best_k = 0x7fffffff;
+      // (only the distance and the position are tracked; the winner's coordinates are read once,
+      // at the end: six conditional moves less per candidate)
       auto consider = [&](const S (&q)[3], int k) {
         const S d0 = w[0] - q[0], d1 = w[1] - q[1], d2 = w[2] - q[2];
         const S dist = d0 * d0 + d1 * d1 + d2 * d2;
@@ -842,7 +844,6 @@ __device__ __forceinline__ void icpMatchBody(const IcpMatchArgs<S> &A, const S (
           found = true;
           best_d = dist;
           best_k = k;
-          best[0] = q[0]; best[1] = q[1]; best[2] = q[2];
         }
       };
       auto fetch = [&](int k, S (&q)[3]) {
@@ -860,7 +861,7 @@ __device__ __forceinline__ void icpMatchBody(const IcpMatchArgs<S> &A, const S (
         xa = xa < 0 ? 0 : xa;
         xb = xb >= A.dims[0] ? A.dims[0] - 1 : xb;
         if (z < 0 || z >= A.dims[2] || y < 0 || y >= A.dims[1] || xa > xb) return;
-        const long long row = ((long long)z * A.dims[1] + y) * A.dims[0];
+        const int row = (z * A.dims[1] + y) * A.dims[0];  // the grid has at most 2^22 cells (icp.cpp)
         const int lo = A.cell_start[row + xa], hi = A.cell_start[row + xb + 1];
         // two candidates per step, both loads issued before either is used
         for (int k = lo; k < hi; k += 2) {
@@ -902,6 +903,7 @@ __device__ __forceinline__ void icpMatchBody(const IcpMatchArgs<S> &A, const S (
           visit(y, z, left ? c[0] - 1 : c[0], right ? c[0] + 1 : c[0]);
         }
       }
+      if (found) fetch(best_k, best);
     }
   }
   const S nan = S(__builtin_nan(""));
