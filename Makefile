@@ -16,7 +16,7 @@ LIBDIR      = moptimizer_0_amd/lib
 LIB         = $(LIBDIR)/libmoptimizer_hip.so
 
 PUBLIC_HEADERS = include/moptimizer_hip.h include/moptimizer_amd/so3.hpp $(CSRC)/sweep.hpp \
-                 $(CSRC)/jit_model.hpp $(CSRC)/cost_state.hpp $(CSRC)/lm_device.hpp
+                 $(CSRC)/sweep_device.hpp $(CSRC)/jit_model.hpp $(CSRC)/cost_state.hpp $(CSRC)/lm_device.hpp
 
 all: $(LIB)
 
@@ -27,6 +27,10 @@ $(OBJDIR) $(LIBDIR):
 $(OBJDIR)/sweep_kernels.o: $(CSRC)/sweep_kernels.hip $(PUBLIC_HEADERS) | $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) $(INCLUDES) -mllvm -amdgpu-kernarg-preload-count=4 -c $< -o $@
 
+# forward-difference sweeps: without the SLP vectorizer (fd_kernels.hip says why)
+$(OBJDIR)/fd_kernels.o: $(CSRC)/fd_kernels.hip $(PUBLIC_HEADERS) | $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) $(INCLUDES) -mllvm -amdgpu-kernarg-preload-count=4 -fno-slp-vectorize -c $< -o $@
+
 $(OBJDIR)/%.o: $(CSRC)/%.cpp $(PUBLIC_HEADERS) | $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) $(INCLUDES) -x hip -c $< -o $@
 
@@ -36,7 +40,7 @@ $(OBJDIR)/icp_grid.o: $(CSRC)/icp_grid.hip $(PUBLIC_HEADERS) | $(OBJDIR)
 $(OBJDIR)/lm_kernels.o: $(CSRC)/lm_kernels.hip $(PUBLIC_HEADERS) | $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) $(INCLUDES) -c $< -o $@
 
-OBJS = $(OBJDIR)/sweep_kernels.o $(OBJDIR)/icp_grid.o $(OBJDIR)/c_abi.o $(OBJDIR)/icp.o \
+OBJS = $(OBJDIR)/sweep_kernels.o $(OBJDIR)/fd_kernels.o $(OBJDIR)/icp_grid.o $(OBJDIR)/c_abi.o $(OBJDIR)/icp.o \
        $(OBJDIR)/group.o $(OBJDIR)/jit_model.o $(OBJDIR)/device_pool.o $(OBJDIR)/combine.o $(OBJDIR)/lm.o $(OBJDIR)/lm_kernels.o
 
 $(LIB): $(OBJS) | $(LIBDIR)

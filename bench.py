@@ -22,7 +22,18 @@ Prints ONE JSON line on rank 0 (contract in the task statement) including
                  carry the dispatch's own timestamps, taken in a pass of their own AFTER the K
                  timed wall-clock steps (which run uninstrumented), vs the 8 TB/s HBM3E peak
   cpu_baseline — the CPU restatement of the reference's single-threaded linearize
-                 (oracle/, kind "port") timed on this box's host cores on a bounded sample
+                 (oracle/, kind "port") timed on rank 0's host cores on a bounded sample, at
+                 every world size
+  rccl         — N > 1: the same K steps with the sums added by ncclAllReduce over the
+                 communicator attached to the cost; "ranks" is what ncclCommCount reports
+  by_collective — N > 1: step time, whole-job rate and fraction of the HBM roof AS A STEP SEES IT
+                 for every transport measured (config.collective names the headline's)
+
+Order for N > 1: attach every transport (host slots, peer slots, RCCL) | headline pass | kernel-
+time pass | RCCL pass | CPU baseline — from there the line is complete — then the comparison
+passes (other transports, no combine, the 10 M strong-scaling split).  A watchdog covers it all:
+firing before the line is complete it ends the rank with exit code 3 and no line; after, it
+prints the line as it stands ("extras_incomplete") and ends the rank.
 """
 import argparse
 import json
@@ -73,6 +84,10 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--deadline-s", type=float,
+                    default=float(os.environ.get("MOPT_BENCH_DEADLINE_S", "330")),
+                    help="N>1: seconds after the ranks have their data by which the run ends "
+                         "whatever has or has not finished (watchdog)")
     return ap.parse_args()
 
 
@@ -314,7 +329,7 @@ def main():
         lo, hi = args.total_n * rank // world, args.total_n * (rank + 1) // world
         args.n = hi - lo
     cost, src, tgt = make_cost(args.n)
-    keep_host = (rank == 0 and world == 1 and not args.no_cpu_baseline)
+    keep_host = (rank == 0 and not args.no_cpu_baseline)
     if keep_host:
         head = min(args.n, 10_000_000)
         src_host = src[:head].double().cpu().numpy()
@@ -322,25 +337,53 @@ def main():
     del src, tgt
     torch.cuda.empty_cache()
 
-    # N > 1: the 43 sums of every sweep are added over the ranks.  Transports in order of
-    # preference (see --collective); a transport is used only if every rank attached it.
-    usable, collective = [], "none"
+    # ---- watchdog: this is the first time more than one GPU runs these paths -------------------
+    # Every wait below is bounded (MOPT_PEER_TIMEOUT_MS inside the combines, 60 s in the blocking
+    # call), but torch.distributed's own collectives are not on a time scale that helps a driver
+    # with a 10-minute limit.  One timer per rank, started before the first pass.
+    import threading
+    line = {}
+    progress = {"stage": "attaching the combine transports", "complete": False}
+    emitted = threading.Lock()
+
+    def emit(final):
+        if not emitted.acquire(blocking=False):
+            return
+        if rank == 0:
+            if not final:
+                line["extras_incomplete"] = True
+                line["note"] = ("watchdog: still in %r at the deadline; reported without it"
+                                % progress["stage"])
+            print(json.dumps(line), flush=True)
+
+    def watchdog():
+        if progress["complete"]:
+            log("rank %d: watchdog fired in %r: reporting the measurement without it"
+                % (rank, progress["stage"]))
+            emit(False)
+            os._exit(0)
+        print(json.dumps({"error": "bench.py watchdog: no complete measurement by the deadline",
+                          "rank": rank, "stage": progress["stage"]}), file=sys.stderr, flush=True)
+        os._exit(3)
+
+    dog = None
     if world > 1:
-        # RCCL is attached later, among the extras behind the watchdog: its communicator is only
-        # needed for the comparison, and nothing that could stall should sit before the measurement
-        if args.collective == "torch":
-            want = ()
-        elif args.collective == "auto":
-            want = ("host", "peer")
-        else:
-            want = (args.collective,)
-        usable = attach_combines(cost, rank, world, want=want, log=log) if want else []
-        if args.collective in usable:
-            collective = args.collective
-        elif args.collective == "auto" and usable:
-            collective = usable[0]
-        else:
-            collective = "torch"  # still RCCL (or gloo when rehearsing), through torch.distributed
+        dog = threading.Timer(args.deadline_s, watchdog)
+        dog.daemon = True
+        dog.start()
+
+    # N > 1: the 43 sums of every sweep are added over the ranks.  Every transport is attached up
+    # front — RCCL included: north_star names the all-reduce over xGMI, so its figure is part of
+    # the line whatever the headline transport is.  A transport counts only if EVERY rank attached
+    # it (attach_combines); it leaves the cost on MOPT_COMBINE_NONE.
+    usable, collective, rccl_note = [], "none", None
+    if world > 1:
+        usable = attach_combines(cost, rank, world, want=("host", "peer", "rccl"), log=log)
+        if "rccl" not in usable:
+            rccl_note = ("ranks share GPUs (rehearsal backend %r): RCCL refuses duplicate devices"
+                         % backend) if backend != "nccl" else "ncclCommInitRank failed on some rank"
+        prefer = ("host", "peer", "rccl") if args.collective == "auto" else (args.collective,)
+        collective = next((c for c in prefer if c in usable), "torch")
     modes = {"none": mo.COMBINE_NONE, "rccl": mo.COMBINE_RCCL, "host": mo.COMBINE_HOST,
              "peer": mo.COMBINE_PEER}
 
@@ -357,10 +400,18 @@ def main():
         return min(20000, max(50, int(ms * 1e-3 / est_step_s)))
 
     def timed_pass(the_cost, combine, steps, warmup, settle, via_torch=None):
-        """barrier | K blocking steps | barrier, wall clock, max over ranks.  Profiling is off."""
-        if combine is not None:
-            the_cost.set_combine(modes[combine])
-        call, x_in, H_out, b_out, s_out = the_cost.bound_linearize(jac_mode)
+        """barrier | K blocking steps | barrier, wall clock, max over ranks.  Profiling is off.
+        A step that fails (a peer that never delivers ends in MOPT_ERR_PEER_TIMEOUT, not in a
+        hang) does not take this rank out of the sequence of collectives: it stops stepping, goes
+        through both barriers and the max-reduce like everybody else, and raises afterwards."""
+        err = None
+        call = x_in = H_out = b_out = s_out = None
+        try:
+            if combine is not None:
+                the_cost.set_combine(modes[combine])
+            call, x_in, H_out, b_out, s_out = the_cost.bound_linearize(jac_mode)
+        except Exception as e:  # noqa: BLE001
+            err = e
 
         def step(k):
             if via_torch is not None:
@@ -369,18 +420,29 @@ def main():
             call()  # blocking C-ABI call: kernels, the sum over the ranks, the 43 results on the host
             return H_out, b_out, s_out[0]
 
-        for k in range(settle + warmup):
-            step(k)
+        H = s = None
+        if err is None:
+            try:
+                for k in range(settle + warmup):
+                    step(k)
+            except Exception as e:  # noqa: BLE001
+                err = e
         barrier()
         t0 = time.perf_counter()
-        for k in range(steps):
-            H, b, s = step(k)
+        if err is None:
+            try:
+                for k in range(steps):
+                    H, b, s = step(k)
+            except Exception as e:  # noqa: BLE001
+                err = e
         barrier()
         elapsed = time.perf_counter() - t0
         if world > 1:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=ctl)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
+        if err is not None:
+            raise err
         return elapsed, np.array(H, dtype=np.float64), float(s)
 
     # ---- the measurement: W warm-up steps, then exactly K timed steps, uninstrumented ----------
@@ -392,8 +454,8 @@ def main():
 
     def guarded_pass(the_cost, name, steps, warmup, settle):
         """A timed pass that every rank either completes or abandons together: a transport that
-        fails at run time on any rank (a peer that never delivers ends in MOPT_ERR_PEER_TIMEOUT, not
-        in a hang) is reported as unusable instead of ending the run."""
+        fails at run time on any rank is reported as unusable instead of ending the run."""
+        progress["stage"] = "timed pass, combine %r" % name
         ok, err, res = True, None, None
         try:
             if name == "torch":
@@ -409,6 +471,17 @@ def main():
                 log("rank %d: combine %r failed in the timed pass: %s" % (rank, name, err))
             return None
         return res
+
+    bpc = BYTES_PER_CORRESPONDENCE[scalar_bytes]
+    total = args.total_n if args.total_n else args.n * world
+
+    def as_step_sees_it(ms, n_per_gpu=None, total_n=None):
+        """Step time -> whole-job rate and the fraction of ONE GPU's HBM roof its shard's
+        algorithmic bytes reach per step (kernel + finalize + combine + hand-over to the host)."""
+        n_per_gpu = args.n if n_per_gpu is None else n_per_gpu
+        total_n = total if total_n is None else total_n
+        return {"ms_per_step": ms, "value": total_n / (ms * 1e-3),
+                "step_frac": n_per_gpu * bpc / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
     cost.set_profiling(False)
     settle = settle_steps(args.n, args.settle_ms)
@@ -442,12 +515,11 @@ def main():
         the_cost.set_profiling(False)
         return ms / max(launches, 1), launches
 
+    progress["stage"] = "kernel-time pass"
     ksteps = args.kernel_steps if args.kernel_steps > 0 else min(args.steps, 100)
     kernel_ms, launches = kernel_pass(cost, ksteps)
 
-    total = args.total_n if args.total_n else args.n * world
     ms_per_step = elapsed / args.steps * 1e3
-    bpc = BYTES_PER_CORRESPONDENCE[scalar_bytes]
     achieved = args.n * bpc / (kernel_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -467,7 +539,8 @@ def main():
            "peer": "finalize kernels push 43 fp64 into each other's HBM slots (xGMI / IPC) and add on the device",
            "rccl": "RCCL all-reduce of 43 fp64 on the cost's stream",
            "torch": "torch.distributed all_reduce of 43 fp64"}[collective]
-    line = {
+    rehearsal = world > 1 and backend != "nccl"
+    line.update({
         "metric": "point-correspondences/sec per LM linearization sweep; % HBM peak",
         "value": total * args.steps / elapsed,
         "unit": "correspondences/s",
@@ -487,10 +560,13 @@ def main():
             "correspondences_per_gpu": args.n,
             "total_correspondences": total,
             "parallelism": "shard%d" % world,
-            "collective": collective if (backend == "nccl" or collective in ("host", "peer", "none"))
+            "collective": collective if not (rehearsal and collective == "torch")
             else "torch/" + backend + " (rehearsal)",
+            "collective_is": how,
             "collectives_attached": list(usable),
             "rank_backend": backend if world > 1 else None,
+            "rehearsal": ("%d ranks on %d GPU(s), torch.distributed over %s" % (world, ndev, backend))
+            if rehearsal else None,
             "kernel_variant": args.variant,
         },
         "roofline": {
@@ -504,55 +580,66 @@ def main():
             "kernel_ms": kernel_ms,
             "kernel_launches_timed": launches,
             "kernel_timing": "separate pass after the timed steps; every launch carries its "
-                             "dispatch timestamps (hipExtLaunchKernelGGL)",
+                             "dispatch timestamps (hipExtLaunchKernelGGL); rank 0's GPU",
             "algorithmic_bytes_per_launch": args.n * bpc,
         },
         "pct_hbm_peak": 100.0 * achieved / HBM_PEAK_GBS,
         "check": {"sum_sq": float(s), "H00": float(H[0, 0])},
-    }
-
-    # The line above is the measurement.  What follows only adds to it (other transports, the
-    # strong-scaling split, the literal kernel, the CPU baseline); if any of it stalls — this is
-    # the first time more than one GPU runs these paths — a watchdog prints the line as it stands
-    # and ends the rank, so that the run still reports.
-    import threading
-    emitted = threading.Lock()
-
-    def emit(final):
-        if not emitted.acquire(blocking=False):
-            return
-        if rank == 0:
-            if not final:
-                line["note"] = "watchdog: an extra pass did not finish; reported without it"
-            print(json.dumps(line), flush=True)
-
-    def watchdog():
-        emit(False)
-        os._exit(0)
-
-    dog = None
+    })
+    per = {}
     if world > 1:
-        dog = threading.Timer(float(os.environ.get("MOPT_BENCH_EXTRAS_TIMEOUT_S", "120")), watchdog)
-        dog.daemon = True
-        dog.start()
+        per[collective] = as_step_sees_it(ms_per_step)
+        line["by_collective"] = per
+        line["roofline"]["step_frac_by_collective"] = {collective: per[collective]["step_frac"]}
+
+    # ---- RCCL: part of the measurement proper, whatever the headline transport ------------------
+    if world > 1:
+        progress["stage"] = "RCCL pass"
+        info = {"attached": "rccl" in usable}
+        if "rccl" in usable:
+            ranks_here, user_rank = cost.comm_info()  # ncclCommCount / ncclCommUserRank
+            t = torch.tensor([ranks_here, -ranks_here], dtype=torch.int64, device=ctl)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            info.update({"ranks": ranks_here, "user_rank": user_rank,
+                         "ranks_min_over_ranks": int(t[0].item()),
+                         "ranks_max_over_ranks": -int(t[1].item()),
+                         "spans_all_ranks": int(t[0].item()) == world == -int(t[1].item())})
+            if collective == "rccl":
+                info.update(per["rccl"])
+            else:
+                r = guarded_pass(cost, "rccl", args.steps, args.warmup, min(settle, 200))
+                if r is not None:
+                    per["rccl"] = as_step_sees_it(r[0] / args.steps * 1e3)
+                    info.update(per["rccl"])
+                    info["check"] = {"sum_sq": r[2], "H00": float(r[1][0, 0])}
+                else:
+                    info["failed_in_timed_pass"] = True
+        else:
+            info["reason"] = rccl_note
+        line["rccl"] = info
+        line["config"]["rccl_ranks"] = info.get("ranks")
+
+    # ---- CPU baseline: rank 0's host cores, every world size -----------------------------------
+    progress["stage"] = "cpu baseline"
+    if rank == 0:
+        line["cpu_baseline"] = (cpu_baseline(src_host, tgt_host, ds.X_GENERIC, jac_mode, args.cpu_seconds)
+                                if keep_host else None)
+    if world > 1:
+        dist.barrier()  # the others wait here, not inside a combine with a 5 s limit
+    progress["complete"] = True  # from here on the watchdog reports instead of failing
 
     if world > 1 and not args.no_compare:
         # every other way of adding the ranks' sums, and no combine at all, K steps each
-        more = tuple(t for t in ("host", "peer", "rccl") if t not in usable and t in
-                     (("host", "peer", "rccl") if args.collective != "torch" else ()))
-        if more:
-            usable = usable + attach_combines(cost, rank, world, want=more, log=log)
-            line["config"]["collectives_attached"] = list(usable)
-        per = {collective: ms_per_step}
-        for name in ["none"] + usable:
+        for name in ["none"] + [u for u in usable if u not in per] + (["torch"] if "torch" not in per else []):
             if name in per:
                 continue
             r = guarded_pass(cost, name, args.steps, min(args.warmup, 10), 20)
             if r is not None:
-                per[name] = r[0] / args.steps * 1e3
-        line["ms_per_step_by_collective"] = per
+                per[name] = as_step_sees_it(r[0] / args.steps * 1e3)
+        line["ms_per_step_by_collective"] = {k: v["ms_per_step"] for k, v in per.items()}
+        line["roofline"]["step_frac_by_collective"] = {k: v["step_frac"] for k, v in per.items()}
         if "none" in per:
-            line["ms_per_step_without_collective"] = per["none"]
+            line["ms_per_step_without_collective"] = per["none"]["ms_per_step"]
     if world == 1 and args.variant == "auto" and args.mode != "analytic_tst":
         # the same sweep evaluated literally (every residual and Jacobian entry per point, as the
         # reference does) — a driver-timed number for that kernel too
@@ -565,6 +652,7 @@ def main():
     if world > 1 and not args.no_compare and not args.total_n:
         # BASELINE config 4: 10 M correspondences IN TOTAL split over the ranks (strong scaling;
         # 60 MB per GPU at 8 ranks, Infinity-Cache resident, latency-bound)
+        progress["stage"] = "config 4 (10 M in total)"
         total4 = 10_000_000
         lo, hi = total4 * rank // world, total4 * (rank + 1) // world
         cost4, s4, t4 = make_cost(hi - lo)
@@ -574,23 +662,24 @@ def main():
         for name in ["none"] + attached4:
             r = guarded_pass(cost4, name, args.steps, min(args.warmup, 10), settle_steps(hi - lo, 50.0))
             if r is not None:
-                per4[name] = r[0] / args.steps * 1e3
+                per4[name] = as_step_sees_it(r[0] / args.steps * 1e3, hi - lo, total4)
         combined = {k: v for k, v in per4.items() if k != "none"}
-        best = min((v, k) for k, v in combined.items()) if combined else (None, None)
+        best = min((v["ms_per_step"], k) for k, v in combined.items()) if combined else (None, None)
+        progress["stage"] = "config 4 kernel-time pass"
+        k4_ms, _ = kernel_pass(cost4, min(ksteps, 30))
         line["config4_strong"] = {
             "total_correspondences": total4, "correspondences_per_gpu": hi - lo,
-            "ms_per_step_by_collective": per4, "collective": best[1], "ms_per_step": best[0],
+            "ms_per_step_by_collective": {k: v["ms_per_step"] for k, v in per4.items()},
+            "by_collective": per4, "rccl": per4.get("rccl"),
+            "collective": best[1], "ms_per_step": best[0],
             "value": (total4 / (best[0] * 1e-3)) if best[0] else None,
-            "unit": "correspondences/s", "scaling": "strong"}
+            "unit": "correspondences/s", "scaling": "strong",
+            "kernel_ms": k4_ms,
+            "kernel_frac": (hi - lo) * bpc / (k4_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         barrier()
         cost4.close()
 
-    if rank == 0:
-        if keep_host:
-            line["cpu_baseline"] = cpu_baseline(src_host, tgt_host, ds.X_GENERIC, jac_mode,
-                                                args.cpu_seconds)
-        elif world == 1:
-            line["cpu_baseline"] = None
+    progress["stage"] = "closing"
     if dog is not None:
         dog.cancel()
     emit(True)

@@ -100,8 +100,15 @@ enum mopt_kernel_variant {
   MOPT_KERNEL_AUTO = 0,    /* fastest variant that meets the parity bar for the mode         */
   MOPT_KERNEL_LITERAL = 1, /* every residual and Jacobian entry formed per point, then
                               w * J^T * S * J accumulated entry by entry, as the reference does */
-  MOPT_KERNEL_MOMENTS = 2  /* Jacobians that are affine in the source point (all point2point
-                              modes) reduced through weighted point/residual moments           */
+  MOPT_KERNEL_MOMENTS = 2, /* Jacobians that are affine in the source point (all point2point
+                              modes) reduced through weighted point/residual moments — except
+                              for forward differences with some 0 < |x_j| < 0.08, where that
+                              evaluation leaves the 1e-6 bar (it lacks the reference's own
+                              per-point cancellation noise eps |R p + t| / h_j) and the literal
+                              evaluation is used                                                */
+  MOPT_KERNEL_MOMENTS_ALWAYS = 3 /* moments whatever the step size: for measurements; forward
+                              differences then differ from the reference's by up to
+                              2e-8 / min |x_j| relative (0.97 at |x_j| ~ 1e-8)                  */
 };
 
 MOPT_API int mopt_device_count(int *count);
@@ -289,6 +296,10 @@ MOPT_API int mopt_cost_synchronize(mopt_cost *cost);
 #define MOPT_COMM_ID_BYTES 128
 MOPT_API int mopt_comm_unique_id(void *id_out, int id_bytes);
 MOPT_API int mopt_cost_comm_init_rank(mopt_cost *cost, const void *id, int rank, int num_ranks);
+/* What the attached communicator itself reports (ncclCommCount / ncclCommUserRank): the number of
+ * ranks the all-reduce of this cost spans and this rank's place among them; 0 / -1 when no
+ * communicator is attached.  Either pointer may be NULL. */
+MOPT_API int mopt_cost_comm_info(const mopt_cost *cost, int *num_ranks, int *rank);
 
 /* ---- latency-optimised shard combine (replaces the all-reduce launch) -----------------------
  *

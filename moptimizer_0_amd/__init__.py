@@ -18,6 +18,7 @@ from ._capi import (  # noqa: F401
     KERNEL_AUTO,
     KERNEL_LITERAL,
     KERNEL_MOMENTS,
+    KERNEL_MOMENTS_ALWAYS,
     LOSS_GEMAN_MCCLURE,
     LOSS_NONE,
     IcpCost,

@@ -16,7 +16,7 @@ MOPT_OK = 0
 JAC_ANALYTIC, JAC_ANALYTIC_TST_LAYOUT, JAC_NUMERIC, JAC_ANALYTIC_LEFT = 0, 1, 2, 3
 LOSS_NONE, LOSS_GEMAN_MCCLURE = 0, 1
 INPUT_HOST, INPUT_DEVICE = 0, 1
-KERNEL_AUTO, KERNEL_LITERAL, KERNEL_MOMENTS = 0, 1, 2
+KERNEL_AUTO, KERNEL_LITERAL, KERNEL_MOMENTS, KERNEL_MOMENTS_ALWAYS = 0, 1, 2, 3
 COMBINE_NONE, COMBINE_RCCL, COMBINE_HOST, COMBINE_PEER = 0, 1, 2, 3
 COMBINE_NAMES = {COMBINE_NONE: "none", COMBINE_RCCL: "rccl", COMBINE_HOST: "host", COMBINE_PEER: "peer"}
 PEER_HANDLE_BYTES = 64
@@ -105,6 +105,7 @@ def load():
                             ctypes.POINTER(ctypes.c_int64)],
         "mopt_comm_unique_id": [ctypes.c_void_p, ctypes.c_int],
         "mopt_cost_comm_init_rank": [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int],
+        "mopt_cost_comm_info": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)],
         "mopt_cost_hostcomm_attach": [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int],
         "mopt_hostcomm_unlink": [ctypes.c_char_p],
         "mopt_cost_peer_export": [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p],
@@ -325,6 +326,13 @@ class _CostBase:
         check(load().mopt_cost_comm_init_rank(self._h, buf, int(rank), int(num_ranks)))
 
     # -- shard combine without a collective launch (include/moptimizer_hip.h) ---------------
+    def comm_info(self):
+        """(ranks, rank) as the attached RCCL communicator reports them (ncclCommCount,
+        ncclCommUserRank); (0, -1) without a communicator."""
+        n, r = ctypes.c_int(0), ctypes.c_int(-1)
+        check(load().mopt_cost_comm_info(self._h, ctypes.byref(n), ctypes.byref(r)))
+        return n.value, r.value
+
     def hostcomm_attach(self, shm_name, rank, num_ranks):
         """MOPT_COMBINE_HOST: every rank's finalize kernel publishes into one shared host block."""
         check(load().mopt_cost_hostcomm_attach(self._h, shm_name.encode(), int(rank),

@@ -255,7 +255,7 @@ int p2pLinearizeAsync(mopt_cost *c, int jac_mode, const S *x, double *d_result, 
   bool moments;
   switch (c->variant) {
     case MOPT_KERNEL_LITERAL: moments = false; break;
-    case MOPT_KERNEL_MOMENTS: moments = true; break;
+    case MOPT_KERNEL_MOMENTS_ALWAYS: moments = true; break;
     default: moments = !(jac_mode == MOPT_JAC_NUMERIC && hasSmallForwardStep<S>(x)); break;
   }
   if (moments) {
@@ -269,8 +269,8 @@ int p2pLinearizeAsync(mopt_cost *c, int jac_mode, const S *x, double *d_result, 
   } else {
     const int grid = gridFor(c, blocksPerCu(2));
     const int nacc = c->cov_mode == mopt::kCovGeneral ? mopt::kAccFull : mopt::kAccSym;
-    // the forward-difference / identity-covariance form takes dispatch timestamps like the moments sweep
-    SweepTimer timer(c, s, jac_mode == MOPT_JAC_NUMERIC && c->cov_mode == mopt::kCovIdentity);
+    // the forward-difference sweep takes dispatch timestamps like the moments sweep
+    SweepTimer timer(c, s, jac_mode == MOPT_JAC_NUMERIC);
     MOPT_HIP_TRY(mopt::launchP2PLinearizeLiteral<S>(args, jac_mode, c->cov_mode, grid, timer.site));
     timer.stop();
     MOPT_HIP_TRY(
@@ -1530,9 +1530,10 @@ int mopt_cost_set_loss(mopt_cost *c, int loss_kind, double parameter) {
 
 int mopt_cost_set_kernel_variant(mopt_cost *c, int variant) {
   if (!c) return fail(MOPT_ERR_INVALID_ARGUMENT, "cost is NULL");
-  if (variant < MOPT_KERNEL_AUTO || variant > MOPT_KERNEL_MOMENTS)
+  if (variant < MOPT_KERNEL_AUTO || variant > MOPT_KERNEL_MOMENTS_ALWAYS)
     return fail(MOPT_ERR_INVALID_ARGUMENT, "unknown kernel variant");
-  if (variant == MOPT_KERNEL_MOMENTS && c->model != kModelPoint2Point)
+  if ((variant == MOPT_KERNEL_MOMENTS || variant == MOPT_KERNEL_MOMENTS_ALWAYS) &&
+      c->model != kModelPoint2Point)
     return fail(MOPT_ERR_UNSUPPORTED, "only point2point Jacobians are affine in the data point");
   if (c->variant != variant) c->state_version += 1;
   c->variant = variant;
@@ -1810,6 +1811,18 @@ int mopt_cost_comm_init_rank(mopt_cost *c, const void *id, int rank, int num_ran
   c->combine.num_ranks = num_ranks;
   c->combine.mode = MOPT_COMBINE_RCCL;
   c->cache.valid = false;
+  return MOPT_OK;
+}
+
+int mopt_cost_comm_info(const mopt_cost *c, int *num_ranks, int *rank) {
+  if (!c) return fail(MOPT_ERR_INVALID_ARGUMENT, "cost is NULL");
+  int count = 0, user_rank = -1;
+  if (c->comm) {
+    MOPT_NCCL_TRY(ncclCommCount(c->comm, &count));
+    MOPT_NCCL_TRY(ncclCommUserRank(c->comm, &user_rank));
+  }
+  if (num_ranks) *num_ranks = count;
+  if (rank) *rank = user_rank;
   return MOPT_OK;
 }
 

@@ -84,33 +84,52 @@ int mopt_cost_hostcomm_attach(mopt_cost *c, const char *shm_name, int rank, int 
       (mopt::slotBlockDoubles(num_ranks) * sizeof(double) + page - 1) / page * page;
   // A fresh object reads as zeros and sequence numbers start at 1, so nobody has to initialise it
   // (and nobody may: a rank that attaches late must not wipe what an early one has published).
-  const int fd = shm_open(shm_name, O_CREAT | O_RDWR, 0600);
+  bool created = true;  // by this call: then a failure below also removes the name again
+  int fd = shm_open(shm_name, O_CREAT | O_EXCL | O_RDWR, 0600);
+  if (fd < 0 && errno == EEXIST) {
+    created = false;
+    fd = shm_open(shm_name, O_CREAT | O_RDWR, 0600);
+  }
   if (fd < 0) return fail(MOPT_ERR_HIP, std::string("shm_open: ") + std::strerror(errno));
+  auto abandon = [&](void *mapped, size_t mapped_bytes) {
+    if (mapped) (void)munmap(mapped, mapped_bytes);
+    (void)close(fd);
+    if (created) (void)shm_unlink(shm_name);
+  };
   if (ftruncate(fd, off_t(bytes)) != 0) {
     const std::string why = std::strerror(errno);
-    close(fd);
+    abandon(nullptr, 0);
     return fail(MOPT_ERR_HIP, "ftruncate: " + why);
   }
   void *base = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
   if (base == MAP_FAILED) {
     const std::string why = std::strerror(errno);
-    close(fd);
+    abandon(nullptr, 0);
     return fail(MOPT_ERR_HIP, "mmap: " + why);
+  }
+  double *dev = nullptr;
+  bool registered = false;
+  hipError_t e = hipHostRegister(base, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+  if (e == hipSuccess) {
+    registered = true;
+    e = hipHostGetDevicePointer(reinterpret_cast<void **>(&dev), base, 0);
+  }
+  if (e != hipSuccess) {
+    // undo what THIS call did and nothing else: a peer block or a communicator attached earlier
+    // stays as it is (other ranks may be pushing into this rank's peer block right now), and so
+    // does the selected transport.  The name is removed only if this call created the object.
+    const std::string why = hipGetErrorString(e);
+    (void)hipGetLastError();
+    if (registered) (void)hipHostUnregister(base);
+    abandon(base, bytes);
+    return fail(MOPT_ERR_HIP, "registering the shared slot block with HIP: " + why);
   }
   sc.shm_fd = fd;
   sc.host_block = static_cast<double *>(base);
+  sc.host_block_dev = dev;
   sc.host_bytes = bytes;
+  sc.host_registered = true;
   sc.shm_name = shm_name;
-  hipError_t e = hipHostRegister(base, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
-  if (e == hipSuccess) {
-    sc.host_registered = true;
-    e = hipHostGetDevicePointer(reinterpret_cast<void **>(&sc.host_block_dev), base, 0);
-  }
-  if (e != hipSuccess) {
-    const std::string why = hipGetErrorString(e);
-    releaseCombine(c);
-    return fail(MOPT_ERR_HIP, "registering the shared slot block with HIP: " + why);
-  }
   sc.rank = rank;
   sc.num_ranks = num_ranks;
   sc.mode = MOPT_COMBINE_HOST;
@@ -182,6 +201,9 @@ int mopt_cost_peer_attach(mopt_cost *c, const void *handles, int rank, int num_r
         sc.peer_opened[q] = false;
         sc.peer_blocks[q] = nullptr;
       }
+      // the own block stays allocated: other ranks may have opened its exported handle already
+      // (it is released with the cost); mopt_cost_peer_attach may be called again with new handles
+      sc.peer_blocks[rank] = nullptr;
       return fail(MOPT_ERR_HIP, "opening the slot block of rank " + std::to_string(k) +
                                     " (hipIpcOpenMemHandle): " + hipGetErrorString(e));
     }

@@ -1,0 +1,318 @@
+// gfx950 kernels of the forward-difference linearization sweep evaluated as the reference does
+// (linearization.h:65-124 with the point-to-point model of tst/point2point.cpp:32-51): seven
+// residuals and eighteen quotients per correspondence.  A translation unit of its own: compiled
+// without the SLP vectorizer (it pairs the fp32 points of a pack into v_pk_* instructions at the
+// price of ~150 register moves and 90 more VGPRs per wave).
+#include "sweep_device.hpp"
+
+#include <cstdlib>
+
+namespace mopt {
+namespace {
+
+// ---- point-to-point, forward differences as the reference evaluates them ------------------------
+// The literal kernel above would carry 7 transforms x 12 scalars as kernel arguments; in fp64 that
+// is 168 SGPRs of constants against ~100 available, so the compiler spilled them and the sweep ran
+// at 28-44 % of the HBM roof.  This form of the same arithmetic
+//   * keeps the constants in LDS and re-reads what a step needs (same-address reads: one broadcast
+//     each; a compiler barrier in front keeps them from being hoisted into ~114 VGPRs);
+//   * uses what the reference's perturbed models have in common: x + h e_j for a translation
+//     parameter leaves R untouched, so r+_a - r_a is EXACTLY zero for a != j and the j-th entry
+//     only needs the shared partial sum (R p)_j — three columns cost 4 operations each instead of
+//     a transformed point each: J = [diag(d) | A];
+//   * spells the transformed point as fma(T2, p2, fma(T1, p1, T0 p0)) + t, the contraction of the
+//     reference's 4x4 * [p;1] product (tst/point2point.cpp:42-45 under -march=native), for every
+//     one of the seven residuals alike, so that r+ - r carries the same rounding as on the CPU;
+//   * takes the V correspondences of a 16-byte pack one after the other behind scheduling barriers
+//     (interleaved by the scheduler they need > 300 registers), with compile-time pack indices.
+// Every J entry, the loss weight and every product are still formed per point (linearization.h:
+// 101-117).  COV: identity (w J^T J has three structural zeros and nine one-term entries), symmetric
+// (rows of kAccSym) or general (rows of kAccFull) covariance — tst/covariance.cpp:45-63,
+// tst/powell.cpp:107-136 are forward differences under a covariance.  Only the bits of J matter for
+// parity with the CPU path (the quotient amplifies them by eps / h); the products that follow are
+// associated for the fewest instructions: S A once, w folded into S A, d and r.
+// acc += a * b: one v_fma_f64 in fp64; in fp32 the product is rounded to fp32 first, as the
+// reference's float instantiation does, and the running sum is fp64
+template <typename S>
+__device__ __forceinline__ void accFma(double &acc, S a, S b) {
+  if constexpr (sizeof(S) == 8)
+    acc = __builtin_fma(a, b, acc);
+  else
+    acc += double(a * b);
+}
+template <typename S>
+__device__ __forceinline__ void accDot3(double &acc, const S (&a)[3], const S (&b)[3]) {
+  if constexpr (sizeof(S) == 8) {
+    acc = __builtin_fma(a[2], b[2], __builtin_fma(a[1], b[1], __builtin_fma(a[0], b[0], acc)));
+  } else {
+    acc += double((a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]);
+  }
+}
+
+// Where the 27 rotation entries at x + h_j e_j (j = 3..5) live during the sweep.  Everything else a
+// point needs — [R | t] at x, t_j + h_j, 1 / h_j, the covariance: 30-39 scalars — is read from the
+// kernel arguments and stays in scalar registers (a VALU instruction takes one scalar operand), and
+// x + h e_j for a rotation parameter leaves t untouched, so the perturbed transforms need no
+// translation column.  What is left does not fit the scalar file next to that (54 more SGPRs):
+//   kFdRotationLds        re-read from LDS per point (same-address reads, 14 ds_read_b128; every
+//                         one of them still returns 1 KiB to the wave, and with all seven transforms
+//                         in LDS — 30 reads per point — that return path, not the VALU, set the pace
+//                         at 88-97 us for 10 M points)
+//   kFdRotationRegisters  54 VGPRs per lane, loaded once
+enum FdRotationHome : int { kFdRotationLds = 0, kFdRotationRegisters = 1 };
+
+template <typename S, bool STREAMING, int COV, int HOME>
+__device__ __forceinline__ void p2pForwardDiffBody(const S *tiles, int num_tiles,
+                                                   const P2PSweepArgs<S> &A) {
+  constexpr int V = TileShape<S>::kVec;
+  constexpr int NACC = (COV == kCovGeneral) ? kAccFull : kAccSym;
+  __shared__ S Rlds[3][12];  // [c][a * 3 + k] = R(x + h_{3+c} e_{3+c})(a, k); 9 of 12 used
+  if (threadIdx.x < 27) {
+    const int c = threadIdx.x / 9, ak = threadIdx.x % 9;
+    Rlds[c][ak] = A.T[4 + c][(ak / 3) * 4 + ak % 3];
+  }
+  __syncthreads();
+  S Rreg[3][9];
+  if constexpr (HOME == kFdRotationRegisters) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Rreg[c][k] = Rlds[c][k];
+  }
+
+  double acc[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+  const long long count = A.count;
+  // H(i, j) in the row layout of the finalize kernel: upper triangle column-wise, or full column-major
+  auto at = [](int i, int j) { return COV == kCovGeneral ? j * kNumParams + i : j * (j + 1) / 2 + i; };
+  constexpr int kB = (COV == kCovGeneral) ? 36 : 21;  // first entry of b
+
+  // `robust`: the loss kind is taken out of the point (a branch inside would split the basic block
+  // and let the compiler sink one point's accumulation below the next point's Jacobian)
+  auto point = [&](auto robust, const S (&in)[6], long long index) {
+    const S p[3] = {in[0], in[1], in[2]};
+    const bool valid = isCorrespondence(index, count, in[3]);
+    const S q[3] = {valid ? in[3] : S(0), valid ? in[4] : S(0), valid ? in[5] : S(0)};
+    S s[3], r[3], d[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      s[a] = __builtin_fma(A.T[0][a * 4 + 2], p[2],
+                           __builtin_fma(A.T[0][a * 4 + 1], p[1], A.T[0][a * 4 + 0] * p[0]));
+      r[a] = (s[a] + A.T[0][a * 4 + 3]) - q[a];
+    }
+    // translation columns: only entry (j, j) moves (t_j + h_j is entry (j, 3) of the transform at
+    // x + h_j e_j)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      d[j] = (((s[j] + A.T[1 + j][j * 4 + 3]) - q[j]) - r[j]) * A.inv_h[j];
+    // rotation columns: a transformed point each
+    S Acol[3][3];  // Acol[c][a] = J[a][3 + c]
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      S Rc[9];
+      if constexpr (HOME == kFdRotationRegisters) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rc[k] = Rreg[c][k];
+      } else {
+        asm volatile("" ::: "memory");  // from LDS here, not from registers kept alive
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rc[k] = Rlds[c][k];
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const S sp = __builtin_fma(Rc[a * 3 + 2], p[2],
+                                   __builtin_fma(Rc[a * 3 + 1], p[1], Rc[a * 3 + 0] * p[0]));
+        const S rp = (sp + A.T[0][a * 4 + 3]) - q[a];
+        Acol[c][a] = (rp - r[a]) * A.inv_h[3 + c];
+      }
+    }
+    S rr = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+    S w = S(1);
+    if constexpr (decltype(robust)::value) w = lossWeight<S>(kLossGemanMcClure, A.loss_param, rr);
+    w = valid ? w : S(0);
+    rr = valid ? rr : S(0);
+    const S wd[3] = {w * d[0], w * d[1], w * d[2]};
+    if constexpr (COV == kCovIdentity) {
+      // w J^T J, w J^T r with J = [diag(d) | A]: entries (0,1), (0,2), (1,2) are sums of exact zeros
+      S wA[3][3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) wA[c][a] = w * Acol[c][a];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) accFma<S>(acc[at(i, i)], wd[i], d[i]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) accFma<S>(acc[at(i, 3 + c)], wd[i], Acol[c][i]);
+#pragma unroll
+        for (int c2 = 0; c2 <= c; ++c2) accDot3<S>(acc[at(3 + c2, 3 + c)], wA[c2], Acol[c]);
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) accFma<S>(acc[kB + i], wd[i], r[i]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) accDot3<S>(acc[kB + 3 + c], wA[c], r);
+    } else {
+      // w S A (column c: wSA[c][a] = w sum_b S(a, b) A(b, c)), S (w d) and S (w r)
+      S wSA[3][3], Swd[3][3], wSr[3];
+      const S wr[3] = {w * r[0], w * r[1], w * r[2]};
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          wSA[c][a] = w * __builtin_fma(A.cov[a * 3 + 2], Acol[c][2],
+                                        __builtin_fma(A.cov[a * 3 + 1], Acol[c][1],
+                                                      A.cov[a * 3 + 0] * Acol[c][0]));
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Swd[j][a] = A.cov[a * 3 + j] * wd[j];  // S(a, j) w d_j
+        wSr[a] = __builtin_fma(A.cov[a * 3 + 2], wr[2],
+                               __builtin_fma(A.cov[a * 3 + 1], wr[1], A.cov[a * 3 + 0] * wr[0]));
+      }
+      // translation x translation: d_i S(i, j) w d_j
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          if (COV == kCovGeneral || i <= j) accFma<S>(acc[at(i, j)], d[i], Swd[j][i]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        // translation x rotation: d_i (w S A)(i, c); and its transpose side under a general S:
+        // sum_a A(a, c) S(a, j) w d_j
+#pragma unroll
+        for (int i = 0; i < 3; ++i) accFma<S>(acc[at(i, 3 + c)], d[i], wSA[c][i]);
+        if constexpr (COV == kCovGeneral) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) accDot3<S>(acc[at(3 + c, j)], Acol[c], Swd[j]);
+        }
+        // rotation x rotation: sum_a A(a, c2) (w S A)(a, c)
+#pragma unroll
+        for (int c2 = 0; c2 < 3; ++c2)
+          if (COV == kCovGeneral || c2 <= c) accDot3<S>(acc[at(3 + c2, 3 + c)], Acol[c2], wSA[c]);
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) accFma<S>(acc[kB + i], d[i], wSr[i]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) accDot3<S>(acc[kB + 3 + c], Acol[c], wSr);
+    }
+    acc[NACC - 1] += double(rr);
+  };
+
+  auto sweep = [&](auto robust) {
+    sweepTiles<S, STREAMING>(tiles, num_tiles, [&](const Pack<S>(&cur)[6], long long first) {
+      if constexpr (V == 2) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          __builtin_amdgcn_sched_barrier(0);  // one point after the other
+          const S in[6] = {cur[0].v[e], cur[1].v[e], cur[2].v[e], cur[3].v[e], cur[4].v[e], cur[5].v[e]};
+          point(robust, in, first + e);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        // four fp32 points per pack: as a real loop (unrolled they need > 256 registers whatever the
+        // barriers say), the pack element picked by selects
+#pragma unroll 1
+        for (int e = 0; e < V; ++e) {
+          S in[6];
+#pragma unroll
+          for (int pl = 0; pl < 6; ++pl) {
+            in[pl] = cur[pl].v[0];
+#pragma unroll
+            for (int k = 1; k < V; ++k) in[pl] = (e == k) ? cur[pl].v[k] : in[pl];
+          }
+          point(robust, in, first + e);
+        }
+      }
+    });
+  };
+  if (A.loss_kind == kLossGemanMcClure)
+    sweep(std::true_type());
+  else
+    sweep(std::false_type());
+  blockReduceStore<NACC>(acc, A.partials + size_t(blockIdx.x) * NACC);
+}
+
+template <typename S, bool STREAMING, int COV, int HOME>
+__global__ __launch_bounds__(kBlockThreads) void p2pForwardDiffKernel(const S *tiles, int num_tiles,
+                                                                      const P2PSweepArgs<S> A) {
+  p2pForwardDiffBody<S, STREAMING, COV, HOME>(tiles, num_tiles, A);
+}
+
+template <typename S, bool STREAMING, int COV>
+__global__ __launch_bounds__(kBlockThreads) void p2pForwardDiffResidentArgsKernel(
+    const P2PSweepArgs<S> *__restrict__ d_args, const LmControl *__restrict__ control) {
+  if (control->done) return;
+  const P2PSweepArgs<S> A = *d_args;
+  p2pForwardDiffBody<S, STREAMING, COV, kFdRotationLds>(A.tiles, A.num_tiles, A);
+}
+
+}  // namespace
+
+template <typename S>
+hipError_t launchForwardDiff(const P2PSweepArgs<S> &args, int cov_mode, int grid,
+                             const LaunchSite &site) {
+  // fp64: identity / symmetric covariance leave room for the 54 VGPRs (206 / 220 in all: two waves
+  // per SIMD either way); the general form (43 accumulators) and fp32 (whose LDS reads are half the
+  // size) re-read from LDS.  MOPT_FD_ROTATION_HOME=0|1 overrides (tuning).
+  static const int forced = [] {
+    const char *e = getenv("MOPT_FD_ROTATION_HOME");
+    return e ? atoi(e) : -1;
+  }();
+  const int home = forced >= 0 ? forced
+                               : ((sizeof(S) == 8 && cov_mode != kCovGeneral) ? int(kFdRotationRegisters)
+                                                                              : int(kFdRotationLds));
+#define MOPT_LAUNCH_FD(COV)                                                                        \
+  (home == kFdRotationRegisters                                                                    \
+       ? (site.streaming                                                                           \
+              ? launchTiled(p2pForwardDiffKernel<S, true, COV, kFdRotationRegisters>, grid, site, args)  \
+              : launchTiled(p2pForwardDiffKernel<S, false, COV, kFdRotationRegisters>, grid, site, args)) \
+       : (site.streaming                                                                           \
+              ? launchTiled(p2pForwardDiffKernel<S, true, COV, kFdRotationLds>, grid, site, args)  \
+              : launchTiled(p2pForwardDiffKernel<S, false, COV, kFdRotationLds>, grid, site, args)))
+  switch (cov_mode) {
+    case kCovIdentity:
+      return MOPT_LAUNCH_FD(kCovIdentity);
+    case kCovSymmetric:
+      return MOPT_LAUNCH_FD(kCovSymmetric);
+    default:
+      return MOPT_LAUNCH_FD(kCovGeneral);
+  }
+#undef MOPT_LAUNCH_FD
+}
+template hipError_t launchForwardDiff<float>(const P2PSweepArgs<float> &, int, int, const LaunchSite &);
+template hipError_t launchForwardDiff<double>(const P2PSweepArgs<double> &, int, int,
+                                              const LaunchSite &);
+
+template <typename S>
+hipError_t launchForwardDiffResident(const P2PSweepArgs<S> *d_args, const LmControl *control,
+                                     int cov_mode, int grid, const LaunchSite &site) {
+  // tiles / num_tiles are not in reach of this signature: read through the argument block
+  const dim3 g(grid), b(kBlockThreads);
+#define MOPT_LAUNCH_FD_RESIDENT(COV)                                                              \
+  if (site.streaming)                                                                             \
+    hipLaunchKernelGGL((p2pForwardDiffResidentArgsKernel<S, true, COV>), g, b, 0, site.stream,    \
+                       d_args, control);                                                          \
+  else                                                                                            \
+    hipLaunchKernelGGL((p2pForwardDiffResidentArgsKernel<S, false, COV>), g, b, 0, site.stream,   \
+                       d_args, control)
+  switch (cov_mode) {
+    case kCovIdentity:
+      MOPT_LAUNCH_FD_RESIDENT(kCovIdentity);
+      break;
+    case kCovSymmetric:
+      MOPT_LAUNCH_FD_RESIDENT(kCovSymmetric);
+      break;
+    default:
+      MOPT_LAUNCH_FD_RESIDENT(kCovGeneral);
+      break;
+  }
+#undef MOPT_LAUNCH_FD_RESIDENT
+  return hipGetLastError();
+}
+template hipError_t launchForwardDiffResident<float>(const P2PSweepArgs<float> *, const LmControl *,
+                                                     int, int, const LaunchSite &);
+template hipError_t launchForwardDiffResident<double>(const P2PSweepArgs<double> *,
+                                                      const LmControl *, int, int,
+                                                      const LaunchSite &);
+
+}  // namespace mopt

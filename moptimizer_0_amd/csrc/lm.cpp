@@ -80,6 +80,10 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
       double hb[mopt_detail::kResultSlots];
       double yk = 0.0;
       float yf = 0.f;
+      if (costs[k]->matcher) {  // cost->update(x0) comes before every linearization (:54)
+        const int rcu = mopt_icp_update(costs[k], x, nullptr);
+        if (rcu != MOPT_OK) return rcu;
+      }
       const int rck = mopt_cost_linearize(costs[k], jacobian_modes[k], x, hb, hb + 64,
                                           lead->scalar_bytes == 8 ? static_cast<void *>(&yk)
                                                                   : static_cast<void *>(&yf));
@@ -144,9 +148,14 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
   // (Running each cost's sweeps on its own stream instead, joined by events, was measured and
   // dropped: a cross-queue dependency costs 7-13 us on this runtime, more than the sweeps that
   // would overlap — DESIGN.md section 3.)
-  for (int k = 0; k < num_costs; ++k)
-    if (costs[k]->foreign_pending || (costs[k]->own_async_pending && costs[k]->stream != s))
-      MOPT_HIP_TRY(quiesceCost(costs[k]));
+  // So does a sweep queued ahead for a linked cost (mopt_costs_link) that nobody has consumed yet.
+  for (int k = 0; k < num_costs; ++k) {
+    mopt_cost *ck = costs[k];
+    const bool other_stream = ck->stream != s;
+    if (ck->foreign_pending || (other_stream && (ck->own_async_pending || ck->prefetch.pending)))
+      MOPT_HIP_TRY(quiesceCost(ck));
+    ck->prefetch.pending = false;  // its partial rows and result are about to be overwritten
+  }
   unsigned long long base_sequence[mopt::kLmMaxCosts];
   for (int k = 0; k < num_costs; ++k) base_sequence[k] = costs[k]->combine.sequence + 1;
 

@@ -286,6 +286,13 @@ hipError_t launchRelayoutReproj(const double *points_xyzw, const int32_t *pixels
 template <typename S>
 hipError_t launchP2PLinearizeLiteral(const P2PSweepArgs<S> &args, int jac_mode, int cov_mode,
                                      int grid, const LaunchSite &site);
+// forward differences evaluated as the reference does (fd_kernels.hip); rows as the literal sweep's
+template <typename S>
+hipError_t launchForwardDiff(const P2PSweepArgs<S> &args, int cov_mode, int grid,
+                             const LaunchSite &site);
+template <typename S>
+hipError_t launchForwardDiffResident(const P2PSweepArgs<S> *d_args, const LmControl *control,
+                                     int cov_mode, int grid, const LaunchSite &site);
 // moment accumulation (analytic modes; numeric via the affine forward-difference basis)
 template <typename S>
 hipError_t launchP2PMoments(const P2PSweepArgs<S> &args, int grid, const LaunchSite &site);

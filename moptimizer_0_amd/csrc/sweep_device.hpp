@@ -1,0 +1,174 @@
+// Device-side building blocks shared by the sweep kernels (sweep_kernels.hip, fd_kernels.hip):
+// 16-byte lane loads, the ping-pong tile walk and the LDS-transpose workgroup reduction.  Everything
+// is in an anonymous namespace of the including translation unit.
+#pragma once
+
+#include "sweep.hpp"
+
+#include <hip/hip_ext.h>
+
+#include <type_traits>
+
+namespace mopt {
+namespace {
+
+template <typename S>
+struct alignas(16) Pack {
+  S v[16 / sizeof(S)];
+};
+
+template <typename S>
+__device__ __forceinline__ Pack<S> loadPack(const S *p) {
+  return *reinterpret_cast<const Pack<S> *>(p);
+}
+
+// Streaming (non-temporal) 16-byte load: the line is not kept in L2 / Infinity Cache.  Used when
+// the data set is larger than the 256 MiB Infinity Cache, where a sweep can never re-use a line
+// of the previous sweep anyway and allocating them only costs fill bandwidth.
+template <typename S>
+__device__ __forceinline__ Pack<S> loadPackStreaming(const S *p) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 raw = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+  Pack<S> out;
+  __builtin_memcpy(&out, &raw, sizeof out);
+  return out;
+}
+
+template <typename S>
+__device__ __forceinline__ S lossWeight(int kind, S param, S s) {
+  if (kind == kLossGemanMcClure) {
+    const S d = s + param;
+    return (param * param) / (d * d);
+  }
+  return S(1);
+}
+
+// r = (R p + t) - q with the association of a 4x4 * [p;1] product followed by the subtraction
+// (tst/point2point.cpp:42-45).
+template <typename S>
+__device__ __forceinline__ void p2pResidual(const S (&T)[12], const S (&p)[3], const S (&q)[3],
+                                            S (&r)[3]) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const S warped = ((T[a * 4 + 0] * p[0] + T[a * 4 + 1] * p[1]) + T[a * 4 + 2] * p[2]) +
+                     T[a * 4 + 3];
+    r[a] = warped - q[a];
+  }
+}
+
+// A slot of the tile layout holds a correspondence when its index is inside the data set and
+// its target is not the NaN marker — the device form of the model's `f` returning false for an
+// index (model.h:32, linearization.h:102,144): padding, and source points the correspondence
+// search (icpMatchKernel) left unmatched.
+template <typename S>
+__device__ __forceinline__ bool isCorrespondence(long long index, long long count, S target_x) {
+  return index < count && target_x == target_x;
+}
+
+// Walks this workgroup's tiles (blockIdx.x, + gridDim.x, ...) with two register sets used in
+// ping-pong: the six 16-byte loads of the NEXT tile are issued into the idle set before the
+// arithmetic of the current one starts, and nothing is ever copied between the sets.
+//
+// Two details matter to the generated waits (checked in the ISA):
+//  * a copy `cur = nxt` at the loop end forces `s_waitcnt vmcnt(0)` there, leaving one tile in
+//    flight per wave;
+//  * a *conditional* prefetch (`if (next < n) load`) makes the wait at the join conservative
+//    (vmcnt(0) again), because on the not-taken path the needed loads are the youngest.  So the
+//    prefetch is unconditional and, past the end, re-reads this workgroup's last tile (an L2 hit).
+// body(packs, first): packs[plane].v[e] is coordinate `plane` of correspondence first + e.
+template <typename S, bool STREAMING, typename Body>
+__device__ __forceinline__ void sweepTiles(const S *tiles, int num_tiles, Body &&body) {
+  constexpr int V = TileShape<S>::kVec;
+  constexpr int TP = TileShape<S>::kPoints;
+  const int stride = gridDim.x;
+  const int first_tile = blockIdx.x;
+  if (first_tile >= num_tiles) return;
+  const int mine = (num_tiles - first_tile + stride - 1) / stride;  // tiles of this workgroup
+  const S *lane_base = tiles + threadIdx.x * V;
+  auto tileOf = [&](int i) { return first_tile + (i < mine ? i : mine - 1) * stride; };
+  auto load = [&](Pack<S>(&dst)[6], int tile) {
+    const S *base = lane_base + size_t(tile) * TileShape<S>::kP2PScalars;
+#pragma unroll
+    for (int pl = 0; pl < 6; ++pl)
+      dst[pl] = STREAMING ? loadPackStreaming<S>(base + pl * TP) : loadPack<S>(base + pl * TP);
+  };
+  Pack<S> a[6], b[6];
+  load(a, tileOf(0));
+  for (int i = 0; i < mine; i += 2) {
+    load(b, tileOf(i + 1));
+    body(a, (long long)tileOf(i) * TP + threadIdx.x * V);
+    if (i + 1 >= mine) break;
+    load(a, tileOf(i + 2));
+    body(b, (long long)tileOf(i + 1) * TP + threadIdx.x * V);
+  }
+}
+
+__device__ __forceinline__ double waveSum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// Per-thread accumulators -> one row of `NACC` doubles per workgroup, through an LDS transpose.
+//
+// Cross-lane shuffles (ds_bpermute) go through the CU's single LDS crossbar: 6 steps x 2 dwords
+// x NACC values x 4 waves of them cost microseconds per workgroup (measured: the 23-value
+// epilogue took as long as ~4 tiles of streaming).  Instead every lane stores its values once
+// (conflict-free ds_write_b64, row of 64 lanes per value, rows padded to 72 doubles so that four
+// consecutive value-rows tile the 64 banks), then thread (k, part) adds the 4 waves x 8 lanes of
+// value k whose lane index is = part (mod 8) and the 8 parts are combined with three xor
+// shuffles.  Order of additions is fixed, so the row is reproducible bit for bit.  Values are
+// processed in chunks of 23 to bound LDS at 53 KB per workgroup.
+constexpr int kReduceChunk = 23;
+constexpr int kReduceRow = 72;
+
+template <int NACC>
+__device__ __forceinline__ void blockReduceStore(double (&acc)[NACC], double *out_row) {
+  constexpr int kWaves = kBlockThreads / 64;
+  constexpr int kChunk = NACC < kReduceChunk ? NACC : kReduceChunk;
+  constexpr int kPasses = (NACC + kChunk - 1) / kChunk;
+  __shared__ double lds[kWaves][kChunk][kReduceRow];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int k_read = threadIdx.x >> 3;  // value handled in the read phase (0..31)
+  const int part = threadIdx.x & 7;
+#pragma unroll
+  for (int pass = 0; pass < kPasses; ++pass) {
+    if (pass > 0) __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < kChunk; ++kk) {
+      const int k = pass * kChunk + kk;
+      if (k < NACC) lds[wave][kk][lane] = acc[k];
+    }
+    __syncthreads();
+    const int k_out = pass * kChunk + k_read;
+    if (k_read < kChunk && k_out < NACC) {
+      double v = 0.0;
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v += lds[w][k_read][j * 8 + part];
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      if (part == 0) out_row[k_out] = v;
+    }
+  }
+}
+
+
+// moments / cost / forward-difference sweeps: (tiles, num_tiles, args) signature (the leading scalar
+// arguments are preloaded into SGPRs at wave launch); optionally a timestamped dispatch
+template <typename Kernel, typename S>
+hipError_t launchTiled(Kernel kernel, int grid, const LaunchSite &site, const P2PSweepArgs<S> &args) {
+  if (site.time_start && site.time_stop)
+    hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(kBlockThreads), 0, site.stream, site.time_start,
+                          site.time_stop, 0, args.tiles, args.num_tiles, args);
+  else
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlockThreads), 0, site.stream, args.tiles,
+                       args.num_tiles, args);
+  return hipGetLastError();
+}
+
+}  // namespace
+}  // namespace mopt

@@ -19,177 +19,11 @@
 //     therefore the result — is deterministic for a given device and count.
 //   * A second tiny kernel adds the workgroup partials in a fixed order and writes
 //     H (column-major) | b | sum_sq; no atomics anywhere.
-#include "sweep.hpp"
+#include "sweep_device.hpp"
 #include "lm_device.hpp"
-
-#include <hip/hip_ext.h>
-
-#include <type_traits>
 
 namespace mopt {
 namespace {
-
-template <typename S>
-struct alignas(16) Pack {
-  S v[16 / sizeof(S)];
-};
-
-template <typename S>
-__device__ __forceinline__ Pack<S> loadPack(const S *p) {
-  return *reinterpret_cast<const Pack<S> *>(p);
-}
-
-// Streaming (non-temporal) 16-byte load: the line is not kept in L2 / Infinity Cache.  Used when
-// the data set is larger than the 256 MiB Infinity Cache, where a sweep can never re-use a line
-// of the previous sweep anyway and allocating them only costs fill bandwidth.
-template <typename S>
-__device__ __forceinline__ Pack<S> loadPackStreaming(const S *p) {
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  const u32x4 raw = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
-  Pack<S> out;
-  __builtin_memcpy(&out, &raw, sizeof out);
-  return out;
-}
-
-template <typename S>
-__device__ __forceinline__ S lossWeight(int kind, S param, S s) {
-  if (kind == kLossGemanMcClure) {
-    const S d = s + param;
-    return (param * param) / (d * d);
-  }
-  return S(1);
-}
-
-// r = (R p + t) - q with the association of a 4x4 * [p;1] product followed by the subtraction
-// (tst/point2point.cpp:42-45).
-template <typename S>
-__device__ __forceinline__ void p2pResidual(const S (&T)[12], const S (&p)[3], const S (&q)[3],
-                                            S (&r)[3]) {
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    const S warped = ((T[a * 4 + 0] * p[0] + T[a * 4 + 1] * p[1]) + T[a * 4 + 2] * p[2]) +
-                     T[a * 4 + 3];
-    r[a] = warped - q[a];
-  }
-}
-
-// A slot of the tile layout holds a correspondence when its index is inside the data set and
-// its target is not the NaN marker — the device form of the model's `f` returning false for an
-// index (model.h:32, linearization.h:102,144): padding, and source points the correspondence
-// search (icpMatchKernel) left unmatched.
-template <typename S>
-__device__ __forceinline__ bool isCorrespondence(long long index, long long count, S target_x) {
-  return index < count && target_x == target_x;
-}
-
-// Walks this workgroup's tiles (blockIdx.x, + gridDim.x, ...) with two register sets used in
-// ping-pong: the six 16-byte loads of the NEXT tile are issued into the idle set before the
-// arithmetic of the current one starts, and nothing is ever copied between the sets.
-//
-// Two details matter to the generated waits (checked in the ISA):
-//  * a copy `cur = nxt` at the loop end forces `s_waitcnt vmcnt(0)` there, leaving one tile in
-//    flight per wave;
-//  * a *conditional* prefetch (`if (next < n) load`) makes the wait at the join conservative
-//    (vmcnt(0) again), because on the not-taken path the needed loads are the youngest.  So the
-//    prefetch is unconditional and, past the end, re-reads this workgroup's last tile (an L2 hit).
-// body(packs, first): packs[plane].v[e] is coordinate `plane` of correspondence first + e.
-template <typename S, bool STREAMING, typename Body>
-__device__ __forceinline__ void sweepTiles(const S *tiles, int num_tiles, Body &&body) {
-  constexpr int V = TileShape<S>::kVec;
-  constexpr int TP = TileShape<S>::kPoints;
-  const int stride = gridDim.x;
-  const int first_tile = blockIdx.x;
-  if (first_tile >= num_tiles) return;
-  const int mine = (num_tiles - first_tile + stride - 1) / stride;  // tiles of this workgroup
-  const S *lane_base = tiles + threadIdx.x * V;
-  auto tileOf = [&](int i) { return first_tile + (i < mine ? i : mine - 1) * stride; };
-  auto load = [&](Pack<S>(&dst)[6], int tile) {
-    const S *base = lane_base + size_t(tile) * TileShape<S>::kP2PScalars;
-#pragma unroll
-    for (int pl = 0; pl < 6; ++pl)
-      dst[pl] = STREAMING ? loadPackStreaming<S>(base + pl * TP) : loadPack<S>(base + pl * TP);
-  };
-  Pack<S> a[6], b[6];
-  load(a, tileOf(0));
-  for (int i = 0; i < mine; i += 2) {
-    load(b, tileOf(i + 1));
-    body(a, (long long)tileOf(i) * TP + threadIdx.x * V);
-    if (i + 1 >= mine) break;
-    load(a, tileOf(i + 2));
-    body(b, (long long)tileOf(i + 1) * TP + threadIdx.x * V);
-  }
-}
-
-// The same walk with one register set: for sweeps whose arithmetic, not the memory stream, sets the
-// pace and that need their registers for it — latency is then hidden by the 2-3 waves a SIMD holds
-// instead of by a second tile in flight per wave.
-template <typename S, bool STREAMING, typename Body>
-__device__ __forceinline__ void sweepTilesSingle(const S *tiles, int num_tiles, Body &&body) {
-  constexpr int V = TileShape<S>::kVec;
-  constexpr int TP = TileShape<S>::kPoints;
-  const S *lane_base = tiles + threadIdx.x * V;
-  for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
-    const S *base = lane_base + size_t(tile) * TileShape<S>::kP2PScalars;
-    Pack<S> cur[6];
-#pragma unroll
-    for (int pl = 0; pl < 6; ++pl)
-      cur[pl] = STREAMING ? loadPackStreaming<S>(base + pl * TP) : loadPack<S>(base + pl * TP);
-    body(cur, (long long)tile * TP + threadIdx.x * V);
-  }
-}
-
-__device__ __forceinline__ double waveSum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
-}
-
-// Per-thread accumulators -> one row of `NACC` doubles per workgroup, through an LDS transpose.
-//
-// Cross-lane shuffles (ds_bpermute) go through the CU's single LDS crossbar: 6 steps x 2 dwords
-// x NACC values x 4 waves of them cost microseconds per workgroup (measured: the 23-value
-// epilogue took as long as ~4 tiles of streaming).  Instead every lane stores its values once
-// (conflict-free ds_write_b64, row of 64 lanes per value, rows padded to 72 doubles so that four
-// consecutive value-rows tile the 64 banks), then thread (k, part) adds the 4 waves x 8 lanes of
-// value k whose lane index is = part (mod 8) and the 8 parts are combined with three xor
-// shuffles.  Order of additions is fixed, so the row is reproducible bit for bit.  Values are
-// processed in chunks of 23 to bound LDS at 53 KB per workgroup.
-constexpr int kReduceChunk = 23;
-constexpr int kReduceRow = 72;
-
-template <int NACC>
-__device__ __forceinline__ void blockReduceStore(double (&acc)[NACC], double *out_row) {
-  constexpr int kWaves = kBlockThreads / 64;
-  constexpr int kChunk = NACC < kReduceChunk ? NACC : kReduceChunk;
-  constexpr int kPasses = (NACC + kChunk - 1) / kChunk;
-  __shared__ double lds[kWaves][kChunk][kReduceRow];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int k_read = threadIdx.x >> 3;  // value handled in the read phase (0..31)
-  const int part = threadIdx.x & 7;
-#pragma unroll
-  for (int pass = 0; pass < kPasses; ++pass) {
-    if (pass > 0) __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < kChunk; ++kk) {
-      const int k = pass * kChunk + kk;
-      if (k < NACC) lds[wave][kk][lane] = acc[k];
-    }
-    __syncthreads();
-    const int k_out = pass * kChunk + k_read;
-    if (k_read < kChunk && k_out < NACC) {
-      double v = 0.0;
-#pragma unroll
-      for (int w = 0; w < kWaves; ++w)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v += lds[w][k_read][j * 8 + part];
-      v += __shfl_xor(v, 1, 64);
-      v += __shfl_xor(v, 2, 64);
-      v += __shfl_xor(v, 4, 64);
-      if (part == 0) out_row[k_out] = v;
-    }
-  }
-}
 
 // acc += w J^T S J (upper triangle, or all n*n entries when S is not symmetric), w J^T S r, r^T r.
 // J is m x n (row index = output), cov row-major m x m.  FULL selects the n*n form.
@@ -288,14 +122,8 @@ __device__ __forceinline__ void p2pPointLiteral(
 #pragma unroll
       for (int j = 0; j < 6; ++j) J[a][j] = Jl[a][j];
   } else {
-    // forward differences, nominal step (linearization.h:103-106); 1/h_j is formed on the host
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      S rp[3];
-      p2pResidual<S>(A.T[1 + j], p, q, rp);
-#pragma unroll
-      for (int a = 0; a < 3; ++a) J[a][j] = (rp[a] - r[a]) * A.inv_h[j];
-    }
+    // forward differences are p2pForwardDiffKernel's (7 transforms do not fit the scalar registers)
+    static_assert(JAC != kJacNumeric, "forward differences: p2pForwardDiffKernel");
   }
   const S rr = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
   const S w = lossWeight<S>(A.loss_kind, A.loss_param, rr);
@@ -337,148 +165,6 @@ __global__ __launch_bounds__(kBlockThreads) void p2pLinearizeLiteralResidentKern
   if (control->done) return;
   const P2PSweepArgs<S> A = *d_args;
   p2pLinearizeLiteralBody<S, JAC, COV>(A);
-}
-
-// ---- point-to-point, forward differences as the reference evaluates them, identity covariance --
-// The literal kernel above carries 7 transforms x 12 scalars as kernel arguments; in fp64 that is
-// 168 SGPRs of constants against ~100 available, so the compiler spills them and the sweep ran at
-// 28-44 % of the HBM roof.  This form of the same arithmetic
-//   * keeps the constants in LDS and re-reads what a step needs (same-address reads: one broadcast
-//     each; a compiler barrier in front keeps them from being hoisted into ~114 VGPRs);
-//   * uses what the reference's perturbed models have in common: x + h e_j for a translation
-//     parameter leaves R untouched, so r+_a - r_a is EXACTLY zero for a != j and the j-th entry
-//     only needs the shared partial sum (R p)_j — three columns cost 4 operations each instead of
-//     a transformed point each — and J^T J then has three structural zeros and nine one-term
-//     entries;
-//   * spells the transformed point as fma(T2, p2, fma(T1, p1, T0 p0)) + t, the contraction of the
-//     reference's 4x4 * [p;1] product (tst/point2point.cpp:42-45 under -march=native), for every
-//     one of the seven residuals alike, so that r+ - r carries the same rounding as on the CPU.
-// Every J entry, the loss weight and every product are still formed per point (linearization.h:
-// 101-117); rows have the kAccSym layout of the literal kernel.
-template <typename S>
-struct ForwardDiffConstants {
-  S T0[12];           // [R | t] at x
-  S Tr[3][12];        // at x + h_j e_j, j = 3..5 (rotation parameters)
-  S t_plus[3];        // t_j + h_j, j = 0..2
-  S inv_h[kNumParams];
-  S loss_param;
-  int loss_kind;
-};
-
-template <typename S, bool STREAMING>
-__device__ __forceinline__ void p2pForwardDiffBody(const S *tiles, int num_tiles,
-                                                   const P2PSweepArgs<S> &A) {
-  constexpr int V = TileShape<S>::kVec;
-  __shared__ ForwardDiffConstants<S> K;
-  if (threadIdx.x < 12) K.T0[threadIdx.x] = A.T[0][threadIdx.x];
-  if (threadIdx.x >= 64 && threadIdx.x < 64 + 36)
-    K.Tr[(threadIdx.x - 64) / 12][(threadIdx.x - 64) % 12] =
-        A.T[4 + (threadIdx.x - 64) / 12][(threadIdx.x - 64) % 12];
-  if (threadIdx.x >= 128 && threadIdx.x < 131)
-    K.t_plus[threadIdx.x - 128] = A.T[1 + (threadIdx.x - 128)][(threadIdx.x - 128) * 4 + 3];
-  if (threadIdx.x >= 192 && threadIdx.x < 192 + kNumParams) K.inv_h[threadIdx.x - 192] = A.inv_h[threadIdx.x - 192];
-  if (threadIdx.x == 255) {
-    K.loss_param = A.loss_param;
-    K.loss_kind = A.loss_kind;
-  }
-  __syncthreads();
-
-  double acc[kAccSym];
-#pragma unroll
-  for (int k = 0; k < kAccSym; ++k) acc[k] = 0.0;
-  const long long count = A.count;
-
-  sweepTiles<S, STREAMING>(tiles, num_tiles, [&](const Pack<S>(&cur)[6], long long first) {
-    // one point at a time, as a real loop: unrolled, the scheduler interleaves the points and the
-    // kernel needs > 300 registers
-#pragma unroll 1
-    for (int e = 0; e < V; ++e) {
-      asm volatile("" ::: "memory");  // constants come from LDS here, not from registers kept alive
-      S in[6];
-#pragma unroll
-      for (int pl = 0; pl < 6; ++pl) {
-        in[pl] = cur[pl].v[0];
-#pragma unroll
-        for (int k = 1; k < V; ++k) in[pl] = (e == k) ? cur[pl].v[k] : in[pl];
-      }
-      const S p[3] = {in[0], in[1], in[2]};
-      const bool valid = isCorrespondence(first + e, count, in[3]);
-      const S q[3] = {valid ? in[3] : S(0), valid ? in[4] : S(0), valid ? in[5] : S(0)};
-      S s[3], r[3], d[3];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        s[a] = __builtin_fma(K.T0[a * 4 + 2], p[2],
-                             __builtin_fma(K.T0[a * 4 + 1], p[1], K.T0[a * 4 + 0] * p[0]));
-        r[a] = (s[a] + K.T0[a * 4 + 3]) - q[a];
-      }
-      // translation columns: only entry (j, j) moves
-#pragma unroll
-      for (int j = 0; j < 3; ++j) d[j] = (((s[j] + K.t_plus[j]) - q[j]) - r[j]) * K.inv_h[j];
-      // rotation columns: a transformed point each
-      S Acol[3][3];  // Acol[a][c] = J[a][3 + c]
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          const S sp = __builtin_fma(K.Tr[c][a * 4 + 2], p[2],
-                                     __builtin_fma(K.Tr[c][a * 4 + 1], p[1], K.Tr[c][a * 4 + 0] * p[0]));
-          const S rp = (sp + K.Tr[c][a * 4 + 3]) - q[a];
-          Acol[a][c] = (rp - r[a]) * K.inv_h[3 + c];
-        }
-      }
-      S rr = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
-      S w = lossWeight<S>(K.loss_kind, K.loss_param, rr);
-      w = valid ? w : S(0);
-      rr = valid ? rr : S(0);
-      // w J^T J (upper triangle, column-wise: k = j (j + 1) / 2 + i), w J^T r, r^T r with
-      // J = [diag(d) | Acol]; entries (0,1), (0,2), (1,2) are sums of exact zeros
-      S wd[3];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) wd[a] = w * d[a];
-      auto wA = [&](int a, int c) { return w * Acol[a][c]; };
-      acc[0] += double(wd[0] * d[0]);
-      acc[2] += double(wd[1] * d[1]);
-      acc[5] += double(wd[2] * d[2]);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const int col = 3 + c, base = col * (col + 1) / 2;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) acc[base + i] += double(wd[i] * Acol[i][c]);
-#pragma unroll
-        for (int c2 = 0; c2 <= c; ++c2) {
-          S v = 0;
-#pragma unroll
-          for (int a = 0; a < 3; ++a) v += wA(a, c2) * Acol[a][c];
-          acc[base + 3 + c2] += double(v);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 3; ++i) acc[21 + i] += double(wd[i] * r[i]);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        S v = 0;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) v += wA(a, c) * r[a];
-        acc[24 + c] += double(v);
-      }
-      acc[27] += double(rr);
-    }
-  });
-  blockReduceStore<kAccSym>(acc, A.partials + size_t(blockIdx.x) * kAccSym);
-}
-
-template <typename S, bool STREAMING>
-__global__ __launch_bounds__(kBlockThreads) void p2pForwardDiffKernel(const S *tiles, int num_tiles,
-                                                                      const P2PSweepArgs<S> A) {
-  p2pForwardDiffBody<S, STREAMING>(tiles, num_tiles, A);
-}
-
-template <typename S, bool STREAMING>
-__global__ __launch_bounds__(kBlockThreads) void p2pForwardDiffResidentArgsKernel(
-    const P2PSweepArgs<S> *__restrict__ d_args, const LmControl *__restrict__ control) {
-  if (control->done) return;
-  p2pForwardDiffBody<S, STREAMING>(d_args->tiles, d_args->num_tiles, *d_args);
 }
 
 // ---- point-to-point, weighted moments --------------------------------------------------------
@@ -876,17 +562,24 @@ __device__ __forceinline__ void icpMatchBody(const IcpMatchArgs<S> &A, const S (
       // The source's own cell first; every other cell of the 3 x 3 x 3 block is visited only if
       // its box can hold something at least as close as what has been found (or within the
       // maximum distance while nothing has) — the bound is the distance to the own cell's faces,
-      // relaxed by 1e-9 relative (targets were binned with the same floor()).  Range bounds are
+      // relaxed by a few ulps of the coordinates (targets were binned with floor()).  Range bounds are
       // fetched only for what is visited.  At about one target per cell and a source close to its
       // target this leaves 1-3 cells of 27 and takes most of the divergent tail off the wave.
+      // The offsets f are recomputed from the cell index and can disagree with the binning's
+      // floor((w - origin) / cell) by a few ulps OF THE COORDINATE (not of the offset): every gap to
+      // a face is shortened by that much before it is squared, in the scalar type's own epsilon.
+      constexpr S kUlps = S(16) * std::numeric_limits<S>::epsilon();
       const S fx = w[0] - (A.origin[0] + S(c[0]) * A.cell);  // offsets inside the own cell, [0, cell)
       const S fy = w[1] - (A.origin[1] + S(c[1]) * A.cell);
       const S fz = w[2] - (A.origin[2] + S(c[2]) * A.cell);
-      const S gx[2] = {fx, A.cell - fx};
-      const S gap_y[3] = {fy, S(0), A.cell - fy};
-      const S gap_z[3] = {fz, S(0), A.cell - fz};
+      const S ex = kUlps * (fabs(w[0]) + fabs(A.origin[0]) + A.cell);
+      const S ey = kUlps * (fabs(w[1]) + fabs(A.origin[1]) + A.cell);
+      const S ez = kUlps * (fabs(w[2]) + fabs(A.origin[2]) + A.cell);
+      const S gx[2] = {fx - ex, (A.cell - fx) - ex};
+      const S gap_y[3] = {fy - ey, S(0), (A.cell - fy) - ey};
+      const S gap_z[3] = {fz - ez, S(0), (A.cell - fz) - ez};
       auto within = [&](S bound) {
-        return bound * (S(1) - S(1e-9)) <= (found ? best_d : A.max_dist2);
+        return bound * (S(1) - kUlps) <= (found ? best_d : A.max_dist2);
       };
       auto sq = [](S v) { return v > S(0) ? v * v : S(0); };
       visit(c[1], c[2], c[0], c[0]);
@@ -1363,18 +1056,6 @@ hipError_t launchSweep(Kernel kernel, int grid, const LaunchSite &site, const Ar
   return hipGetLastError();
 }
 
-// moments / cost sweeps: (tiles, num_tiles, args) signature; optionally timestamped dispatch
-template <typename Kernel, typename S>
-hipError_t launchTiled(Kernel kernel, int grid, const LaunchSite &site, const P2PSweepArgs<S> &args) {
-  if (site.time_start && site.time_stop)
-    hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(kBlockThreads), 0, site.stream, site.time_start,
-                          site.time_stop, 0, args.tiles, args.num_tiles, args);
-  else
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlockThreads), 0, site.stream, args.tiles,
-                       args.num_tiles, args);
-  return hipGetLastError();
-}
-
 template <typename S, int JAC>
 hipError_t launchLiteralCov(const P2PSweepArgs<S> &args, int cov_mode, int grid,
                             const LaunchSite &site) {
@@ -1387,6 +1068,7 @@ hipError_t launchLiteralCov(const P2PSweepArgs<S> &args, int cov_mode, int grid,
       return launchSweep(p2pLinearizeLiteralKernel<S, JAC, kCovGeneral>, grid, site, args);
   }
 }
+
 }  // namespace
 
 template <typename S>
@@ -1398,10 +1080,7 @@ hipError_t launchP2PLinearizeLiteral(const P2PSweepArgs<S> &args, int jac_mode, 
     case kJacAnalyticTst:
       return launchLiteralCov<S, kJacAnalyticTst>(args, cov_mode, grid, site);
     case kJacNumeric:
-      if (cov_mode == kCovIdentity)
-        return site.streaming ? launchTiled(p2pForwardDiffKernel<S, true>, grid, site, args)
-                              : launchTiled(p2pForwardDiffKernel<S, false>, grid, site, args);
-      return launchLiteralCov<S, kJacNumeric>(args, cov_mode, grid, site);
+      return launchForwardDiff<S>(args, cov_mode, grid, site);
     case kJacAnalyticLeft:
       return launchLiteralCov<S, kJacAnalyticLeft>(args, cov_mode, grid, site);
     default:
@@ -1636,18 +1315,7 @@ hipError_t launchP2PLiteralResident(const P2PSweepArgs<S> *d_args, const LmContr
     case kJacAnalyticTst:
       return launchLiteralResidentCov<S, kJacAnalyticTst>(d_args, control, cov_mode, grid, site);
     case kJacNumeric:
-      if (cov_mode == kCovIdentity) {
-        // tiles / num_tiles are not in reach of this signature: read them through the argument
-        // block like everything else
-        if (site.streaming)
-          hipLaunchKernelGGL((p2pForwardDiffResidentArgsKernel<S, true>), dim3(grid),
-                             dim3(kBlockThreads), 0, site.stream, d_args, control);
-        else
-          hipLaunchKernelGGL((p2pForwardDiffResidentArgsKernel<S, false>), dim3(grid),
-                             dim3(kBlockThreads), 0, site.stream, d_args, control);
-        return hipGetLastError();
-      }
-      return launchLiteralResidentCov<S, kJacNumeric>(d_args, control, cov_mode, grid, site);
+      return launchForwardDiffResident<S>(d_args, control, cov_mode, grid, site);
     case kJacAnalyticLeft:
       return launchLiteralResidentCov<S, kJacAnalyticLeft>(d_args, control, cov_mode, grid, site);
     default:

@@ -63,13 +63,26 @@ class ShardedSweep:
 
 
 def gpu_point2point_sweep(cost, jac_mode_default=None):
-    """ShardedSweep over a Point2PointCost (this rank's shard) using torch's current stream."""
+    """ShardedSweep over a Point2PointCost (this rank's shard) using torch's current stream.
+
+    The all-reduce is this wrapper's: the cost itself must not be combining (with the peer
+    transport selected the asynchronous calls already return the sums over all ranks, and the
+    all-reduce would multiply them by the world size)."""
+
+    def _local_only():
+        mode = cost.get_combine()[0]
+        if mode != 0:  # MOPT_COMBINE_NONE
+            raise RuntimeError("ShardedSweep all-reduces the ranks' sums itself: select "
+                               "set_combine(COMBINE_NONE) on the cost first (combine mode %d is "
+                               "selected)" % mode)
 
     def lin(x, jac_mode, out):
+        _local_only()
         cost.linearize_async(x, jac_mode, out.data_ptr(),
                              torch.cuda.current_stream().cuda_stream)
 
     def cst(x, out):
+        _local_only()
         cost.compute_cost_async(x, out.data_ptr() + 42 * 8,
                                 torch.cuda.current_stream().cuda_stream)
 
@@ -91,9 +104,16 @@ def attach_combines(cost, rank, world, want=("host", "peer", "rccl"), group=None
     torch.distributed only as the side channel (a name, IPC handles, an RCCL id).  A transport
     counts only if EVERY rank attached it.  Returns the list of usable transports, in `want` order;
     collective: every rank calls it with the same arguments.  RCCL cannot span ranks that share a
-    GPU, so it is only tried with the "nccl" backend (one rank per GPU)."""
+    GPU, so it is only tried with the "nccl" backend (one rank per GPU).
+
+    The C attach calls select what they attach; a transport that attached here but not on every
+    rank must not stay selected (this rank's next blocking sweep would wait for peers that never
+    push), and neither should whichever happened to be attached last.  On return the cost is
+    back on the transport it had selected on entry (MOPT_COMBINE_NONE for a fresh cost): the
+    caller picks one of the returned names with `cost.set_combine(...)`, on every rank alike."""
     from . import _capi as capi
     import os
+    selected_on_entry = cost.get_combine()[0]
     usable = []
     for name in want:
         ok, err = True, None
@@ -128,5 +148,6 @@ def attach_combines(cost, rank, world, want=("host", "peer", "rccl"), group=None
             usable.append(name)
         elif log is not None:
             log("rank %d: combine transport %r unavailable (%s)" % (rank, name, err or "on a peer"))
+    cost.set_combine(selected_on_entry)
     dist.barrier(group=group)  # nobody sweeps before everybody has attached
     return usable

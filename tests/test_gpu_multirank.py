@@ -146,22 +146,93 @@ def test_random_call_sequences_over_sharded_costs(hip_lib, tmp_path, world, seed
     assert (ops == 2).sum() > 30
 
 
+def _check_multirank_line(line, world, rehearsal):
+    """What a > 1-rank bench line must carry: the headline transport named, the
+    RCCL figure with the rank count the communicator itself reports (or, when ranks share a GPU,
+    why there is none), every transport's step time / rate / step-level roofline fraction, and the
+    CPU baseline on rank 0."""
+    assert line["n_gpus"] == world
+    cfg = line["config"]
+    assert cfg["collective"] in ("host", "peer", "rccl"), cfg["collective"]
+    assert cfg["collective"] in line["by_collective"]
+    for name, entry in line["by_collective"].items():
+        assert entry["ms_per_step"] > 0 and entry["value"] > 0 and 0 < entry["step_frac"] < 1.2, (name, entry)
+    assert set(line["roofline"]["step_frac_by_collective"]) == set(line["by_collective"])
+    assert {"none", "host", "peer"} <= set(line["ms_per_step_by_collective"])
+    rccl = line["rccl"]
+    if rehearsal:
+        assert rccl["attached"] is False and "share" in rccl["reason"]
+        assert cfg["rehearsal"] and cfg["rccl_ranks"] is None
+    else:
+        assert rccl["attached"] and rccl["ranks"] == world and rccl["spans_all_ranks"]
+        assert rccl["ms_per_step"] > 0 and cfg["rccl_ranks"] == world
+        assert "rccl" in line["by_collective"]
+    cpu = line["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["value"] > 1e6
+    assert "extras_incomplete" not in line, line.get("note")
+    c4 = line["config4_strong"]
+    assert c4["total_correspondences"] == 10_000_000 and c4["ms_per_step"] > 0
+    assert c4["kernel_ms"] > 0 and set(c4["by_collective"]) >= {"none", "host", "peer"}
+
+
 def test_bench_launches_its_own_ranks(hip_lib):
     """`python bench.py --gpus 2` without a launcher (as the driver calls it), rehearsed on however
-    many GPUs this box has: one JSON line, n_gpus = 2, a fused combine selected."""
+    many GPUs this box has: one JSON line, n_gpus = 2, a fused combine selected, and every field a
+    > 1-rank line has to carry."""
     import json
     env = dict(os.environ)
     import torch
-    if torch.cuda.device_count() < 2:
+    rehearsal = torch.cuda.device_count() < 2
+    if rehearsal:
         env["MOPT_BENCH_BACKEND"] = "gloo"
     out = subprocess.run([sys.executable, os.path.join(ds.ROOT, "bench.py"), "--gpus", "2",
-                          "--steps", "20", "--warmup", "3", "--n", "300000", "--settle-ms", "5"],
+                          "--steps", "20", "--warmup", "3", "--n", "300000", "--settle-ms", "5",
+                          "--cpu-seconds", "1"],
                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert out.returncode == 0, out.stderr.decode()[-3000:]
     lines = [ln for ln in out.stdout.decode().splitlines() if ln.strip()]
     assert len(lines) == 1
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["config"]["collective"] in ("host", "peer")
     assert line["check"]["H00"] == 600000.0  # both shards were summed
-    assert set(line["ms_per_step_by_collective"]) >= {"none", "host", "peer"}
-    assert line["config4_strong"]["total_correspondences"] == 10_000_000
+    _check_multirank_line(line, 2, rehearsal)
+
+
+def test_driver_command_rehearsed_with_four_ranks(hip_lib):
+    """The driver's multi-GPU command as it stands — default workload (10 M correspondences per
+    rank), default settling, every extra pass, the 10 M strong-scaling split, the CPU baseline —
+    with 4 ranks (this pool lets 6 processes share one GPU, and the test runner is one of them;
+    scripts/rehearse_driver_command.sh runs the same with 6 outside pytest), started by
+    torch.distributed.run like the driver does.  It must report every field and finish well inside
+    the driver's 600 s."""
+    import json
+    import time
+    import torch
+    ndev = torch.cuda.device_count()
+    world = 4
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    rehearsal = ndev < world
+    if rehearsal:
+        env["MOPT_BENCH_BACKEND"] = "gloo"
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    t0 = time.time()
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                          "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ds.ROOT, "bench.py"),
+                          "--gpus", str(world), "--steps", "20", "--warmup", "5"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=500)
+    elapsed = time.time() - t0
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.lstrip().startswith("{")]
+    assert len(lines) == 1, out.stdout.decode()[-2000:]
+    line = json.loads(lines[0])
+    assert line["check"]["H00"] == 10_000_000.0 * world
+    assert line["config"]["correspondences_per_gpu"] == 10_000_000
+    _check_multirank_line(line, world, rehearsal)
+    assert elapsed < 300, elapsed
+    keep = os.path.join(ds.ROOT, "gpurun_out")
+    if os.path.isdir(keep):
+        line["_rehearsal_wall_s"] = elapsed
+        with open(os.path.join(keep, "r3_4rank_driver_command_rehearsal.json"), "w") as f:
+            json.dump(line, f, indent=1)

@@ -28,11 +28,14 @@ def fd_tolerance(x, variant=0):
     the north-star bar applies as it stands.  AUTO selects that evaluation whenever a step is small
     enough for the other one to matter.
 
-    The moments evaluation (variant 2) forms column j as ((R_j - R) p + (t_j - t)) / h_j, which is
-    the same quotient without the reference's per-point cancellation error eps |R p + t| / h_j —
-    with h_j = sqrt(eps) |x_j| that error is part of what the reference computes once |x_j| is
-    small.  Measured distance, worst of 20 poses per decade: 2e-8 / |x_j|; bound = 4 x that."""
-    if variant != 2:
+    The moments evaluation forms column j as ((R_j - R) p + (t_j - t)) / h_j, which is the same
+    quotient without the reference's per-point cancellation error eps |R p + t| / h_j — with
+    h_j = sqrt(eps) |x_j| that error is part of what the reference computes once |x_j| is small.
+    Measured distance, worst of 20 poses per decade: 2e-8 / |x_j|; bound = 4 x that.  Variant 2
+    (MOPT_KERNEL_MOMENTS) therefore evaluates literally below |x_j| = 0.08 like AUTO and meets the
+    bar as it stands; only variant 3 (MOPT_KERNEL_MOMENTS_ALWAYS, a measurement switch) gets the
+    wider bound."""
+    if variant != 3:
         return REL
     x = np.abs(np.asarray(x, dtype=np.float64))
     nz = x[x > 0]
@@ -975,7 +978,7 @@ def test_randomized_configurations_against_oracle(hip_lib, oracle):
         else:
             x = rng.normal(0, 0.7, 6)
         jac_mode = int(rng.integers(0, 3))
-        variant = int(rng.integers(0, 3))
+        variant = int(rng.integers(0, 4))  # incl. MOMENTS_ALWAYS (3)
         cov_kind = int(rng.integers(0, 4))
         if cov_kind == 0:
             cov = None
@@ -1105,17 +1108,33 @@ def test_numeric_mode_meets_the_bar_at_every_step_size(hip_lib, oracle):
     rng = np.random.default_rng(5)
     src, tgt = ds.synthetic_pair(30_000, seed=42, noise=0.01)
     cost = mo.Point2PointCost(src, tgt)
+    # forward differences under a covariance are tst/covariance.cpp:45-63 and tst/powell.cpp:107-136:
+    # the same bar under a diagonal, a symmetric and a non-symmetric one, with and without a loss
+    covs = {"identity": None, "diagonal": np.diag([0.5, 2.0, 3.0]),
+            "symmetric": np.array([[2.0, 0.3, -0.1], [0.3, 0.5, 0.2], [-0.1, 0.2, 1.5]]),
+            "general": np.array([[2.0, 0.7, -0.1], [0.3, 0.5, 0.9], [-0.4, 0.2, 1.5]])}
     for scale in (1e-8, 1e-6, 1e-4, 1e-3, 1e-2, 1e-1, 1.0):
-        for _ in range(6):
+        for trial in range(6):
             x = rng.choice([-1.0, 1.0], 6) * scale * rng.uniform(0.3, 3.0, 6)
             if rng.random() < 0.3:
                 x[rng.integers(0, 6)] = 0.0  # a zero component takes the fixed step sqrt(eps)
-            want = oracle_ref(oracle, src, tgt, x, 2)
-            for variant in (mo.KERNEL_AUTO, mo.KERNEL_LITERAL):
-                cost.set_kernel_variant(variant)
+            for cname, cov in covs.items():
+                if cname != "identity" and trial >= 2:
+                    continue
+                loss = (mo.LOSS_GEMAN_MCCLURE, 100.0) if (trial % 2 and cname != "identity") else (mo.LOSS_NONE, 0.0)
+                cost.set_covariance(cov)
+                cost.set_loss(*loss)
+                want = oracle_ref(oracle, src, tgt, x, 2, cov=cov, loss_kind=loss[0], loss_param=loss[1])
+                for variant in (mo.KERNEL_AUTO, mo.KERNEL_LITERAL):
+                    cost.set_kernel_variant(variant)
+                    try:
+                        check(cost.linearize(x, mo.JAC_NUMERIC), want, tol=REL)
+                    except AssertionError as e:
+                        raise AssertionError((cname, loss, variant, scale, e.args)) from e
+                cost.set_kernel_variant(mo.KERNEL_MOMENTS)  # literal where moments would miss the bar
                 check(cost.linearize(x, mo.JAC_NUMERIC), want, tol=REL)
-            cost.set_kernel_variant(mo.KERNEL_MOMENTS)
-            check(cost.linearize(x, mo.JAC_NUMERIC), want, tol=fd_tolerance(x, 2))
+                cost.set_kernel_variant(mo.KERNEL_MOMENTS_ALWAYS)
+                check(cost.linearize(x, mo.JAC_NUMERIC), want, tol=fd_tolerance(x, 3))
     cost.close()
 
 
