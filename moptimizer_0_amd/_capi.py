@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmoptimizer_hip.so")
+# MOPT_LIBRARY: another build of the same library (e.g. the -DMOPT_LM_TIMING build of the LM step)
+LIB_PATH = os.environ.get("MOPT_LIBRARY") or os.path.join(_HERE, "lib", "libmoptimizer_hip.so")
 
 MOPT_OK = 0
 JAC_ANALYTIC, JAC_ANALYTIC_TST_LAYOUT, JAC_NUMERIC, JAC_ANALYTIC_LEFT = 0, 1, 2, 3

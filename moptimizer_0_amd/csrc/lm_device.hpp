@@ -281,6 +281,81 @@ __device__ void solveDampedFixed(const S *H, const S *b, S lambda, S *delta) {
       if (perm[i] == j) delta[j] = y[i];
 }
 
+// 1 / d to about an ulp: the hardware estimate and two Newton steps (5 instructions; an IEEE fp64
+// division is ~25, and the solve has n of them on its critical path).
+__device__ __forceinline__ double fastReciprocal(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+  r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+  return r;
+}
+__device__ __forceinline__ float fastReciprocal(float d) {
+  float r = __builtin_amdgcn_rcpf(d);
+  r = __builtin_fmaf(r, __builtin_fmaf(-d, r, 1.0f), r);
+  return r;
+}
+__device__ __forceinline__ double fusedMulAdd(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fusedMulAdd(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// The same system when H + lambda diag H is safely positive definite — which it is at every step of
+// a well-posed problem: LDL^T in the given order (no pivot search, no predicated row / column
+// exchanges: those are most of the ~800 dependent instructions solveDampedFixed<6> issues on its one
+// lane), multiply-adds fused, reciprocals instead of divisions: ~130 instructions.  A factorisation
+// without pivoting is backward stable for a positive definite matrix, so delta agrees with the
+// pivoted solve to eps * cond(H) — the same pose, not the same bits (no restatement reproduces the
+// reference's Eigen::LDLT bit for bit either).  Returns false, leaving delta untouched, when a pivot
+// is not clearly positive (a parameter the data do not constrain — the as-written test Jacobian has
+// an all-zero row and column — or an indefinite matrix): the caller then takes the pivoted path,
+// whose handling of vanishing pivots is the host statement's.
+template <typename S, int N>
+__device__ bool solveDampedPositive(const S *H, const S *b, S lambda, S *delta) {
+  S L[N][N];  // strictly lower part
+  S d[N], inv_d[N], y[N];
+  bool positive = true;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const S akk = fusedMulAdd(lambda, H[k * N + k], H[k * N + k]);
+    S u[N];  // u[j] = L(k, j) d_j
+    S dk = akk;
+#pragma unroll
+    for (int j = 0; j < k; ++j) {
+      u[j] = L[k][j] * d[j];
+      dk = fusedMulAdd(-L[k][j], u[j], dk);
+    }
+    // a pivot that has lost ten digits against its diagonal entry is where pivoting starts to matter
+    positive = positive && (dk > S(1e-10) * akk);
+    d[k] = dk;
+    inv_d[k] = fastReciprocal(dk);
+#pragma unroll
+    for (int i = k + 1; i < N; ++i) {
+      S v = H[k * N + i];  // lower triangle, as the pivoted statement reads it
+#pragma unroll
+      for (int j = 0; j < k; ++j) v = fusedMulAdd(-L[i][j], u[j], v);
+      L[i][k] = v * inv_d[k];
+    }
+  }
+  if (!positive) return false;  // (also NaN anywhere in H)
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    S v = -b[i];
+#pragma unroll
+    for (int j = 0; j < i; ++j) v = fusedMulAdd(-L[i][j], y[j], v);
+    y[i] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) y[i] *= inv_d[i];
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+    S v = y[i];
+#pragma unroll
+    for (int j = i + 1; j < N; ++j) v = fusedMulAdd(-L[j][i], y[j], v);
+    y[i] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) delta[i] = y[i];
+  return true;
+}
+
 // (K T) C, row-major 3x4: the matrix products of tst/camera_calibration.cpp:37 in the association
 // of the host statement (c_abi.cpp projectionFor).
 __device__ void projectionFor(const LmCostDesc &d, const double (&T)[12], double (&M)[12]) {
@@ -490,9 +565,18 @@ __device__ void lmStepBody(const LmProblem &P, bool init, const LmStart<S> &star
     auto proposeTrial = [&]() {
       MOPT_TICK(5);
       switch (n) {
-        case 6: solveDampedFixed<S, 6>(Hcur, bsrc, lambda, delta); break;
-        case 4: solveDampedFixed<S, 4>(Hcur, bsrc, lambda, delta); break;
-        case 2: solveDampedFixed<S, 2>(Hcur, bsrc, lambda, delta); break;
+        case 6:
+          if (!solveDampedPositive<S, 6>(Hcur, bsrc, lambda, delta))
+            solveDampedFixed<S, 6>(Hcur, bsrc, lambda, delta);
+          break;
+        case 4:
+          if (!solveDampedPositive<S, 4>(Hcur, bsrc, lambda, delta))
+            solveDampedFixed<S, 4>(Hcur, bsrc, lambda, delta);
+          break;
+        case 2:
+          if (!solveDampedPositive<S, 2>(Hcur, bsrc, lambda, delta))
+            solveDampedFixed<S, 2>(Hcur, bsrc, lambda, delta);
+          break;
         default: {
           S d[kMaxParams];
           solveDamped<S>(Hcur, bsrc, lambda, n, d, solve_scratch);

@@ -297,16 +297,23 @@ def test_icp_cost_with_the_search_inside_the_device_loop(hip_lib):
     # sources = targets moved by the inverse pose (+ noise), shuffled: registration must undo it
     src = (tgt - x_true[:3]) @ R + rng.normal(0, 0.002, tgt.shape)
     src = src[rng.permutation(len(src))][:30_000]
-    # iterate for iterate the host loop's answer (the poses agree to 1e-16 all the way; only the
-    # noise-level stop at the very end — rho < 0 with |delta| < sqrt eps, decided by the last bits
-    # of two differently summed costs — may come at a different iteration)
+    # iterate for iterate the host loop's answer.  The device solves the damped system without
+    # pivoting where it is positive definite (lm_device.hpp solveDampedPositive): the same step to
+    # eps * cond(H), not the same bits, so the poses agree to 1e-13 all the way and only the
+    # noise-level stop at the very end — rho < 0 with |delta| < sqrt eps, decided by the last bits of
+    # two costs that differ in them — may come at a different iteration (k = 27: the pose has been
+    # stationary for iterations by then).
     for k in (3, 12, 27):
         dev = mo.IcpCost(src, tgt, max_distance=0.6)
         ref = mo.IcpCost(src, tgt, max_distance=0.6)
         xd, rep = mo.capi.lm_minimize([dev], [mo.JAC_ANALYTIC], np.zeros(6), max_iterations=k)
         xh, sh, ih = host_lm(ref, mo.JAC_ANALYTIC, np.zeros(6), max_iter=k)
-        assert (rep["status"], rep["iterations"]) == (sh, ih), (k, rep, sh, ih)
-        assert rep["sweeps"] == 2 * k  # search + linearization, then one accepted trial, per iteration
+        if k < 27:
+            assert (rep["status"], rep["iterations"]) == (sh, ih), (k, rep, sh, ih)
+            assert rep["sweeps"] == 2 * k  # search + linearization, then one accepted trial, per iteration
+        else:
+            assert rep["status"] in (MAX_ITERATIONS, SMALL_DELTA, CONVERGED), rep
+            assert 20 <= rep["iterations"] <= k, rep
         assert np.abs(xd - xh).max() < 1e-9, (k, xd, xh)
         # the correspondences the two loops ended with are the same
         md, mr = dev.matches(), ref.matches()
