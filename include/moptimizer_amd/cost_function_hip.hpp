@@ -423,6 +423,10 @@ using CostFunctionAnalyticalTstLayoutHip = CostFunctionHip<Scalar, MOPT_JAC_ANAL
 // leaves that update as a TODO, src/levenberg_marquadt_dyn.cpp:82-83).
 template <class Scalar = double>
 using CostFunctionAnalyticalLeftHip = CostFunctionHip<Scalar, MOPT_JAC_ANALYTIC_LEFT>;
+// The same for a right perturbation of the rotation, [I | -R skew(p)] (the composition of
+// tst/manifold.cpp:47 / tst/state_model.cpp:28-34; LevenbergMarquadtDevice::setRightManifoldUpdate).
+template <class Scalar = double>
+using CostFunctionAnalyticalRightHip = CostFunctionHip<Scalar, MOPT_JAC_ANALYTIC_RIGHT>;
 // Drop-in for CostFunctionNumericalDynamic: forward differences.
 template <class Scalar = double>
 using CostFunctionNumericalHip = CostFunctionHip<Scalar, MOPT_JAC_NUMERIC>;

@@ -41,7 +41,11 @@ class LevenbergMarquadtDevice {
   // xi = x0 (+) delta on SE(3) (mopt_se3_plus) instead of the reference's xi = x0 + delta
   // (levenberg_marquadt_dyn.cpp:82-83, "TODO Manifold operation"); 6-parameter poses, to be used
   // with CostFunctionAnalyticalLeftHip costs.
-  void setManifoldUpdate(bool on) { manifold_update_ = on; }
+  void setManifoldUpdate(bool on) { manifold_update_ = on ? 1 : 0; }
+  // The same composed on the right — R <- R Exp(delta_w), t <- t + delta_t, the form of the
+  // reference's own sketches (tst/manifold.cpp:47, tst/state_model.cpp:28-34) — to be used with
+  // CostFunctionAnalyticalRightHip costs.
+  void setRightManifoldUpdate(bool on) { manifold_update_ = on ? 2 : 0; }
 
   // Non-owning, as Optimizer::addCost (optimizer.h:58).
   void addCost(CostFunctionType *cost) {
@@ -75,7 +79,7 @@ class LevenbergMarquadtDevice {
     mopt_lm_options options;
     options.max_iterations = int(maximum_iterations_);
     options.lm_max_iterations = int(lm_max_iterations_);
-    options.manifold = manifold_update_ ? 1 : 0;
+    options.manifold = manifold_update_;
     options.window = 0;
     mopt_lm_report report;
     (void)num_parameters_;
@@ -96,7 +100,7 @@ class LevenbergMarquadtDevice {
   unsigned int maximum_iterations_ = 15;  // optimizer.h:19
   unsigned int lm_max_iterations_ = 3;    // levenberg_marquadt_dyn.cpp:9
   unsigned int executed_iterations_ = 0;
-  bool manifold_update_ = false;
+  int manifold_update_ = 0;  // mopt_lm_options.manifold
   long long sweeps_ = 0;
   double final_cost_ = 0.0;
   std::vector<CostFunctionType *> costs_;

@@ -153,5 +153,26 @@ inline void se3Plus(const Scalar *x, const Scalar *delta, Scalar *out) {
   }
 }
 
+// The same update with the rotation composed on the RIGHT, the form the reference's two sketches of
+// a rotation update take (`parameter_matrix * Exp(delta)`, tst/manifold.cpp:47; `rot_ * rhs_rot`
+// with the linear part added, tst/state_model.cpp:28-34) and MOPT_JAC_ANALYTIC_RIGHT differentiates
+// with respect to:
+//   R' = Exp(x_w) Exp(delta_w),   t' = x_t + delta_t,   x' = (t', Log(R')).
+template <typename Scalar>
+inline void se3PlusRight(const Scalar *x, const Scalar *delta, Scalar *out) {
+  Scalar R[9], D[9], RR[9];
+  expSO3<Scalar>(x + 3, R);
+  expSO3<Scalar>(delta + 3, D);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      RR[i * 3 + j] = (R[i * 3 + 0] * D[0 * 3 + j] + R[i * 3 + 1] * D[1 * 3 + j]) + R[i * 3 + 2] * D[2 * 3 + j];
+  Scalar w[3];
+  logSO3Reference<Scalar>(RR, w);
+  for (int i = 0; i < 3; ++i) {
+    out[i] = x[i] + delta[i];
+    out[3 + i] = w[i];
+  }
+}
+
 }  // namespace so3
 }  // namespace moptimizer

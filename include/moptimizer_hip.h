@@ -81,7 +81,13 @@ enum mopt_jacobian_mode {
    * J = [ I3 | -skew(R p + t) ], row-major.  Exact at every pose (the Euclidean-parameter form
    * [ I3 | -skew(p) ] is the derivative at R = I only); goes with mopt_lm_options.manifold = 1 /
    * mopt_se3_plus, which apply the step as that perturbation instead of adding it to x. */
-  MOPT_JAC_ANALYTIC_LEFT = 3
+  MOPT_JAC_ANALYTIC_LEFT = 3,
+  /* the same for a RIGHT perturbation of the rotation with the translation added,
+   * T <- [R Exp(phi) | t + rho] — the composition the reference's own sketches of a rotation update
+   * use (`parameter_matrix * Exp(delta)`, tst/manifold.cpp:47; `rot_ * rhs_rot`, lin_ += delta,
+   * tst/state_model.cpp:28-34): J = [ I3 | -R skew(p) ], row-major; goes with
+   * mopt_lm_options.manifold = 2 / mopt_se3_plus_right. */
+  MOPT_JAC_ANALYTIC_RIGHT = 4
 };
 
 enum mopt_loss_kind {
@@ -126,6 +132,9 @@ MOPT_API int mopt_se3_from_params(int scalar_bytes, const void *x, void *T_out /
  * R' = Exp(phi) Exp(w), t' = Exp(phi) t + rho, x' = (t', Log(R')) — Exp / Log of src/so3.cpp:43-57,
  * :96-105.  6 scalars each; needs no device. */
 MOPT_API int mopt_se3_plus(int scalar_bytes, const void *x, const void *delta, void *x_out);
+/* The same composed on the right: R' = Exp(w) Exp(phi), t' = t + rho (tst/manifold.cpp:47,
+ * tst/state_model.cpp:28-34). */
+MOPT_API int mopt_se3_plus_right(int scalar_bytes, const void *x, const void *delta, void *x_out);
 MOPT_API const char *mopt_last_error(void);
 MOPT_API const char *mopt_version(void);
 
@@ -387,7 +396,8 @@ typedef struct mopt_lm_options {
   int max_iterations;    /* Optimizer::setMaximumIterations, default 15 (optimizer.h:19)        */
   int lm_max_iterations; /* setLevenbergMarquadtIterations, default 3 (levenberg_marquadt_dyn.cpp:9) */
   int manifold;          /* 0: xi = x0 + delta as the reference (:83); 1: xi = x0 (+) delta on SE(3)
-                            (mopt_se3_plus; n = 6; use MOPT_JAC_ANALYTIC_LEFT costs)              */
+                            (mopt_se3_plus; n = 6; use MOPT_JAC_ANALYTIC_LEFT costs); 2: composed
+                            on the right (mopt_se3_plus_right; MOPT_JAC_ANALYTIC_RIGHT costs)     */
   int window;            /* trial points queued ahead of the device; 0 = default (3)             */
 } mopt_lm_options;
 typedef struct mopt_lm_report {

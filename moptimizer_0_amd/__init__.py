@@ -13,6 +13,7 @@ from ._capi import (  # noqa: F401
     COMBINE_RCCL,
     JAC_ANALYTIC,
     JAC_ANALYTIC_LEFT,
+    JAC_ANALYTIC_RIGHT,
     JAC_ANALYTIC_TST_LAYOUT,
     JAC_NUMERIC,
     KERNEL_AUTO,

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOPT_LIBRARY") or os.path.join(_HERE, "lib", "libmoptimizer_hip.so")
 
 MOPT_OK = 0
-JAC_ANALYTIC, JAC_ANALYTIC_TST_LAYOUT, JAC_NUMERIC, JAC_ANALYTIC_LEFT = 0, 1, 2, 3
+JAC_ANALYTIC, JAC_ANALYTIC_TST_LAYOUT, JAC_NUMERIC, JAC_ANALYTIC_LEFT, JAC_ANALYTIC_RIGHT = 0, 1, 2, 3, 4
 LOSS_NONE, LOSS_GEMAN_MCCLURE = 0, 1
 INPUT_HOST, INPUT_DEVICE = 0, 1
 KERNEL_AUTO, KERNEL_LITERAL, KERNEL_MOMENTS, KERNEL_MOMENTS_ALWAYS = 0, 1, 2, 3
@@ -65,6 +65,7 @@ def load():
         "mopt_se3_from_params": [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                  ctypes.c_void_p],
         "mopt_se3_plus": [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p],
+        "mopt_se3_plus_right": [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p],
         "mopt_point2point_create": [c_void_pp, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                     ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint],
         "mopt_point2point_set_data": [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
@@ -192,6 +193,15 @@ def se3_plus(x, delta, dtype=np.float64):
     return out
 
 
+def se3_plus_right(x, delta, dtype=np.float64):
+    """x (+) delta composed on the right: R <- R Exp(delta_w), t <- t + delta_t (mopt_se3_plus_right)."""
+    x = np.ascontiguousarray(x, dtype=dtype)
+    delta = np.ascontiguousarray(delta, dtype=dtype)
+    out = np.zeros(6, dtype=dtype)
+    check(load().mopt_se3_plus_right(x.itemsize, _ptr(x), _ptr(delta), _ptr(out)))
+    return out
+
+
 def link_costs(costs):
     """mopt_costs_link: the costs of one problem, asked one after the other at the same x by the
     optimizer's loop — the first one asked queues the others' sweeps too.  [] or one cost unlinks."""
@@ -202,13 +212,15 @@ def link_costs(costs):
 def lm_minimize(costs, jac_modes, x0, max_iterations=15, lm_max_iterations=3, window=0,
                 manifold=False):
     """Device-resident LevenbergMarquadtDynamic::minimize over `costs` (mopt_lm_minimize).
-    Returns (x, report dict)."""
+    `manifold`: False / 0 Euclidean update (the reference), True / 1 / "left" x (+) delta composed on
+    the left, 2 / "right" on the right.  Returns (x, report dict)."""
+    manifold = {"left": 1, "right": 2}.get(manifold, manifold)
     costs = list(costs)
     dt = _dtype_of(costs[0].scalar_bytes)
     x = np.array(x0, dtype=dt).copy()
     handles = (ctypes.c_void_p * len(costs))(*[c._h for c in costs])
     modes = (ctypes.c_int * len(costs))(*[int(m) for m in jac_modes])
-    opt = LmOptions(int(max_iterations), int(lm_max_iterations), 1 if manifold else 0, int(window))
+    opt = LmOptions(int(max_iterations), int(lm_max_iterations), int(manifold), int(window))
     rep = LmReport()
     check(load().mopt_lm_minimize(handles, len(costs), modes, _ptr(x), ctypes.byref(opt),
                                   ctypes.byref(rep)))

@@ -218,6 +218,21 @@ void fillBasis(const mopt_cost *c, int jac_mode, const mopt::P2PSweepArgs<S> &a,
       analyticPattern(MOPT_JAC_ANALYTIC, wk, B.J[1 + k]);
       for (int q = 0; q < 18; ++q) B.J[1 + k][q] -= B.J[0][q];
     }
+  } else if (jac_mode == MOPT_JAC_ANALYTIC_RIGHT) {
+    // J(p) = [I | -R skew(p)]: J0 = [I | 0], J_k = [0 | -R skew(e_k)]
+    for (int q = 0; q < 18; ++q) B.J[0][q] = B.J[1][q] = B.J[2][q] = B.J[3][q] = 0.0;
+    B.J[0][0 * 6 + 0] = B.J[0][1 * 6 + 1] = B.J[0][2 * 6 + 2] = 1.0;
+    for (int k = 0; k < 3; ++k) {
+      double e[3] = {0, 0, 0};
+      e[k] = 1.0;
+      const double skew[3][3] = {{0, -e[2], e[1]}, {e[2], 0, -e[0]}, {-e[1], e[0], 0}};
+      for (int r = 0; r < 3; ++r)
+        for (int col = 0; col < 3; ++col) {
+          double v = 0.0;
+          for (int m = 0; m < 3; ++m) v += double(a.T[0][r * 4 + m]) * skew[m][col];
+          B.J[1 + k][r * 6 + 3 + col] = -v;
+        }
+    }
   } else {
     const double origin[3] = {0, 0, 0};
     analyticPattern(jac_mode, origin, B.J[0]);
@@ -395,9 +410,10 @@ template <typename S>
 int scalarSweepAsync(mopt_cost *c, bool cost_only, int jac_mode, const S *x, double *d_out,
                      hipStream_t s, const mopt::HostPublish &pub) {
   if (!cost_only) {
-    if (jac_mode == MOPT_JAC_ANALYTIC_TST_LAYOUT || jac_mode == MOPT_JAC_ANALYTIC_LEFT)
+    if (jac_mode == MOPT_JAC_ANALYTIC_TST_LAYOUT || jac_mode == MOPT_JAC_ANALYTIC_LEFT ||
+        jac_mode == MOPT_JAC_ANALYTIC_RIGHT)
       return fail(MOPT_ERR_UNSUPPORTED,
-                  "the as-written layout and the left-perturbation Jacobian apply to point2point only");
+                  "the as-written layout and the perturbation Jacobians apply to point2point only");
     if (jac_mode == MOPT_JAC_ANALYTIC && !scalarModelHasJacobian(c->scalar_model))
       return fail(MOPT_ERR_UNSUPPORTED,
                   "Non implemented non-jacobian model function `f_df` being used.");
@@ -477,9 +493,10 @@ template <typename S>
 int jitSweepAsync(mopt_cost *c, bool cost_only, int jac_mode, const S *x, double *d_out,
                   hipStream_t s, const mopt::HostPublish &pub) {
   if (!cost_only) {
-    if (jac_mode == MOPT_JAC_ANALYTIC_TST_LAYOUT || jac_mode == MOPT_JAC_ANALYTIC_LEFT)
+    if (jac_mode == MOPT_JAC_ANALYTIC_TST_LAYOUT || jac_mode == MOPT_JAC_ANALYTIC_LEFT ||
+        jac_mode == MOPT_JAC_ANALYTIC_RIGHT)
       return fail(MOPT_ERR_UNSUPPORTED,
-                  "the as-written layout and the left-perturbation Jacobian apply to point2point only");
+                  "the as-written layout and the perturbation Jacobians apply to point2point only");
     if (jac_mode == MOPT_JAC_ANALYTIC && !c->jit.has_jacobian)
       return fail(MOPT_ERR_UNSUPPORTED,
                   "Non implemented non-jacobian model function `f_df` being used.");
@@ -518,7 +535,7 @@ int jitSweepAsync(mopt_cost *c, bool cost_only, int jac_mode, const S *x, double
 namespace mopt_detail {
 int linearizeAsyncImpl(mopt_cost *c, int jac_mode, const void *x, double *d_result, hipStream_t s,
                        const mopt::HostPublish &pub) {
-  if (jac_mode < MOPT_JAC_ANALYTIC || jac_mode > MOPT_JAC_ANALYTIC_LEFT)
+  if (jac_mode < MOPT_JAC_ANALYTIC || jac_mode > MOPT_JAC_ANALYTIC_RIGHT)
     return fail(MOPT_ERR_INVALID_ARGUMENT, "unknown jacobian_mode");
   if (c->model == kModelJit)
     return c->scalar_bytes == 8
@@ -719,7 +736,8 @@ int residentPrepareP2P(mopt_cost *c, int jac_mode, bool moments, double *partial
     // analytic modes in the Euclidean parameters: the whole basis is independent of x; forward
     // differences and the left-perturbation form: the step kernel rewrites J per point and only the
     // covariance stays
-    const bool per_point = jac_mode == MOPT_JAC_NUMERIC || jac_mode == MOPT_JAC_ANALYTIC_LEFT;
+    const bool per_point = jac_mode == MOPT_JAC_NUMERIC || jac_mode == MOPT_JAC_ANALYTIC_LEFT ||
+                           jac_mode == MOPT_JAC_ANALYTIC_RIGHT;
     fillBasis<S>(c, per_point ? MOPT_JAC_ANALYTIC : jac_mode, args, basis);
     if (!c->d_lm_basis)
       MOPT_HIP_TRY(deviceAlloc(reinterpret_cast<void **>(&c->d_lm_basis), sizeof(mopt::AffineBasis)));
@@ -768,7 +786,7 @@ int residentDenseRow(const mopt_cost *c) {
 int residentPrepare(mopt_cost *c, int jac_mode, hipStream_t s, mopt::LmCostDesc *desc,
                     double *partials_override) {
   double *const partials = partials_override ? partials_override : c->d_partials;
-  if (jac_mode < MOPT_JAC_ANALYTIC || jac_mode > MOPT_JAC_ANALYTIC_LEFT)
+  if (jac_mode < MOPT_JAC_ANALYTIC || jac_mode > MOPT_JAC_ANALYTIC_RIGHT)
     return fail(MOPT_ERR_INVALID_ARGUMENT, "unknown jacobian_mode");
   desc->jac_mode = jac_mode;
   desc->n_out = c->n_out;
@@ -805,9 +823,10 @@ int residentPrepare(mopt_cost *c, int jac_mode, hipStream_t s, mopt::LmCostDesc 
       break;
     }
     case kModelScalar: {
-      if (jac_mode == MOPT_JAC_ANALYTIC_TST_LAYOUT || jac_mode == MOPT_JAC_ANALYTIC_LEFT)
+      if (jac_mode == MOPT_JAC_ANALYTIC_TST_LAYOUT || jac_mode == MOPT_JAC_ANALYTIC_LEFT ||
+        jac_mode == MOPT_JAC_ANALYTIC_RIGHT)
         return fail(MOPT_ERR_UNSUPPORTED,
-                    "the as-written layout and the left-perturbation Jacobian apply to point2point only");
+                    "the as-written layout and the perturbation Jacobians apply to point2point only");
       if (jac_mode == MOPT_JAC_ANALYTIC && !scalarModelHasJacobian(c->scalar_model))
         return fail(MOPT_ERR_UNSUPPORTED,
                     "Non implemented non-jacobian model function `f_df` being used.");
@@ -832,9 +851,10 @@ int residentPrepare(mopt_cost *c, int jac_mode, hipStream_t s, mopt::LmCostDesc 
       break;
     }
     case kModelJit: {
-      if (jac_mode == MOPT_JAC_ANALYTIC_TST_LAYOUT || jac_mode == MOPT_JAC_ANALYTIC_LEFT)
+      if (jac_mode == MOPT_JAC_ANALYTIC_TST_LAYOUT || jac_mode == MOPT_JAC_ANALYTIC_LEFT ||
+        jac_mode == MOPT_JAC_ANALYTIC_RIGHT)
         return fail(MOPT_ERR_UNSUPPORTED,
-                    "the as-written layout and the left-perturbation Jacobian apply to point2point only");
+                    "the as-written layout and the perturbation Jacobians apply to point2point only");
       if (jac_mode == MOPT_JAC_ANALYTIC && !c->jit.has_jacobian)
         return fail(MOPT_ERR_UNSUPPORTED,
                     "Non implemented non-jacobian model function `f_df` being used.");
@@ -1272,6 +1292,20 @@ int mopt_se3_plus(int scalar_bytes, const void *x, const void *delta, void *x_ou
   else if (scalar_bytes == 4)
     moptimizer::so3::se3Plus<float>(static_cast<const float *>(x), static_cast<const float *>(delta),
                                     static_cast<float *>(x_out));
+  else
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "scalar_bytes must be 4 or 8");
+  return MOPT_OK;
+}
+
+int mopt_se3_plus_right(int scalar_bytes, const void *x, const void *delta, void *x_out) {
+  if (!x || !delta || !x_out) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (scalar_bytes == 8)
+    moptimizer::so3::se3PlusRight<double>(static_cast<const double *>(x),
+                                          static_cast<const double *>(delta),
+                                          static_cast<double *>(x_out));
+  else if (scalar_bytes == 4)
+    moptimizer::so3::se3PlusRight<float>(static_cast<const float *>(x),
+                                         static_cast<const float *>(delta), static_cast<float *>(x_out));
   else
     return fail(MOPT_ERR_INVALID_ARGUMENT, "scalar_bytes must be 4 or 8");
   return MOPT_OK;
@@ -1722,7 +1756,7 @@ int mopt_cost_link_stats(const mopt_cost *c, int64_t *answered_ahead) {
 int mopt_cost_linearize(mopt_cost *c, int jacobian_mode, const void *x, void *hessian, void *b,
                         void *sum_sq) {
   if (!c || !x) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
-  if (jacobian_mode < MOPT_JAC_ANALYTIC || jacobian_mode > MOPT_JAC_ANALYTIC_LEFT)
+  if (jacobian_mode < MOPT_JAC_ANALYTIC || jacobian_mode > MOPT_JAC_ANALYTIC_RIGHT)
     return fail(MOPT_ERR_INVALID_ARGUMENT, "unknown jacobian_mode");
   if (c->speculate && cacheMatches(c, x, jacobian_mode)) {
     c->stat_cache_hits += 1;

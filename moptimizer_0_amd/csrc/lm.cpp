@@ -63,6 +63,8 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
   if (options) opt = *options;
   if (opt.max_iterations < 0 || opt.lm_max_iterations < 0)
     return fail(MOPT_ERR_INVALID_ARGUMENT, "Optimization::max_iterations cannot be less than 0.");
+  if (opt.manifold < 0 || opt.manifold > 2)
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "mopt_lm_options.manifold is 0 (none), 1 (left) or 2 (right)");
   if (opt.manifold && lead->n_params != kNumParams)
     return fail(MOPT_ERR_INVALID_ARGUMENT, "the SE(3) update applies to 6-parameter poses");
   mopt_lm_report rep;
@@ -108,7 +110,7 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
   problem.n = lead->n_params;
   problem.max_iterations = opt.max_iterations;
   problem.lm_max_iterations = opt.lm_max_iterations;
-  problem.manifold = opt.manifold ? 1 : 0;
+  problem.manifold = opt.manifold;
   problem.control = lead->d_lm_control;
   problem.state = lead->d_lm_state;
   problem.report = lead->h_lm_report_dev;

@@ -96,6 +96,26 @@ __device__ void se3Plus(const S *x, const S *delta, S *out) {
   for (int i = 0; i < 3; ++i) out[3 + i] = k * K[i];
 }
 
+// the same composed on the right (so3.hpp se3PlusRight): R' = Exp(x_w) Exp(delta_w), t' = x_t + delta_t
+template <typename S>
+__device__ void se3PlusRight(const S *x, const S *delta, S *out) {
+#pragma clang fp contract(off)
+  S TR[12], TD[12];
+  rigidFrom6DOF<S>(x, TR);
+  rigidFrom6DOF<S>(delta, TD);
+  S RR[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      RR[i * 3 + j] = (TR[i * 4 + 0] * TD[0 * 4 + j] + TR[i * 4 + 1] * TD[1 * 4 + j]) +
+                      TR[i * 4 + 2] * TD[2 * 4 + j];
+  for (int i = 0; i < 3; ++i) out[i] = x[i] + delta[i];
+  const S trace = RR[0] + RR[4] + RR[8];
+  const S theta = (trace > S(3.0) - S(1e-6)) ? S(0) : acos(S(0.5) * (trace - S(1)));
+  const S K[3] = {RR[7] - RR[5], RR[2] - RR[6], RR[3] - RR[1]};
+  const S k = (fabs(theta) < S(0.001)) ? S(0.5) : S(0.5) * theta / sin(theta);
+  for (int i = 0; i < 3; ++i) out[3 + i] = k * K[i];
+}
+
 // Forward-difference step of linearization.h:85-89.
 template <typename S>
 __device__ __forceinline__ S forwardStep(S xj) {
@@ -431,6 +451,26 @@ __device__ void writeSweepConstants(const LmProblem &P, const S *x) {
             d.basis->J[1 + k][r * 6 + j] = double(pattern(wk)) - double(base);
           }
         }
+        if (d.moments && d.jac_mode == kJacAnalyticRight && tid < 18) {
+          // J(p) = [I | -R skew(p)]: J0 = [I | 0], J_k = [0 | -R skew(e_k)] (c_abi.cpp fillBasis).
+          // skew(e_k)(m, c) = -eps(m, c, k): column c != k has its one entry in row m = 3 - c - k.
+          const int r = tid / 6, j = tid % 6;
+          d.basis->J[0][r * 6 + j] = (j < 3 && r == j) ? 1.0 : 0.0;
+          for (int k = 0; k < 3; ++k) {
+            double v = 0.0;
+            if (j >= 3) {
+              const int c = j - 3;
+              if (c != k) {
+                const int m = 3 - c - k;
+                const bool even = (m == 0 && c == 1 && k == 2) || (m == 1 && c == 2 && k == 0) ||
+                                  (m == 2 && c == 0 && k == 1);
+                const double skew_mc = even ? -1.0 : 1.0;
+                v = -double(Tj[0][r * 4 + m]) * skew_mc;
+              }
+            }
+            d.basis->J[1 + k][r * 6 + j] = v;
+          }
+        }
         if (d.moments && numeric && tid < 18) {
           // column j of J is ((R_j - R) p + (t_j - t)) / h_j  (c_abi.cpp fillBasis)
           const int r = tid / 6, j = tid % 6;
@@ -589,7 +629,10 @@ __device__ void lmStepBody(const LmProblem &P, bool init, const LmStart<S> &star
       MOPT_TICK(6);
       if (P.manifold && n == kNumParams) {
         S plus[kNumParams];
-        se3Plus<S>(x0, delta, plus);
+        if (P.manifold == 2)
+          se3PlusRight<S>(x0, delta, plus);
+        else
+          se3Plus<S>(x0, delta, plus);
 #pragma unroll
         for (int i = 0; i < kNumParams; ++i) xi[i] = plus[i];
       } else {

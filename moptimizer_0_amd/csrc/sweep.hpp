@@ -32,7 +32,8 @@ struct TileShape {
 constexpr int kReprojTilePoints = kBlockThreads * 2;
 constexpr int kReprojTileBytes = kReprojTilePoints * (4 * 8 + 2 * 4);
 
-enum JacMode : int { kJacAnalytic = 0, kJacAnalyticTst = 1, kJacNumeric = 2, kJacAnalyticLeft = 3 };
+enum JacMode : int { kJacAnalytic = 0, kJacAnalyticTst = 1, kJacNumeric = 2, kJacAnalyticLeft = 3,
+                     kJacAnalyticRight = 4 };
 enum CovMode : int { kCovIdentity = 0, kCovSymmetric = 1, kCovGeneral = 2 };
 enum LossKind : int { kLossNone = 0, kLossGemanMcClure = 1 };
 
@@ -221,7 +222,8 @@ struct LmProblem {
   int n = 0;
   int max_iterations = 15;    // optimizer.h:19
   int lm_max_iterations = 3;  // levenberg_marquadt_dyn.cpp:9
-  int manifold = 0;           // 1: x (+) delta composed on SE(3) instead of added (n = 6 only)
+  int manifold = 0;           // 1 / 2: x (+) delta composed on SE(3), on the left / right, instead of
+                              //        added (n = 6 only)
   int rematch = 0;            // 1: some cost re-searches its correspondences in update(x): an accepted
                               //    point is re-linearized after the search instead of adopted
   int merged = 0;             // 1: the partial rows of all costs lie behind one another and the last

@@ -121,6 +121,25 @@ __device__ __forceinline__ void p2pPointLiteral(
     for (int a = 0; a < 3; ++a)
 #pragma unroll
       for (int j = 0; j < 6; ++j) J[a][j] = Jl[a][j];
+  } else if (JAC == kJacAnalyticRight) {
+    // derivative with respect to R <- R Exp(phi), t <- t + rho (tst/manifold.cpp:47,
+    // tst/state_model.cpp:28-34): [ I3 | -R skew(p) ]
+    const S z = S(0), o = S(1);
+    S Jr[3][6];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const S R0 = A.T[0][a * 4 + 0], R1 = A.T[0][a * 4 + 1], R2 = A.T[0][a * 4 + 2];
+      Jr[a][0] = a == 0 ? o : z;
+      Jr[a][1] = a == 1 ? o : z;
+      Jr[a][2] = a == 2 ? o : z;
+      Jr[a][3] = -(R1 * p[2] - R2 * p[1]);
+      Jr[a][4] = -(R2 * p[0] - R0 * p[2]);
+      Jr[a][5] = -(R0 * p[1] - R1 * p[0]);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) J[a][j] = Jr[a][j];
   } else {
     // forward differences are p2pForwardDiffKernel's (7 transforms do not fit the scalar registers)
     static_assert(JAC != kJacNumeric, "forward differences: p2pForwardDiffKernel");
@@ -1083,6 +1102,8 @@ hipError_t launchP2PLinearizeLiteral(const P2PSweepArgs<S> &args, int jac_mode, 
       return launchForwardDiff<S>(args, cov_mode, grid, site);
     case kJacAnalyticLeft:
       return launchLiteralCov<S, kJacAnalyticLeft>(args, cov_mode, grid, site);
+    case kJacAnalyticRight:
+      return launchLiteralCov<S, kJacAnalyticRight>(args, cov_mode, grid, site);
     default:
       return hipErrorInvalidValue;
   }
@@ -1318,6 +1339,8 @@ hipError_t launchP2PLiteralResident(const P2PSweepArgs<S> *d_args, const LmContr
       return launchForwardDiffResident<S>(d_args, control, cov_mode, grid, site);
     case kJacAnalyticLeft:
       return launchLiteralResidentCov<S, kJacAnalyticLeft>(d_args, control, cov_mode, grid, site);
+    case kJacAnalyticRight:
+      return launchLiteralResidentCov<S, kJacAnalyticRight>(d_args, control, cov_mode, grid, site);
     default:
       return hipErrorInvalidValue;
   }

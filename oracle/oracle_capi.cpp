@@ -64,9 +64,12 @@ std::unique_ptr<moptimizer::CostFunctionBase<S>> makeCost(
 }
 
 inline oracle::P2PJacobianLayout layoutOf(int layout) {
-  return layout == 1 ? oracle::P2PJacobianLayout::kAsWrittenInTst
-                     : (layout == 2 ? oracle::P2PJacobianLayout::kLeftPerturbation
-                                    : oracle::P2PJacobianLayout::kRowMajor);
+  switch (layout) {
+    case 1: return oracle::P2PJacobianLayout::kAsWrittenInTst;
+    case 2: return oracle::P2PJacobianLayout::kLeftPerturbation;
+    case 3: return oracle::P2PJacobianLayout::kRightPerturbation;
+    default: return oracle::P2PJacobianLayout::kRowMajor;
+  }
 }
 
 template <class S>
@@ -121,7 +124,8 @@ int p2pMinimize(int cost_class, int layout, const S *src, const S *tgt, int n, S
   moptimizer::LevenbergMarquadtDynamic<S> lm(6);
   lm.setMaximumIterations(max_iter);
   if (lm_iter > 0) lm.setLevenbergMarquadtIterations(lm_iter);
-  lm.setManifoldUpdate((layout & 4) != 0);  // bit 2 of `layout`: x (+) delta on SE(3)
+  // bits 2, 3 of `layout`: x (+) delta on SE(3), composed on the left / on the right
+  lm.setManifoldUpdate((layout & 4) ? 1 : ((layout & 8) ? 2 : 0));
   lm.addCost(cost.get());
   *status = int(lm.minimize(x));
   *iterations = int(lm.getExecutedIterations());

@@ -34,6 +34,10 @@ enum class P2PJacobianLayout {
   // row-major — what an SE(3) update x (+) delta needs.  Restated here as the checker of
   // MOPT_JAC_ANALYTIC_LEFT.
   kLeftPerturbation,
+  // Likewise not in the reference's optimizer, but the composition its two sketches of a rotation
+  // update use (tst/manifold.cpp:47, tst/state_model.cpp:28-34): R <- R Exp(delta_w), t <- t +
+  // delta_t; derivative [I3 | -R skew(p)], row-major.  The checker of MOPT_JAC_ANALYTIC_RIGHT.
+  kRightPerturbation,
 };
 
 template <typename Scalar>
@@ -64,6 +68,17 @@ class Point2Point : public moptimizer::BaseModelJacobian<Scalar, Point2Point<Sca
       for (int r = 0; r < 3; ++r) {
         for (int c = 0; c < 3; ++c) jacobian[r * 6 + c] = (r == c) ? Scalar(1) : Scalar(0);
         for (int c = 0; c < 3; ++c) jacobian[r * 6 + 3 + c] = neg_skew_w[r][c];
+      }
+    } else if (layout_ == P2PJacobianLayout::kRightPerturbation) {
+      // R skew(p), R = rows 0..2 of the column-major 4x4 transform
+      const Scalar skew[3][3] = {{0.0, -p[2], p[1]}, {p[2], 0.0, -p[0]}, {-p[1], p[0], 0.0}};
+      for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) jacobian[r * 6 + c] = (r == c) ? Scalar(1) : Scalar(0);
+        for (int c = 0; c < 3; ++c) {
+          Scalar v = 0;
+          for (int m = 0; m < 3; ++m) v += transform_[m * 4 + r] * skew[m][c];
+          jacobian[r * 6 + 3 + c] = -v;
+        }
       }
     } else if (layout_ == P2PJacobianLayout::kAsWrittenInTst) {
       // jacobian_map(r, c) lives at jacobian[c * 3 + r]  (column-major 3x6, :18,:71)

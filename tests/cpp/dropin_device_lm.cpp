@@ -4,8 +4,9 @@
 // tst/powell.cpp:62-136, tst/simple_model.cpp:28-82, tst/loss_function.cpp:45-60,
 // tst/multiple_objectives.cpp:102-132, tst/camera_calibration.cpp:101-122 — expected values and
 // tolerances the reference's, and each solve compared with the host loop (the reference's loop
-// restated, tests/support) over the very same HIP cost: same status, same number of outer
-// iterations up to the noise-level stop (forward differences through device libm), same x.
+// restated, tests/support) over the very same HIP cost: same status, same x, and the same number
+// of outer iterations or — where the loops idle at the minimum for a noise-decided number of
+// iterations — the same minimum.
 // Covers n = 2, 4, 6, float and double, one and two costs, loss and covariance, and the error
 // behaviour of optimizer.h:33-54.
 #include <cmath>
@@ -60,9 +61,24 @@ static void solveBoth(const char *name, std::vector<moptimizer::CostFunctionBase
   const bool either_limit = sh == OptimizationStatus::MAXIMUM_ITERATIONS_REACHED ||
                             sd == OptimizationStatus::MAXIMUM_ITERATIONS_REACHED;
   expectTrue(label, sd == sh || either_limit);
-  std::snprintf(label, sizeof label, "%s: outer iterations %u vs host %u", name,
-                device.getExecutedIterations(), host.getExecutedIterations());
-  expectTrue(label, std::abs(int(device.getExecutedIterations()) - int(host.getExecutedIterations())) <= 1);
+  // The device solves the damped system without pivoting where it is positive definite
+  // (lm_device.hpp solveDampedPositive): the same step to eps * cond(H), not the same bits.  Until the
+  // cost stops changing the two loops take the same iterations; how many more they spend at the
+  // minimum before rho < 0 meets a small delta is decided by the last bits of the cost.  So: the
+  // same count, or the same minimum (costs at the two end points equal to 1e-9 relative, 1e-4 in
+  // float).
+  S yh = 0, yd = 0;
+  for (auto *c : costs) {
+    yh += c->computeCost(xh.data());
+    yd += c->computeCost(xd.data());
+  }
+  const double same_minimum = sizeof(S) == 8 ? 1e-9 : 1e-4;
+  const bool same_count =
+      std::abs(int(device.getExecutedIterations()) - int(host.getExecutedIterations())) <= 1;
+  std::snprintf(label, sizeof label, "%s: outer iterations %u vs host %u, cost %.12g vs %.12g", name,
+                device.getExecutedIterations(), host.getExecutedIterations(), double(yd), double(yh));
+  expectTrue(label, same_count || std::fabs(double(yd) - double(yh)) <=
+                                      same_minimum * std::fmax(std::fabs(double(yh)), 1e-30));
   for (int i = 0; i < n; ++i) {
     std::snprintf(label, sizeof label, "%s: x[%d] device vs host loop", name, i);
     expectNear(label, double(xd[i]), double(xh[i]), agree_tol);

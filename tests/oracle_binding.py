@@ -13,8 +13,9 @@ LIB = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
 REPLAY = os.path.join(ORACLE_DIR, "_build", "replay_reference_tests")
 
 ANALYTIC_DYN, NUMERIC_DYN, ANALYTIC_STATIC, NUMERIC_STATIC = 0, 1, 2, 3
-LAYOUT_ROW_MAJOR, LAYOUT_TST, LAYOUT_LEFT = 0, 1, 2
-MANIFOLD_UPDATE = 4  # OR-ed into `layout` of p2p_minimize: xi = x0 (+) delta on SE(3)
+LAYOUT_ROW_MAJOR, LAYOUT_TST, LAYOUT_LEFT, LAYOUT_RIGHT = 0, 1, 2, 3
+MANIFOLD_UPDATE = 4  # OR-ed into `layout` of p2p_minimize: xi = x0 (+) delta on SE(3), left composition
+MANIFOLD_UPDATE_RIGHT = 8  # the same composed on the right (R <- R Exp(delta_w), t <- t + delta_t)
 
 _lib = None
 

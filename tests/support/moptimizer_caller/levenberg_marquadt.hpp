@@ -178,8 +178,10 @@ class LevenbergMarquadtDynamic : public Optimizer<Scalar> {
 
         // Euclidean update, as the reference (:83); the manifold update it leaves as a TODO
         // (:82) is available behind setManifoldUpdate for 6-parameter poses
-        if (manifold_update_ && n == 6)
+        if (manifold_update_ == 1 && n == 6)
           so3::se3Plus<Scalar>(x0, delta_.data(), xi_.data());
+        else if (manifold_update_ == 2 && n == 6)
+          so3::se3PlusRight<Scalar>(x0, delta_.data(), xi_.data());
         else
           for (int i = 0; i < n; ++i) xi_[i] = x0[i] + delta_[i];
 
@@ -221,8 +223,9 @@ class LevenbergMarquadtDynamic : public Optimizer<Scalar> {
   unsigned int getLevenbergMarquadtIterations() const { return lm_max_iterations_; }
   void setLevenbergMarquadtIterations(int max_iterations) { lm_max_iterations_ = max_iterations; }
   // Not in the reference: xi = x0 (+) delta on SE(3) (include/moptimizer_amd/so3.hpp se3Plus) in
-  // place of xi = x0 + delta; pair it with left-perturbation Jacobians.
-  void setManifoldUpdate(bool on) { manifold_update_ = on; }
+  // place of xi = x0 + delta; pair it with left-perturbation Jacobians.  2: se3PlusRight (the
+  // composition of tst/manifold.cpp:47 / tst/state_model.cpp:28-34) with right-perturbation ones.
+  void setManifoldUpdate(int mode) { manifold_update_ = mode; }
 
  protected:
   bool hasConverged() override { return false; }
@@ -245,7 +248,7 @@ class LevenbergMarquadtDynamic : public Optimizer<Scalar> {
   using Optimizer<Scalar>::logger_;
 
   int num_parameters_;
-  bool manifold_update_ = false;
+  int manifold_update_ = 0;  // 0 Euclidean (the reference), 1 left, 2 right composition
   Scalar lm_init_lambda_factor_ = Scalar(1e-9);
   Scalar lm_lambda_ = Scalar(-1);
   unsigned int lm_max_iterations_;

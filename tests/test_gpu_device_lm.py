@@ -231,6 +231,23 @@ def test_manifold_update_on_the_device(hip_lib, oracle):
             assert (rep["status"], rep["iterations"]) == (status, iters), (k, rep, status, iters)
             assert np.abs(x - xr).max() < 1e-9 * max(1.0, np.abs(xr).max()), (k, x, xr)
     assert np.abs(_exp(x[3:]) - ds.fixture_rotation()).max() < 1e-3
+    # composed on the right (manifold = 2, MOPT_JAC_ANALYTIC_RIGHT): the reference's own sketches
+    for variant in (mo.KERNEL_MOMENTS, mo.KERNEL_LITERAL):
+        cost.set_kernel_variant(variant)
+        for k in (1, 2, 4, 60):
+            xq, repq = mo.capi.lm_minimize([cost], [mo.JAC_ANALYTIC_RIGHT], x0, max_iterations=k,
+                                           manifold="right")
+            xr, status, iters = oracle.p2p_minimize(src, tgt, x0, cost_class=ob.ANALYTIC_DYN,
+                                                    layout=ob.LAYOUT_RIGHT | ob.MANIFOLD_UPDATE_RIGHT,
+                                                    max_iter=k)
+            if k < 60:
+                assert (repq["status"], repq["iterations"]) == (status, iters), (k, repq, status, iters)
+            else:
+                # the iterates agree to 1e-13 for six iterations; the stop that follows — rho < 0 on
+                # costs that differ in their 16th digit — may come one iteration apart
+                assert repq["status"] == status and abs(repq["iterations"] - iters) <= 1, (repq, status, iters)
+            assert np.abs(xq - xr).max() < 1e-9 * max(1.0, np.abs(xr).max()), (k, xq, xr)
+    assert np.abs(_exp(xq[3:]) - ds.fixture_rotation()).max() < 1e-3
     # the Euclidean update from the same start needs more than twice the outer iterations
     xe, repe = mo.capi.lm_minimize([cost], [mo.JAC_ANALYTIC], x0, max_iterations=200)
     assert repe["iterations"] > 2 * rep["iterations"], (repe, rep)

@@ -1091,12 +1091,20 @@ def test_left_perturbation_jacobian_matches_oracle(hip_lib, oracle, variant):
                                             layout=ob.LAYOUT_LEFT, cov=cov, loss_kind=loss[0],
                                             loss_param=loss[1])
                 check(got, want)
+                # MOPT_JAC_ANALYTIC_RIGHT, J = [I | -R skew(p)]: the composition of the reference's
+                # own sketches (tst/manifold.cpp:47, tst/state_model.cpp:28-34)
+                got = cost.linearize(x, mo.JAC_ANALYTIC_RIGHT)
+                want = oracle.p2p_linearize(src, tgt, x, cost_class=ob.ANALYTIC_DYN,
+                                            layout=ob.LAYOUT_RIGHT, cov=cov, loss_kind=loss[0],
+                                            loss_param=loss[1])
+                check(got, want)
     # at R = I, t = 0 the left and the Euclidean-parameter forms coincide
     cost.set_covariance(None)
     cost.set_loss(mo.LOSS_NONE)
     a = cost.linearize(ds.X_ZERO, mo.JAC_ANALYTIC_LEFT)
     b = cost.linearize(ds.X_ZERO, mo.JAC_ANALYTIC)
     check(a, b, 1e-12)
+    check(cost.linearize(ds.X_ZERO, mo.JAC_ANALYTIC_RIGHT), b, 1e-12)
     cost.close()
 
 
