@@ -503,7 +503,7 @@ int jitSweepAsync(mopt_cost *c, bool cost_only, int jac_mode, const S *x, double
   }
   const int mode = cost_only ? 0 : (jac_mode == MOPT_JAC_NUMERIC ? 2 : 1);
   const bool cov_symmetric = !c->jit.wide && c->cov_mode != mopt::kCovGeneral;
-  const mopt::JitVariant *variant = mopt::jitVariant(c->jit, mode, cov_symmetric);
+  const mopt::JitVariant *variant = mopt::jitVariant(c->jit, mode, c->cov_mode);
   if (!variant) return fail(MOPT_ERR_INVALID_ARGUMENT, mopt::jitLastError());
   const int grid = jitGrid(c);
   const int n = c->n_params;
@@ -863,8 +863,7 @@ int residentPrepare(mopt_cost *c, int jac_mode, hipStream_t s, mopt::LmCostDesc 
                     "mopt_lm_minimize keeps its state for n <= 8: drive a wide model (n > 8 or m > 4) "
                     "through the blocking calls");
       // compile (first use) before anything is queued: a source error must surface here
-      if (!mopt::jitVariant(c->jit, jac_mode == MOPT_JAC_NUMERIC ? 2 : 1,
-                            c->cov_mode != mopt::kCovGeneral))
+      if (!mopt::jitVariant(c->jit, jac_mode == MOPT_JAC_NUMERIC ? 2 : 1, c->cov_mode))
         return fail(MOPT_ERR_INVALID_ARGUMENT, mopt::jitLastError());
       desc->model = mopt::kLmJit;
       desc->x_offset = c->scalar_bytes == 8 ? int(offsetof(mopt::JitArgs<double>, x))
@@ -1029,9 +1028,8 @@ int residentSweep(mopt_cost *c, int jac_mode, mopt::LmControl *control, hipStrea
       return MOPT_OK;
     }
     case kModelJit: {
-      const bool cov_symmetric = c->cov_mode != mopt::kCovGeneral;
       const mopt::JitVariant *variant =
-          mopt::jitVariant(c->jit, jac_mode == MOPT_JAC_NUMERIC ? 2 : 1, cov_symmetric);
+          mopt::jitVariant(c->jit, jac_mode == MOPT_JAC_NUMERIC ? 2 : 1, c->cov_mode);
       if (!variant) return fail(MOPT_ERR_INVALID_ARGUMENT, mopt::jitLastError());
       const int grid = residentGrid(c);
       const int nacc = residentDenseRow(c);

@@ -25,7 +25,7 @@ namespace mopt {
 namespace {
 
 // Compiled at run time as  kJitPrologue + the three user functions + kJitSweep;  MOPT_S / MOPT_N /
-// MOPT_M / MOPT_D / MOPT_A / MOPT_MODE / MOPT_COVSYM arrive as -D options.
+// MOPT_M / MOPT_D / MOPT_A / MOPT_MODE / MOPT_COV / MOPT_S_BYTES arrive as -D options.
 const char *const kJitPrologue = R"JIT(
 #define kBlock 256
 typedef MOPT_S S;
@@ -34,7 +34,8 @@ typedef MOPT_S S;
 #define D MOPT_D
 #define AUX MOPT_A
 #define MODE MOPT_MODE       /* 0 cost only, 1 supplied Jacobian, 2 forward differences */
-#define COVSYM MOPT_COVSYM   /* 1: S symmetric -> H symmetric, upper triangle only */
+#define COV MOPT_COV         /* 0 identity, 1 symmetric, 2 general covariance */
+#define COVSYM (COV != 2)    /* S symmetric -> H symmetric, upper triangle only */
 #define NH (COVSYM ? N * (N + 1) / 2 : N * N)
 #define NACC (MODE == 0 ? 1 : NH + N + 1)
 
@@ -96,24 +97,31 @@ __device__ inline void block_reduce_store(double (&acc)[NACC], double *out_row) 
   }
 }
 
-__device__ inline void sweep_body(const JitArgs &A) {
-  // IBaseModel::setup (model.h:19-22): once per parameter vector, here once per workgroup and
-  // parameter vector - x itself and, for forward differences, x + h_j e_j (the reference sets
-  // up one clone of the model per perturbed vector, linearization.h:91-95).
-  __shared__ S aux[(N + 1) * (AUX > 0 ? AUX : 1)];
-  if (AUX > 0) {
-    const int variants = MODE == 2 ? N + 1 : 1;
-    if ((int)threadIdx.x < variants) {
-      S xs[N];
+// acc += a . b over M terms: in fp64 a chain of fused multiply-adds straight into the accumulator
+// (one instruction per term); in fp32 the sum is formed in fp32 as the reference's float
+// instantiation does and added to the fp64 running sum
+__device__ inline void acc_dot(double &acc, const S *a, int sa, const S *b, int sb) {
+  if (sizeof(S) == 8) {
+    double v = acc;
 #pragma unroll
-      for (int k = 0; k < N; ++k) xs[k] = A.x[k] + ((int)threadIdx.x == k + 1 ? A.h[k] : S(0));
-      user_setup(xs, aux + threadIdx.x * AUX);
-    }
-    __syncthreads();
+    for (int q = 0; q < M; ++q) v = __builtin_fma((double)a[q * sa], (double)b[q * sb], v);
+    acc = v;
+  } else {
+    S v = 0;
+#pragma unroll
+    for (int q = 0; q < M; ++q) v += a[q * sa] * b[q * sb];
+    acc += (double)v;
   }
-  double acc[NACC];
-#pragma unroll
-  for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+}
+
+struct RobustLoss { static constexpr bool value = true; };
+struct NoLoss { static constexpr bool value = false; };
+
+// `Loss`: the loss kind is a property of the whole sweep, not of the element — a branch inside the
+// element would split its basic block and let the compiler sink one element's accumulation below
+// the next element's residual evaluations (then both elements' Jacobians are live at once).
+template <typename Loss>
+__device__ inline void sweep_elements(const JitArgs &A, const S *aux, double (&acc)[NACC]) {
 #if MODE == 2
   // the quotient (r+ - r) / h_j (linearization.h:105) as a product with 1 / h_j, formed once: M * N
   // fp64 divisions per element were a quarter of the forward-difference sweep's instructions (the
@@ -122,39 +130,8 @@ __device__ inline void sweep_body(const JitArgs &A) {
 #pragma unroll
   for (int j = 0; j < N; ++j) inv_h[j] = S(1) / A.h[j];
 #endif
-  const long long step = (long long)gridDim.x * kBlock * VEC;
-  long long i = ((long long)blockIdx.x * kBlock + threadIdx.x) * VEC;
-  Pack cur[D > 0 ? D : 1], nxt[D > 0 ? D : 1];
-  if (i < A.count) {
-#pragma unroll
-    for (int p = 0; p < D; ++p) nxt[p] = *(const Pack *)(A.data + p * A.stride + i);
-  }
-  for (; i < A.count; i += step) {
-#pragma unroll
-    for (int p = 0; p < D; ++p) cur[p] = nxt[p];
-    // the next step's data are requested before this one's arithmetic starts
-    const long long ahead = i + step < A.count ? i + step : i;
-#pragma unroll
-    for (int p = 0; p < D; ++p) nxt[p] = *(const Pack *)(A.data + p * A.stride + ahead);
-    // forward differences evaluate the residual N + 1 times per element: the elements of a pack
-    // are then taken one at a time in a real loop (unrolled, the scheduler interleaves them and the
-    // register count doubles); the cheaper sweeps are unrolled
-#if MODE == 2
-#pragma unroll 1
-#else
-#pragma unroll
-#endif
-    for (int e = 0; e < VEC; ++e) {
-    // an element past the end (the padded tail of the last pack) is evaluated on the pack's first
-    // element, which is in range, and enters every sum with weight zero
-    const bool valid = i + e < A.count;
-    S d[D > 0 ? D : 1];
-#pragma unroll
-    for (int p = 0; p < D; ++p) {
-      d[p] = cur[p].v[0];
-#pragma unroll
-      for (int k = 1; k < VEC; ++k) d[p] = (valid && e == k) ? cur[p].v[k] : d[p];
-    }
+  // one element: residual, Jacobian (supplied or by forward differences), loss weight, the sums
+  auto element = [&](const S (&d)[D > 0 ? D : 1], bool valid) {
     // the per-x values stay in LDS: without this the compiler keeps all (N + 1) * AUX of them in
     // registers across the loop
     asm volatile("" ::: "memory");
@@ -185,11 +162,19 @@ __device__ inline void sweep_body(const JitArgs &A) {
     user_jacobian(A.x, aux, d, J);
 #endif
     S w = 1;
-    if (A.loss_kind == 1) {
+    if (Loss::value) {
       const S den = rr + A.loss_param;
       w = (A.loss_param * A.loss_param) / (den * den);
     }
     w = valid ? w : S(0);
+    // w J^T S J, w J^T S r (linearization.h:113-115, :150-152); under the identity covariance S J is J
+    S wJ[M * N];
+#pragma unroll
+    for (int q = 0; q < M * N; ++q) wJ[q] = w * J[q];
+#if COV == 0
+    const S *SJ = J;
+    const S *Sr = r;
+#else
     S SJ[M * N], Sr[M];
 #pragma unroll
     for (int a = 0; a < M; ++a) {
@@ -205,26 +190,91 @@ __device__ inline void sweep_body(const JitArgs &A) {
       for (int c = 0; c < M; ++c) v += A.cov[a * M + c] * r[c];
       Sr[a] = v;
     }
+#endif
 #pragma unroll
     for (int j = 0; j < N; ++j)
 #pragma unroll
-      for (int i2 = 0; i2 < (COVSYM ? j + 1 : N); ++i2) {
-        S v = 0;
+      for (int i2 = 0; i2 < (COVSYM ? j + 1 : N); ++i2)
+        acc_dot(acc[COVSYM ? j * (j + 1) / 2 + i2 : j * N + i2], wJ + i2, N, SJ + j, N);   // H(i2, j)
 #pragma unroll
-        for (int a = 0; a < M; ++a) v += (w * J[a * N + i2]) * SJ[a * N + j];
-        acc[COVSYM ? j * (j + 1) / 2 + i2 : j * N + i2] += (double)v;   // H(i2, j)
-      }
-#pragma unroll
-    for (int i2 = 0; i2 < N; ++i2) {
-      S v = 0;
-#pragma unroll
-      for (int a = 0; a < M; ++a) v += (w * J[a * N + i2]) * Sr[a];
-      acc[NH + i2] += (double)v;
-    }
+    for (int i2 = 0; i2 < N; ++i2) acc_dot(acc[NH + i2], wJ + i2, N, Sr, 1);
     acc[NH + N] += (double)rr;
 #endif
-    }
+  };
+
+  const long long step = (long long)gridDim.x * kBlock * VEC;
+  long long i = ((long long)blockIdx.x * kBlock + threadIdx.x) * VEC;
+  Pack cur[D > 0 ? D : 1], nxt[D > 0 ? D : 1];
+  if (i < A.count) {
+#pragma unroll
+    for (int p = 0; p < D; ++p) nxt[p] = *(const Pack *)(A.data + p * A.stride + i);
   }
+  for (; i < A.count; i += step) {
+#pragma unroll
+    for (int p = 0; p < D; ++p) cur[p] = nxt[p];
+    // the next step's data are requested before this one's arithmetic starts
+    const long long ahead = i + step < A.count ? i + step : i;
+#pragma unroll
+    for (int p = 0; p < D; ++p) nxt[p] = *(const Pack *)(A.data + p * A.stride + ahead);
+    // an element past the end (the padded tail of the last pack) is evaluated on the pack's first
+    // element, which is in range, and enters every sum with weight zero
+#if MODE == 2 && MOPT_S_BYTES == 4
+    // forward differences evaluate the residual N + 1 times per element; four fp32 elements per
+    // pack are taken in a real loop (unrolled they need more than 256 registers), the element
+    // picked by selects
+#pragma unroll 1
+    for (int e = 0; e < VEC; ++e) {
+      const bool valid = i + e < A.count;
+      S d[D > 0 ? D : 1];
+#pragma unroll
+      for (int p = 0; p < D; ++p) {
+        d[p] = cur[p].v[0];
+#pragma unroll
+        for (int k = 1; k < VEC; ++k) d[p] = (valid && e == k) ? cur[p].v[k] : d[p];
+      }
+      element(d, valid);
+    }
+#else
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+#if MODE == 2
+      __builtin_amdgcn_sched_barrier(0);  // one element after the other: the scheduler would
+#endif                                    // interleave them and double the live Jacobian entries
+      const bool valid = i + e < A.count;
+      S d[D > 0 ? D : 1];
+#pragma unroll
+      for (int p = 0; p < D; ++p) d[p] = valid ? cur[p].v[e] : cur[p].v[0];
+      element(d, valid);
+    }
+#if MODE == 2
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+#endif
+  }
+}
+
+__device__ inline void sweep_body(const JitArgs &A) {
+  // IBaseModel::setup (model.h:19-22): once per parameter vector, here once per workgroup and
+  // parameter vector - x itself and, for forward differences, x + h_j e_j (the reference sets
+  // up one clone of the model per perturbed vector, linearization.h:91-95).
+  __shared__ __attribute__((aligned(16))) S aux[(N + 1) * (AUX > 0 ? AUX : 1)];
+  if (AUX > 0) {
+    const int variants = MODE == 2 ? N + 1 : 1;
+    if ((int)threadIdx.x < variants) {
+      S xs[N];
+#pragma unroll
+      for (int k = 0; k < N; ++k) xs[k] = A.x[k] + ((int)threadIdx.x == k + 1 ? A.h[k] : S(0));
+      user_setup(xs, aux + threadIdx.x * AUX);
+    }
+    __syncthreads();
+  }
+  double acc[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+  if (MODE != 0 && A.loss_kind == 1)
+    sweep_elements<RobustLoss>(A, aux, acc);
+  else
+    sweep_elements<NoLoss>(A, aux, acc);
   block_reduce_store(acc, A.partials + (size_t)blockIdx.x * NACC);
 }
 
@@ -412,7 +462,7 @@ std::string &jitError() {
   return e;
 }
 
-bool compileVariant(JitKernel &k, int mode, bool cov_symmetric, JitVariant &out) {
+bool compileVariant(JitKernel &k, int mode, int cov_mode, JitVariant &out) {
   const std::string defs[] = {
       std::string("-DMOPT_S=") + (k.scalar_bytes == 8 ? "double" : "float"),
       "-DMOPT_N=" + std::to_string(k.n_params),
@@ -420,7 +470,8 @@ bool compileVariant(JitKernel &k, int mode, bool cov_symmetric, JitVariant &out)
       "-DMOPT_D=" + std::to_string(k.n_planes),
       "-DMOPT_A=" + std::to_string(k.n_aux),
       "-DMOPT_MODE=" + std::to_string(mode),
-      std::string("-DMOPT_COVSYM=") + (cov_symmetric ? "1" : "0"),
+      "-DMOPT_COV=" + std::to_string(cov_mode),
+      "-DMOPT_S_BYTES=" + std::to_string(k.scalar_bytes),
       "--offload-arch=gfx950",
       "-O3",
       "-std=c++17",
@@ -497,16 +548,18 @@ bool jitCreate(int scalar_bytes, int n_params, int n_outputs, int n_planes, int 
   out.source += out.wide ? kJitWideSweep : kJitSweep;
   // Errors in the user's text must surface at construction: build the sweeps that touch each
   // body now (cost only: setup + residual; supplied Jacobian); the others on first use.
-  if (!jitVariant(out, 0, true)) return false;
-  if (out.has_jacobian && !jitVariant(out, 1, true)) return false;
+  if (!jitVariant(out, 0, kCovIdentity)) return false;
+  if (out.has_jacobian && !jitVariant(out, 1, kCovIdentity)) return false;
   return true;
 }
 
-const JitVariant *jitVariant(JitKernel &k, int mode, bool cov_symmetric) {
-  if (k.wide) cov_symmetric = false;  // one row form
-  const int key = mode * 2 + (mode != 0 && cov_symmetric ? 1 : 0);
+const JitVariant *jitVariant(JitKernel &k, int mode, int cov_mode) {
+  // cost only: one form; wide models: one row form (n*n + n + 1), covariance always applied
+  if (mode == 0) cov_mode = kCovIdentity;
+  if (k.wide && mode != 0) cov_mode = kCovGeneral;
+  const int key = mode == 0 ? 0 : 1 + (mode - 1) * 3 + cov_mode;
   JitVariant &v = k.variants[key];
-  if (!v.sweep && !compileVariant(k, mode, mode == 0 || cov_symmetric, v)) return nullptr;
+  if (!v.sweep && !compileVariant(k, mode, cov_mode, v)) return nullptr;
   return &v;
 }
 

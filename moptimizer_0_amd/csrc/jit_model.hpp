@@ -21,7 +21,7 @@ struct JitKernel {
   int scalar_bytes = 8, n_params = 0, n_outputs = 0, n_planes = 0, n_aux = 0;
   bool has_jacobian = false;
   bool wide = false;  // n > 8 or m > 4: the column-per-lane sweep (JitWideArgs, rows of n*n + n + 1)
-  JitVariant variants[6];  // [mode * 2 + cov_symmetric]; mode 0 (cost only) uses slot 0
+  JitVariant variants[7];  // [0]: cost only; [1 + (mode - 1) * 3 + cov_mode]: mode 1 / 2 x CovMode
 };
 
 // Kernel argument block; the device-side declaration in jit_model.cpp has the same members in the
@@ -60,9 +60,10 @@ constexpr int kJitWideElementsPerBlock = 16;  // 256 threads = 16 elements x 16 
 bool jitCreate(int scalar_bytes, int n_params, int n_outputs, int n_planes, int n_aux,
                const char *setup_body, const char *residual_body, const char *jacobian_body,
                JitKernel &out);
-// mode: 0 cost only, 1 supplied Jacobian, 2 forward differences.  Compiled on first use;
+// mode: 0 cost only, 1 supplied Jacobian, 2 forward differences; cov_mode: CovMode (identity /
+// symmetric rows are the upper triangle, general rows the full matrix).  Compiled on first use;
 // nullptr (and jitLastError) when that fails.
-const JitVariant *jitVariant(JitKernel &k, int mode, bool cov_symmetric);
+const JitVariant *jitVariant(JitKernel &k, int mode, int cov_mode);
 void jitRelease(JitKernel &k);
 hipError_t jitLaunch(const JitVariant &v, const void *args, size_t args_bytes, int grid,
                      hipStream_t stream);

@@ -272,7 +272,12 @@ def test_run_time_compiled_models_under_the_device_loop(hip_lib, oracle):
     for jac in (mo.JAC_NUMERIC, mo.JAC_ANALYTIC):
         xj, rj = mo.capi.lm_minimize([jit], [jac], np.zeros(2), max_iterations=50)
         xh, sh, ih = host_lm_n(jit, jac, np.zeros(2), 50)
-        assert rj["status"] == sh and abs(rj["iterations"] - ih) <= 1, (rj, sh, ih)
+        # same status and end point; the same number of outer iterations, or — both loops idle at
+        # the minimum until rho < 0 meets a small delta, which the last bits of the cost decide — the
+        # same minimum
+        assert rj["status"] == sh, (rj, sh, ih)
+        assert abs(rj["iterations"] - ih) <= 1 or \
+            abs(rj["cost"] - jit.compute_cost(xh)) <= 1e-9 * rj["cost"], (rj, sh, ih)
         assert np.abs(xj - xh).max() < 1e-6
         assert np.abs(xj - np.array([0.3, 0.1])).max() < 0.1  # near the generating parameters
     xb, rb = mo.capi.lm_minimize([builtin], [mo.JAC_NUMERIC], np.zeros(2), max_iterations=50)
