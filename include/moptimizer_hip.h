@@ -213,9 +213,9 @@ MOPT_API int mopt_scalar_model_create(mopt_cost **out, int device, int scalar_by
  * S is `double` or `float` per scalar_bytes; 1 <= n <= 16, 1 <= m <= 16, 0 <= n_planes <= 16,
  * 0 <= n_aux <= 64.  Models with n <= 8 and m <= 4 get the per-lane sweep and everything the
  * built-in models have; wider ones (tst/state_model.cpp: n = m = 15) get a sweep that spreads an
- * element's Jacobian columns over 16 lanes, through the blocking and async calls and the RCCL
- * communicator only — mopt_lm_minimize and the host / peer combines return MOPT_ERR_UNSUPPORTED
- * for them (their state and slots are sized for n <= 8).  data: n_planes arrays of `count` scalars, plane p at data + p * plane_stride
+ * element's Jacobian columns over 16 lanes — every call of the narrow ones works for them too
+ * (blocking, async, mopt_lm_minimize, all three shard combines); only costs of one
+ * mopt_lm_minimize problem must share n.  data: n_planes arrays of `count` scalars, plane p at data + p * plane_stride
  * (host memory, or device memory with MOPT_INPUT_DEVICE); copied once.  Everything else (loss,
  * covariance, numeric differentiation with the reference's step, the returned unweighted cost,
  * speculation, async calls, communicators) is that of the built-in models.  A body that does not

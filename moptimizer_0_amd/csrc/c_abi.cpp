@@ -509,9 +509,6 @@ int jitSweepAsync(mopt_cost *c, bool cost_only, int jac_mode, const S *x, double
   const int n = c->n_params;
   SweepTimer timer(c, s);
   if (c->jit.wide) {
-    if (c->combine.mode == MOPT_COMBINE_HOST || c->combine.mode == MOPT_COMBINE_PEER)
-      return fail(MOPT_ERR_UNSUPPORTED,
-                  "the host / peer combine slots hold the sums of models with n <= 8");
     mopt::JitWideArgs<S> args;
     fillJitWideArgs<S>(c, x, args);
     MOPT_HIP_TRY(mopt::jitLaunch(*variant, &args, sizeof args, grid, s));
@@ -717,8 +714,8 @@ namespace mopt_detail {
 namespace {
 template <typename Args>
 int uploadArgs(mopt_cost *c, const Args &host_value, hipStream_t s) {
-  if (!c->d_lm_args) MOPT_HIP_TRY(deviceAlloc(&c->d_lm_args, 2048));  // >= every Args struct
-  static_assert(sizeof(Args) <= 2048, "resident argument block too small");
+  if (!c->d_lm_args) MOPT_HIP_TRY(deviceAlloc(&c->d_lm_args, 4096));  // >= every Args struct
+  static_assert(sizeof(Args) <= 4096, "resident argument block too small");
   MOPT_HIP_TRY(mopt::launchStoreArgs<Args>(host_value, static_cast<Args *>(c->d_lm_args), s));
   return MOPT_OK;
 }
@@ -775,8 +772,10 @@ int residentDenseRow(const mopt_cost *c) {
       return c->cov_mode == mopt::kCovGeneral ? mopt::kAccFull : mopt::kAccSym;
     case kModelReprojection:
       return c->cov_mode == mopt::kCovGeneral ? mopt::kAccFull : mopt::kAccSym;
-    case kModelScalar:
     case kModelJit:
+      if (c->jit.wide) return n * n + n + 1;  // the column-per-lane sweep has one row form
+      return c->cov_mode == mopt::kCovGeneral ? n * n + n + 1 : n * (n + 1) / 2 + n + 1;
+    case kModelScalar:
       return c->cov_mode == mopt::kCovGeneral ? n * n + n + 1 : n * (n + 1) / 2 + n + 1;
     default:
       return 0;
@@ -858,14 +857,31 @@ int residentPrepare(mopt_cost *c, int jac_mode, hipStream_t s, mopt::LmCostDesc 
       if (jac_mode == MOPT_JAC_ANALYTIC && !c->jit.has_jacobian)
         return fail(MOPT_ERR_UNSUPPORTED,
                     "Non implemented non-jacobian model function `f_df` being used.");
-      if (c->jit.wide)
-        return fail(MOPT_ERR_UNSUPPORTED,
-                    "mopt_lm_minimize keeps its state for n <= 8: drive a wide model (n > 8 or m > 4) "
-                    "through the blocking calls");
       // compile (first use) before anything is queued: a source error must surface here
       if (!mopt::jitVariant(c->jit, jac_mode == MOPT_JAC_NUMERIC ? 2 : 1, c->cov_mode))
         return fail(MOPT_ERR_INVALID_ARGUMENT, mopt::jitLastError());
       desc->model = mopt::kLmJit;
+      if (c->jit.wide) {  // x[16] | h[16] in the wide sweep's argument block
+        desc->x_slots = mopt::kMaxWideParams;
+        desc->x_offset = c->scalar_bytes == 8 ? int(offsetof(mopt::JitWideArgs<double>, x))
+                                              : int(offsetof(mopt::JitWideArgs<float>, x));
+        if (stale) {
+          if (c->scalar_bytes == 8) {
+            mopt::JitWideArgs<double> args;
+            const double zero[mopt::kMaxWideParams] = {0};
+            fillJitWideArgs<double>(c, zero, args);
+            args.partials = partials;
+            rc = uploadArgs(c, args, s);
+          } else {
+            mopt::JitWideArgs<float> args;
+            const float zero[mopt::kMaxWideParams] = {0};
+            fillJitWideArgs<float>(c, zero, args);
+            args.partials = partials;
+            rc = uploadArgs(c, args, s);
+          }
+        }
+        break;
+      }
       desc->x_offset = c->scalar_bytes == 8 ? int(offsetof(mopt::JitArgs<double>, x))
                                             : int(offsetof(mopt::JitArgs<float>, x));
       if (stale) {

@@ -332,7 +332,7 @@ struct JitArgs {
 )JIT";
 
 const char *const kJitWideSweep = R"JIT(
-extern "C" __global__ __launch_bounds__(kBlock) void mopt_jit_sweep(const JitArgs A) {
+__device__ inline void wide_body(const JitArgs &A) {
   __shared__ S aux[(N + 1) * (AUX > 0 ? AUX : 1)];
   // Jacobians of the 16 elements in flight (row-major M x N each); afterwards the lanes' sums
   __shared__ double pool[kBlock * (N + 2)];
@@ -455,6 +455,19 @@ extern "C" __global__ __launch_bounds__(kBlock) void mopt_jit_sweep(const JitArg
     out_row[t] = v;
   }
 }
+
+extern "C" __global__ __launch_bounds__(kBlock) void mopt_jit_sweep(const JitArgs A) { wide_body(A); }
+
+// Resident form for the device-resident LM, as the narrow sweep's: x and the forward-difference
+// steps in the argument block are rewritten by the LM step kernel for every trial point.
+struct LmControl {
+  int done, trial, pad[2];
+};
+extern "C" __global__ __launch_bounds__(kBlock) void mopt_jit_sweep_resident(
+    const JitArgs *__restrict__ d_args, const LmControl *__restrict__ control) {
+  if (control->done) return;
+  wide_body(*d_args);
+}
 )JIT";
 
 std::string &jitError() {
@@ -505,8 +518,7 @@ bool compileVariant(JitKernel &k, int mode, int cov_mode, JitVariant &out) {
     return false;
   }
   if (hipModuleGetFunction(&out.sweep, out.module, "mopt_jit_sweep") != hipSuccess ||
-      (!k.wide && hipModuleGetFunction(&out.sweep_resident, out.module, "mopt_jit_sweep_resident") !=
-                      hipSuccess)) {
+      hipModuleGetFunction(&out.sweep_resident, out.module, "mopt_jit_sweep_resident") != hipSuccess) {
     jitError() = "compiled model has no mopt_jit_sweep";
     (void)hipModuleUnload(out.module);
     out.module = nullptr;

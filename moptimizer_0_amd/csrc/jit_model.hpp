@@ -40,7 +40,7 @@ struct JitArgs {
   double *partials;
 };
 
-// The wide sweep's argument block (n <= 16, m <= 16; no resident form).
+// The wide sweep's argument block (n <= 16, m <= 16).
 template <typename S>
 struct JitWideArgs {
   const S *data;

@@ -12,13 +12,16 @@
 namespace mopt {
 namespace {
 
-template <typename S>
+// NMAX: kMaxParams (8) for the models of the path, kMaxWideParams (16) for wide run-time compiled
+// models (tst/state_model.cpp: n = 15) — the step is instantiated for both and a problem uses the
+// one its n asks for, so that the 6-parameter problems do not carry 16-wide loops.
+template <typename S, int NMAX>
 struct LmState {
-  S x0[kMaxParams];
-  S xi[kMaxParams];
-  S delta[kMaxParams];
-  S H[kMaxParams * kMaxParams];  // column-major n x n, at x0
-  S b[kMaxParams];
+  S x0[NMAX];
+  S xi[NMAX];
+  S delta[NMAX];
+  S H[NMAX * NMAX];  // column-major n x n, at x0
+  S b[NMAX];
   S y0;
   S lambda;
   S nu;
@@ -32,7 +35,7 @@ struct LmState {
 
 template <typename S>
 struct LmStart {
-  S x[kMaxParams];
+  S x[kMaxWideParams];
 };
 
 __device__ __forceinline__ void sinCosOf(double t, double *s, double *c) { sincos(t, s, c); }
@@ -131,16 +134,16 @@ __device__ __forceinline__ S forwardStep(S xj) {
 // statement of tests/support/moptimizer_caller/ldlt.hpp (vanishing pivots give a zero component).
 // Runs on one lane; its work arrays live in LDS (indexed dynamically: as private arrays they would
 // go to scratch memory, a global-memory round trip per dependent access).
-template <typename S>
+template <typename S, int NMAX>
 struct SolveScratch {
-  S m[kMaxParams][kMaxParams];
-  S scaled[kMaxParams], y[kMaxParams];
-  int perm[kMaxParams];
+  S m[NMAX][NMAX];
+  S scaled[NMAX], y[NMAX];
+  int perm[NMAX];
 };
 
-template <typename S>
+template <typename S, int NMAX>
 __device__ void solveDamped(const S *H, const S *b, S lambda, int n, S *delta,
-                            SolveScratch<S> &w) {
+                            SolveScratch<S, NMAX> &w) {
 #pragma clang fp contract(off)
   auto &m = w.m;
   auto &perm = w.perm;
@@ -494,10 +497,11 @@ __device__ void writeSweepConstants(const LmProblem &P, const S *x) {
     } else {  // scalar / run-time compiled models: the sweep differentiates (and runs the user's
               // setup) by itself, it needs x and the steps; d.x_offset locates them in the block
       S *xs = reinterpret_cast<S *>(static_cast<char *>(d.args) + d.x_offset);
-      if (tid < kMaxParams) {
+      const int slots = d.x_slots;  // x[slots] | h[slots]: 8, or 16 in a wide model's block
+      if (tid < slots) {
         const S xv = tid < P.n ? x[tid] : S(0);
         xs[tid] = xv;
-        xs[kMaxParams + tid] = forwardStep<S>(xv);  // h[] follows x[] in both argument layouts
+        xs[slots + tid] = forwardStep<S>(xv);  // h[] follows x[] in every argument layout
       }
     }
   }
@@ -522,10 +526,10 @@ __device__ __forceinline__ void storeReport(double *p, double v) {
 //               nullptr when every cost's result comes from HBM
 //   state_word  word `threadIdx.x` of the stored state, loaded by the caller ahead of its own work
 //               so that the round trip overlaps it (ignored when `prefetched` is false)
-template <typename S>
-__device__ void lmStepBody(const LmProblem &P, bool init, const LmStart<S> &start,
-                           const double *own_result, int own_index, bool prefetched,
-                           unsigned int state_word) {
+template <typename S, int NMAX>
+__device__ void lmStepBodyFor(const LmProblem &P, bool init, const LmStart<S> &start,
+                              const double *own_result, int own_index, bool prefetched,
+                              unsigned int state_word) {
 #ifdef MOPT_LM_TIMING
   __shared__ unsigned long long tick[8];
 #define MOPT_TICK(i) if (threadIdx.x == 0) tick[i] = wall_clock64()
@@ -536,16 +540,16 @@ __device__ void lmStepBody(const LmProblem &P, bool init, const LmStart<S> &star
   LmControl *ctl = P.control;
   // The loop's state lives in HBM between launches; this run works on a copy in LDS (loaded and
   // written back by all lanes: one memory round trip each way instead of one per access).
-  __shared__ LmState<S> st;
-  __shared__ S sums[kMaxParams * kMaxParams + kMaxParams + 1];  // H | b | sum_sq over the costs
-  __shared__ S next_x[kMaxParams];
+  __shared__ LmState<S, NMAX> st;
+  __shared__ S sums[NMAX * NMAX + NMAX + 1];  // H | b | sum_sq over the costs
+  __shared__ S next_x[NMAX];
   __shared__ int propose, finished;
-  __shared__ SolveScratch<S> solve_scratch;
-  LmState<S> *stored = static_cast<LmState<S> *>(P.state);
+  __shared__ SolveScratch<S, NMAX> solve_scratch;
+  LmState<S, NMAX> *stored = static_cast<LmState<S, NMAX> *>(P.state);
   const int n = P.n;
   const int nn = n * n;
   const int tid = threadIdx.x;
-  constexpr int kStateWords = int(sizeof(LmState<S>) / sizeof(unsigned int));
+  constexpr int kStateWords = int(sizeof(LmState<S, NMAX>) / sizeof(unsigned int));
   if (!init) {
     if (prefetched) {
       if (tid < kStateWords) reinterpret_cast<unsigned int *>(&st)[tid] = state_word;
@@ -580,9 +584,9 @@ __device__ void lmStepBody(const LmProblem &P, bool init, const LmStart<S> &star
     finished = 0;
     adopt_sums = 0;
     rematch_next = init ? P.rematch : 0;
-    S x0[kMaxParams], xi[kMaxParams], delta[kMaxParams], bcur[kMaxParams];
+    S x0[NMAX], xi[NMAX], delta[NMAX], bcur[NMAX];
 #pragma unroll
-    for (int i = 0; i < kMaxParams; ++i) {
+    for (int i = 0; i < NMAX; ++i) {
       x0[i] = init ? (i < n ? start.x[i] : S(0)) : st.x0[i];
       xi[i] = init ? x0[i] : st.xi[i];
       delta[i] = init ? S(0) : st.delta[i];
@@ -618,10 +622,10 @@ __device__ void lmStepBody(const LmProblem &P, bool init, const LmStart<S> &star
             solveDampedFixed<S, 2>(Hcur, bsrc, lambda, delta);
           break;
         default: {
-          S d[kMaxParams];
-          solveDamped<S>(Hcur, bsrc, lambda, n, d, solve_scratch);
+          S d[NMAX];
+          solveDamped<S, NMAX>(Hcur, bsrc, lambda, n, d, solve_scratch);
 #pragma unroll
-          for (int i = 0; i < kMaxParams; ++i)
+          for (int i = 0; i < NMAX; ++i)
             if (i < n) delta[i] = d[i];
           break;
         }
@@ -637,11 +641,11 @@ __device__ void lmStepBody(const LmProblem &P, bool init, const LmStart<S> &star
         for (int i = 0; i < kNumParams; ++i) xi[i] = plus[i];
       } else {
 #pragma unroll
-        for (int i = 0; i < kMaxParams; ++i)
+        for (int i = 0; i < NMAX; ++i)
           if (i < n) xi[i] = x0[i] + delta[i];
       }
 #pragma unroll
-      for (int i = 0; i < kMaxParams; ++i) next_x[i] = xi[i];
+      for (int i = 0; i < NMAX; ++i) next_x[i] = xi[i];
       propose = 1;
     };
     // top of an outer iteration once H, b, y0 at x0 are known (:62-70)
@@ -650,7 +654,7 @@ __device__ void lmStepBody(const LmProblem &P, bool init, const LmStart<S> &star
       if (lambda < S(0)) {
         S max_diag = 0;
 #pragma unroll
-        for (int i = 0; i < kMaxParams; ++i)
+        for (int i = 0; i < NMAX; ++i)
           if (i < n) max_diag = fmax(max_diag, fabs(Hcur[i * n + i]));
         lambda = S(1e-9) * max_diag;
       }
@@ -664,7 +668,7 @@ __device__ void lmStepBody(const LmProblem &P, bool init, const LmStart<S> &star
       st.trials = 0;
       st.steps = 0;
 #pragma unroll
-      for (int i = 0; i < kMaxParams; ++i) next_x[i] = x0[i];
+      for (int i = 0; i < NMAX; ++i) next_x[i] = x0[i];
       propose = 1;
     } else {
       const S ys = sums[nn + n];
@@ -684,13 +688,13 @@ __device__ void lmStepBody(const LmProblem &P, bool init, const LmStart<S> &star
       } else {
         S predicted = S(0);
 #pragma unroll
-        for (int i = 0; i < kMaxParams; ++i)
+        for (int i = 0; i < NMAX; ++i)
           if (i < n) predicted += delta[i] * (lambda * delta[i] - bcur[i]);
         const S rho = (y0 - ys) / predicted;  // :93
         if (rho < S(0)) {
           S max_delta = S(0);
 #pragma unroll
-          for (int i = 0; i < kMaxParams; ++i)
+          for (int i = 0; i < NMAX; ++i)
             if (i < n) max_delta = fmax(max_delta, fabs(delta[i]));
           if (max_delta < sqrt(std::numeric_limits<S>::epsilon())) {  // delta.h:10-16
             finish(isCostSmall<S>(ys) ? kLmConverged : kLmSmallDelta);
@@ -710,7 +714,7 @@ __device__ void lmStepBody(const LmProblem &P, bool init, const LmStart<S> &star
           }
         } else {
 #pragma unroll
-          for (int i = 0; i < kMaxParams; ++i)
+          for (int i = 0; i < NMAX; ++i)
             if (i < n) x0[i] = xi[i];  // :112
           const double t = 2.0 * double(rho) - 1.0;
           const double shrink = fmax(1.0 / 3.0, 1.0 - t * t * t);  // :113
@@ -727,7 +731,7 @@ __device__ void lmStepBody(const LmProblem &P, bool init, const LmStart<S> &star
             st.awaiting_x0 = 1;
             rematch_next = 1;
 #pragma unroll
-            for (int i = 0; i < kMaxParams; ++i) next_x[i] = x0[i];
+            for (int i = 0; i < NMAX; ++i) next_x[i] = x0[i];
             propose = 1;
           } else {
             adopt();  // the trial sweep WAS the linearization at the new x0
@@ -737,7 +741,7 @@ __device__ void lmStepBody(const LmProblem &P, bool init, const LmStart<S> &star
       }
     }
 #pragma unroll
-    for (int i = 0; i < kMaxParams; ++i) {
+    for (int i = 0; i < NMAX; ++i) {
       st.x0[i] = x0[i];
       st.xi[i] = xi[i];
       st.delta[i] = delta[i];
@@ -752,8 +756,8 @@ __device__ void lmStepBody(const LmProblem &P, bool init, const LmStart<S> &star
   }
   __syncthreads();
   if (init) {
-    for (int q = tid; q < kMaxParams * kMaxParams; q += blockDim.x) st.H[q] = S(0);
-    if (tid < kMaxParams) st.b[tid] = S(0);
+    for (int q = tid; q < NMAX * NMAX; q += blockDim.x) st.H[q] = S(0);
+    if (tid < NMAX) st.b[tid] = S(0);
     __syncthreads();
   } else if (adopt_sums) {
     if (tid < nn) st.H[tid] = sums[tid];
@@ -778,14 +782,14 @@ __device__ void lmStepBody(const LmProblem &P, bool init, const LmStart<S> &star
   // payload write-through, drained, then the word with its low bit set.
   if (tid == 0 && P.report) {
     if (finished) {
-      double *rep = reinterpret_cast<double *>(P.report);
-      for (int i = 0; i < kMaxParams; ++i) storeReport(rep + i, double(st.x0[i]));
-      storeReport(rep + 8, double(st.y0));
-      storeReport(rep + 9, double(st.lambda));
-      storeReport(rep + 10, double(st.status));
-      storeReport(rep + 11, double(st.it));
-      storeReport(rep + 12, double(st.trials));
-      storeReport(rep + 13, double(ctl->pad[0]));
+      LmReport *rep = P.report;
+      for (int i = 0; i < NMAX; ++i) storeReport(&rep->x[i], double(st.x0[i]));
+      storeReport(&rep->cost, double(st.y0));
+      storeReport(&rep->lambda, double(st.lambda));
+      storeReport(&rep->status, double(st.status));
+      storeReport(&rep->iterations, double(st.it));
+      storeReport(&rep->trials, double(st.trials));
+      storeReport(&rep->peer_status, double(ctl->pad[0]));
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 #ifdef MOPT_LM_TIMING
@@ -804,10 +808,21 @@ __device__ void lmStepBody(const LmProblem &P, bool init, const LmStart<S> &star
 // Word `threadIdx.x` of the stored state, for lmStepBody's `state_word`.
 template <typename S>
 __device__ __forceinline__ unsigned int lmPrefetchState(const LmProblem &P) {
-  constexpr int kStateWords = int(sizeof(LmState<S>) / sizeof(unsigned int));
-  return int(threadIdx.x) < kStateWords
-             ? reinterpret_cast<const unsigned int *>(P.state)[threadIdx.x]
-             : 0u;
+  const int words = P.n <= kMaxParams ? int(sizeof(LmState<S, kMaxParams>) / sizeof(unsigned int))
+                                      : int(sizeof(LmState<S, kMaxWideParams>) / sizeof(unsigned int));
+  return int(threadIdx.x) < words ? reinterpret_cast<const unsigned int *>(P.state)[threadIdx.x]
+                                  : 0u;
+}
+
+// The step for this problem's parameter count (see LmState).
+template <typename S>
+__device__ void lmStepBody(const LmProblem &P, bool init, const LmStart<S> &start,
+                           const double *own_result, int own_index, bool prefetched,
+                           unsigned int state_word) {
+  if (P.n <= kMaxParams)
+    lmStepBodyFor<S, kMaxParams>(P, init, start, own_result, own_index, prefetched, state_word);
+  else
+    lmStepBodyFor<S, kMaxWideParams>(P, init, start, own_result, own_index, prefetched, state_word);
 }
 
 }  // namespace

@@ -37,7 +37,7 @@ __global__ void storeArgsKernel(const Args value, Args *dst) {
 template <typename S>
 hipError_t launchLmStep(const LmProblem &problem, bool init, const S *x0, hipStream_t stream) {
   LmStart<S> start;
-  for (int i = 0; i < kMaxParams; ++i) start.x[i] = (init && x0 && i < problem.n) ? x0[i] : S(0);
+  for (int i = 0; i < kMaxWideParams; ++i) start.x[i] = (init && x0 && i < problem.n) ? x0[i] : S(0);
   hipLaunchKernelGGL((lmStepKernel<S>), dim3(1), dim3(128), 0, stream, problem, init ? 1 : 0, start);
   return hipGetLastError();
 }
@@ -65,5 +65,9 @@ template hipError_t launchStoreArgs<JitArgs<float>>(const JitArgs<float> &, JitA
                                                     hipStream_t);
 template hipError_t launchStoreArgs<JitArgs<double>>(const JitArgs<double> &, JitArgs<double> *,
                                                      hipStream_t);
+template hipError_t launchStoreArgs<JitWideArgs<float>>(const JitWideArgs<float> &,
+                                                        JitWideArgs<float> *, hipStream_t);
+template hipError_t launchStoreArgs<JitWideArgs<double>>(const JitWideArgs<double> &,
+                                                         JitWideArgs<double> *, hipStream_t);
 
 }  // namespace mopt

@@ -143,10 +143,10 @@ struct HostPublish {
 // can only be one sweep ahead of the slowest reader (it needs that reader's flag of the sweep in
 // between), so a slot is never overwritten while someone may still read it.
 constexpr int kMaxPeers = 8;                    // one node: 8 GPUs
-constexpr int kSlotData = 96;                   // >= n*n + n + 1 for n <= 8
+constexpr int kSlotData = 288;                  // >= n*n + n + 1 for n <= 16 (wide models: 273)
 constexpr int kSlotFlag = kSlotData;            // sequence word (as unsigned long long)
 constexpr int kSlotStatus = kSlotData + 1;      // 0 ok, kStatusPeerTimeout
-constexpr int kSlotDoubles = kSlotData + 16;    // 896 B: flag and status on their own 128-B line
+constexpr int kSlotDoubles = kSlotData + 16;    // 2432 B: flag and status on their own 128-B line
 constexpr unsigned long long kStatusPeerTimeout = 1;
 __host__ __device__ inline size_t slotBlockDoubles(int num_ranks) { return size_t(2) * num_ranks * kSlotDoubles; }
 __host__ __device__ inline size_t slotIndex(unsigned long long sequence, int num_ranks, int rank) {
@@ -196,8 +196,8 @@ struct LmCostDesc {
   int jac_mode = 0;  // JacMode
   int n_out = 0;
   int moments = 0;   // point2point: the finalize kernel contracts moments with `basis`
-  int x_offset = 0;  // scalar / run-time compiled models: byte offset of x[8] | h[8] inside `args`
-  int pad = 0;
+  int x_offset = 0;  // scalar / run-time compiled models: byte offset of x[] | h[] inside `args`
+  int x_slots = 8;   // length of each of the two (16 in a wide model's argument block)
   void *args = nullptr;           // device: P2PSweepArgs<S> / ReprojSweepArgs / ScalarSweepArgs<S>
   AffineBasis *basis = nullptr;   // device, point2point moments
   const double *result = nullptr; // device: this cost's H | b | sum_sq (summed over the ranks)
@@ -206,7 +206,7 @@ struct LmCostDesc {
 };
 
 struct LmReport {  // mapped host memory (as doubles so that one layout serves float and double)
-  double x[kMaxParams];
+  double x[kMaxWideParams];
   double cost;        // sum of squares at the returned x
   double lambda;
   double status;      // LmStatus

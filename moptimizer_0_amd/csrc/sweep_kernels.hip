@@ -1439,7 +1439,7 @@ hipError_t launchFinalizeDenseResident(const double *partials, int grid, int nac
                                        double *result, LmControl *control, hipStream_t stream,
                                        const PeerCombine *peers, const LmProblem *step,
                                        int own_index, int scalar_bytes) {
-  if (n < 1 || n > kMaxParams || (nacc != n * (n + 1) / 2 + n + 1 && nacc != n * n + n + 1))
+  if (n < 1 || n > kMaxWideParams || (nacc != n * (n + 1) / 2 + n + 1 && nacc != n * n + n + 1))
     return hipErrorInvalidValue;
   const PeerCombine pc = peers ? *peers : PeerCombine();
   const dim3 g(1), b(kFinalThreads);

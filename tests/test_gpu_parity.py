@@ -1211,8 +1211,6 @@ def test_state_model_of_the_reference_n15_m15(hip_lib, oracle):
     cost.set_loss(mo.LOSS_NONE, 0.0)
     with pytest.raises(mo.capi.MoptError):   # no f_df, as the reference's BaseModel throws (model.h:29-33)
         cost.linearize(x, mo.JAC_ANALYTIC)
-    with pytest.raises(mo.capi.MoptError):   # the device-resident loop keeps its state for n <= 8
-        mo.capi.lm_minimize([cost], [mo.JAC_NUMERIC], x)
 
     # lm.addCost(&cost); lm.minimize(x) (:108-109) as the host loop over the HIP cost
     def host_loop(x0, max_iter=15, lm_iter=3):
@@ -1243,6 +1241,34 @@ def test_state_model_of_the_reference_n15_m15(hip_lib, oracle):
     xo, so, io = oracle.state_minimize(x_init, x)
     assert status == so and abs(iters - io) <= 1, (status, iters, so, io)
     assert np.abs(xs - x_init).max() < 1e-7 and np.abs(xs - xo).max() < 1e-7, (xs, xo)
+    # ... and as LevenbergMarquadtDevice: the same program with the loop on the device (round 3: the
+    # loop's state, its solve and its report hold n <= 16)
+    xd, rep = mo.capi.lm_minimize([cost], [mo.JAC_NUMERIC], x)
+    assert rep["status"] == so and abs(rep["iterations"] - io) <= 1, (rep, so, io)
+    assert np.abs(xd - x_init).max() < 1e-7 and np.abs(xd - xo).max() < 1e-7, (xd, xo)
+    # iterate for iterate against the host loop over the same HIP cost (against the CPU cost only
+    # the end point is comparable: so3::Log's `trace > 3 - 1e-6` switch (src/so3.cpp:99) sits where
+    # the second iterate lands, and device libm puts forward differences on the other side of it)
+    for k in (1, 2, 3):
+        xk, repk = mo.capi.lm_minimize([cost], [mo.JAC_NUMERIC], x, max_iterations=k)
+        xhk, shk, ihk = host_loop(x, max_iter=k)
+        assert (repk["status"], repk["iterations"]) == (shk, ihk), (k, repk, shk, ihk)
+        assert np.abs(xk - xhk).max() < 1e-7, (k, xk, xhk)  # numpy solve there, LDL^T here
+    # the shard-combine slots hold 15 * 15 + 15 + 1 = 241 sums too: a one-rank block of each kind
+    want = cost.linearize(points[2], mo.JAC_NUMERIC)
+    tag = "/mopt-test-wide-%d" % os.getpid()
+    cost.hostcomm_attach(tag, 0, 1)
+    cost.peer_attach([cost.peer_export(1)], 0, 1)
+    for mode in (mo.COMBINE_HOST, mo.COMBINE_PEER):
+        cost.set_combine(mode)
+        got = cost.linearize(points[2], mo.JAC_NUMERIC)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[2] == want[2]
+        assert abs(cost.compute_cost(points[2]) - want[2]) <= 1e-12 * want[2]
+    cost.set_combine(mo.COMBINE_PEER)
+    xp, repp = mo.capi.lm_minimize([cost], [mo.JAC_NUMERIC], x)
+    assert repp["status"] == rep["status"] and np.array_equal(xp, xd), (repp, rep, xp, xd)
+    cost.set_combine(mo.COMBINE_NONE)
+    mo.capi.hostcomm_unlink(tag)
     cost.close()
 
 
