@@ -66,6 +66,11 @@ def parse_args():
     ap.add_argument("--mode", choices=["analytic", "analytic_tst", "numeric"], default="analytic")
     ap.add_argument("--variant", choices=["auto", "literal", "moments"], default="auto")
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--cov", choices=["identity", "symmetric", "general"], default="identity",
+                    help="covariance of the cost (CostFunctionBase::setCovariance): the reference's "
+                         "default identity, or a fixed symmetric / non-symmetric 3x3 one")
+    ap.add_argument("--loss", choices=["none", "gm"], default="none",
+                    help="gm = loss::GemmanMCClure(100)")
     ap.add_argument("--collective", choices=["auto", "host", "peer", "rccl", "torch"], default="auto",
                     help="N>1, how the 43 sums are added over the ranks: host = every finalize kernel "
                          "publishes into one shared pinned host block, the host adds (one hop, no "
@@ -323,6 +328,11 @@ def main():
         cost = mo.Point2PointCost(src.data_ptr(), tgt.data_ptr(), device=local_rank, dtype=np_dtype,
                                   device_ptrs=True, count=n)
         cost.set_kernel_variant(variant)
+        if args.cov != "identity":
+            cost.set_covariance({"symmetric": [[2.0, 0.3, -0.1], [0.3, 1.5, 0.2], [-0.1, 0.2, 0.8]],
+                                 "general": [[2.0, 0.5, -0.1], [0.3, 1.5, 0.4], [-0.3, 0.2, 0.8]]}[args.cov])
+        if args.loss == "gm":
+            cost.set_loss(mo.LOSS_GEMAN_MCCLURE, 100.0)
         return cost, src, tgt
 
     if args.total_n:
@@ -396,6 +406,8 @@ def main():
         torch.cuda.synchronize()
 
     def settle_steps(n_per_rank, ms):
+        # n_per_rank must be the same number on every rank (shards of an indivisible total differ by
+        # one correspondence): every settling step holds a combine, so the counts have to agree
         est_step_s = 20e-6 + n_per_rank * BYTES_PER_CORRESPONDENCE[scalar_bytes] / 6.0e12
         return min(20000, max(50, int(ms * 1e-3 / est_step_s)))
 
@@ -484,7 +496,7 @@ def main():
                 "step_frac": n_per_gpu * bpc / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
     cost.set_profiling(False)
-    settle = settle_steps(args.n, args.settle_ms)
+    settle = settle_steps(total // world, args.settle_ms)
     if world == 1:
         elapsed, H, s = timed_pass(cost, None, args.steps, args.warmup, settle)
     else:
@@ -568,6 +580,8 @@ def main():
             "rehearsal": ("%d ranks on %d GPU(s), torch.distributed over %s" % (world, ndev, backend))
             if rehearsal else None,
             "kernel_variant": args.variant,
+            "covariance": args.cov,
+            "loss": args.loss,
         },
         "roofline": {
             "bound": "hbm",
@@ -660,7 +674,8 @@ def main():
         attached4 = attach_combines(cost4, rank, world, want=tuple(usable), log=log) if usable else []
         per4 = {}
         for name in ["none"] + attached4:
-            r = guarded_pass(cost4, name, args.steps, min(args.warmup, 10), settle_steps(hi - lo, 50.0))
+            r = guarded_pass(cost4, name, args.steps, min(args.warmup, 10),
+                             settle_steps(total4 // world, 50.0))
             if r is not None:
                 per4[name] = as_step_sees_it(r[0] / args.steps * 1e3, hi - lo, total4)
         combined = {k: v for k, v in per4.items() if k != "none"}

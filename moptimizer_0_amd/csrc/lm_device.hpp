@@ -137,13 +137,13 @@ __device__ __forceinline__ S forwardStep(S xj) {
 template <typename S, int NMAX>
 struct SolveScratch {
   S m[NMAX][NMAX];
-  S scaled[NMAX], y[NMAX];
+  S scaled[NMAX], y[NMAX], delta[NMAX];
   int perm[NMAX];
 };
 
+// The solution is left in w.delta (LDS: it is written through the permutation, a dynamic index).
 template <typename S, int NMAX>
-__device__ void solveDamped(const S *H, const S *b, S lambda, int n, S *delta,
-                            SolveScratch<S, NMAX> &w) {
+__device__ void solveDamped(const S *H, const S *b, S lambda, int n, SolveScratch<S, NMAX> &w) {
 #pragma clang fp contract(off)
   auto &m = w.m;
   auto &perm = w.perm;
@@ -203,7 +203,7 @@ __device__ void solveDamped(const S *H, const S *b, S lambda, int n, S *delta,
     for (int j = i + 1; j < n; ++j) v -= m[j][i] * y[j];
     y[i] = v;
   }
-  for (int i = 0; i < n; ++i) delta[perm[i]] = y[i];
+  for (int i = 0; i < n; ++i) w.delta[perm[i]] = y[i];
 }
 
 // The same factorisation for a compile-time n, fully unrolled so that the matrix lives in registers
@@ -406,7 +406,7 @@ __device__ void projectionFor(const LmCostDesc &d, const double (&T)[12], double
 // The per-x constants of every cost's next sweep, at point x (LDS).  Lane j (0..6) forms the
 // transform at x (j = 0) or at x + h_j e_j.
 template <typename S>
-__device__ void writeSweepConstants(const LmProblem &P, const S *x) {
+__device__ __forceinline__ void writeSweepConstants(const LmProblem &P, const S *x) {
   __shared__ S Tj[1 + kNumParams][12];
   __shared__ S inv_h[kNumParams];
   const int tid = threadIdx.x;
@@ -526,8 +526,10 @@ __device__ __forceinline__ void storeReport(double *p, double v) {
 //               nullptr when every cost's result comes from HBM
 //   state_word  word `threadIdx.x` of the stored state, loaded by the caller ahead of its own work
 //               so that the round trip overlaps it (ignored when `prefetched` is false)
+// (forced inline: as a real call the by-value kernel arguments it takes by reference — 1.2 KB of
+// LmProblem — are first copied to scratch by every lane of the 1024-thread workgroup: 60 us)
 template <typename S, int NMAX>
-__device__ void lmStepBodyFor(const LmProblem &P, bool init, const LmStart<S> &start,
+__device__ __forceinline__ void lmStepBodyFor(const LmProblem &P, bool init, const LmStart<S> &start,
                               const double *own_result, int own_index, bool prefetched,
                               unsigned int state_word) {
 #ifdef MOPT_LM_TIMING
@@ -584,7 +586,16 @@ __device__ void lmStepBodyFor(const LmProblem &P, bool init, const LmStart<S> &s
     finished = 0;
     adopt_sums = 0;
     rematch_next = init ? P.rematch : 0;
-    S x0[NMAX], xi[NMAX], delta[NMAX], bcur[NMAX];
+    // (16-wide problems keep these in LDS: 4 x 16 fp64 values in registers next to the solve would
+    // not fit the 128 VGPRs a 1024-thread workgroup leaves a lane, and scratch costs every launch)
+    constexpr bool kInRegisters = NMAX <= kMaxParams;
+    S x0_r[kInRegisters ? NMAX : 1], xi_r[kInRegisters ? NMAX : 1], delta_r[kInRegisters ? NMAX : 1],
+        bcur_r[kInRegisters ? NMAX : 1];
+    __shared__ S vectors_l[kInRegisters ? 1 : 4 * NMAX];
+    S *const x0 = kInRegisters ? x0_r : vectors_l;
+    S *const xi = kInRegisters ? xi_r : vectors_l + NMAX;
+    S *const delta = kInRegisters ? delta_r : vectors_l + 2 * NMAX;
+    S *const bcur = kInRegisters ? bcur_r : vectors_l + 3 * NMAX;
 #pragma unroll
     for (int i = 0; i < NMAX; ++i) {
       x0[i] = init ? (i < n ? start.x[i] : S(0)) : st.x0[i];
@@ -608,30 +619,36 @@ __device__ void lmStepBodyFor(const LmProblem &P, bool init, const LmStart<S> &s
     // (H + lambda D) delta = -b ; xi = x0 + delta  (levenberg_marquadt_dyn.cpp:78-83)
     auto proposeTrial = [&]() {
       MOPT_TICK(5);
-      switch (n) {
-        case 6:
-          if (!solveDampedPositive<S, 6>(Hcur, bsrc, lambda, delta))
-            solveDampedFixed<S, 6>(Hcur, bsrc, lambda, delta);
-          break;
-        case 4:
-          if (!solveDampedPositive<S, 4>(Hcur, bsrc, lambda, delta))
-            solveDampedFixed<S, 4>(Hcur, bsrc, lambda, delta);
-          break;
-        case 2:
-          if (!solveDampedPositive<S, 2>(Hcur, bsrc, lambda, delta))
-            solveDampedFixed<S, 2>(Hcur, bsrc, lambda, delta);
-          break;
-        default: {
-          S d[NMAX];
-          solveDamped<S, NMAX>(Hcur, bsrc, lambda, n, d, solve_scratch);
-#pragma unroll
-          for (int i = 0; i < NMAX; ++i)
-            if (i < n) delta[i] = d[i];
-          break;
+      bool solved = false;
+      if constexpr (kInRegisters) {  // (the 16-wide instantiation never sees these n)
+        switch (n) {
+          case 6:
+            if (!solveDampedPositive<S, 6>(Hcur, bsrc, lambda, delta))
+              solveDampedFixed<S, 6>(Hcur, bsrc, lambda, delta);
+            solved = true;
+            break;
+          case 4:
+            if (!solveDampedPositive<S, 4>(Hcur, bsrc, lambda, delta))
+              solveDampedFixed<S, 4>(Hcur, bsrc, lambda, delta);
+            solved = true;
+            break;
+          case 2:
+            if (!solveDampedPositive<S, 2>(Hcur, bsrc, lambda, delta))
+              solveDampedFixed<S, 2>(Hcur, bsrc, lambda, delta);
+            solved = true;
+            break;
+          default:
+            break;
         }
       }
+      if (!solved) {
+        solveDamped<S, NMAX>(Hcur, bsrc, lambda, n, solve_scratch);
+#pragma unroll
+        for (int i = 0; i < NMAX; ++i)
+          if (i < n) delta[i] = solve_scratch.delta[i];
+      }
       MOPT_TICK(6);
-      if (P.manifold && n == kNumParams) {
+      if (kInRegisters && P.manifold && n == kNumParams) {
         S plus[kNumParams];
         if (P.manifold == 2)
           se3PlusRight<S>(x0, delta, plus);
@@ -816,7 +833,7 @@ __device__ __forceinline__ unsigned int lmPrefetchState(const LmProblem &P) {
 
 // The step for this problem's parameter count (see LmState).
 template <typename S>
-__device__ void lmStepBody(const LmProblem &P, bool init, const LmStart<S> &start,
+__device__ __forceinline__ void lmStepBody(const LmProblem &P, bool init, const LmStart<S> &start,
                            const double *own_result, int own_index, bool prefetched,
                            unsigned int state_word) {
   if (P.n <= kMaxParams)

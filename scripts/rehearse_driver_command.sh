@@ -10,6 +10,11 @@ NGPU=$(python -c 'import torch; print(torch.cuda.device_count())')
 if [ "$NGPU" -lt "$RANKS" ]; then export MOPT_BENCH_BACKEND=gloo; fi
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 START=$(date +%s)
-python -m torch.distributed.run --nnodes=1 --nproc-per-node "$RANKS" --master-addr 127.0.0.1 \
-  --master-port 29517 bench.py --gpus "$RANKS" --steps 20 --warmup 5
+if [ "$RANKS" -ge 6 ]; then
+  # torch.distributed.run's agent process holds the GPU too: with 6 ranks bench.py starts them itself
+  python bench.py --gpus "$RANKS" --steps 20 --warmup 5
+else
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node "$RANKS" --master-addr 127.0.0.1 \
+    --master-port 29517 bench.py --gpus "$RANKS" --steps 20 --warmup 5
+fi
 echo "wall seconds: $(( $(date +%s) - START ))" >&2
