@@ -921,15 +921,38 @@ int residentFinalizeMerged(mopt_cost *last, int rows, int row_length, mopt::LmCo
   return MOPT_OK;
 }
 
-bool residentSetSupported(mopt_cost *const *costs, int num_costs) {
-  for (int k = 0; k < num_costs; ++k)
-    if (costs[k]->model != kModelReprojection || costs[k]->cov_mode != costs[0]->cov_mode)
+// Can the resident sweeps of these costs (whose rows already lie behind one another: `merged` in
+// lm.cpp) go out as ONE launch?  They must run the same kernel: same model kind, scalar type,
+// Jacobian mode and covariance form — and for run-time compiled models the same source.
+bool residentSetSupported(mopt_cost *const *costs, int num_costs, const int *jac_modes) {
+  if (num_costs < 2) return false;
+  const mopt_cost *first = costs[0];
+  for (int k = 0; k < num_costs; ++k) {
+    const mopt_cost *c = costs[k];
+    if (c->model != first->model || c->cov_mode != first->cov_mode ||
+        c->scalar_bytes != first->scalar_bytes || jac_modes[k] != jac_modes[0] || c->matcher)
       return false;
-  return num_costs > 1;
+    switch (c->model) {
+      case kModelReprojection:
+        break;
+      case kModelPoint2Point:
+        if (usesMoments(c)) return false;  // rows of moments: one finalize per cost anyway
+        break;
+      case kModelScalar:
+        if (c->scalar_model != first->scalar_model) return false;
+        break;
+      case kModelJit:
+        if (c->jit.wide || c->jit.source != first->jit.source) return false;
+        break;
+      default:
+        return false;
+    }
+  }
+  return true;
 }
 
-int residentSweepSet(mopt_cost *const *costs, int num_costs, const int *first_row,
-                     mopt::LmControl *control, hipStream_t s) {
+int residentSweepSet(mopt_cost *const *costs, int num_costs, const int *jac_modes,
+                     const int *first_row, mopt::LmControl *control, hipStream_t s) {
   mopt::ResidentSweepSet set;
   set.num_costs = num_costs;
   size_t bytes = 0;
@@ -942,8 +965,38 @@ int residentSweepSet(mopt_cost *const *costs, int num_costs, const int *first_ro
   mopt::LaunchSite site;
   site.stream = s;
   site.streaming = bytes > (size_t(32) << 20);
-  MOPT_HIP_TRY(mopt::launchReprojResidentSet(set, control, costs[0]->cov_mode, site));
-  return MOPT_OK;
+  mopt_cost *first = costs[0];
+  const int jac_mode = jac_modes[0];
+  switch (first->model) {
+    case kModelReprojection:
+      MOPT_HIP_TRY(mopt::launchReprojResidentSet(set, control, first->cov_mode, site));
+      return MOPT_OK;
+    case kModelPoint2Point:
+      if (first->scalar_bytes == 8)
+        MOPT_HIP_TRY(mopt::launchP2PLiteralResidentSet<double>(set, control, jac_mode,
+                                                               first->cov_mode, site));
+      else
+        MOPT_HIP_TRY(mopt::launchP2PLiteralResidentSet<float>(set, control, jac_mode,
+                                                              first->cov_mode, site));
+      return MOPT_OK;
+    case kModelScalar:
+      if (first->scalar_bytes == 8)
+        MOPT_HIP_TRY(mopt::launchScalarModelResidentSet<double>(set, control, first->scalar_model,
+                                                                jac_mode, first->cov_mode, s));
+      else
+        MOPT_HIP_TRY(mopt::launchScalarModelResidentSet<float>(set, control, first->scalar_model,
+                                                               jac_mode, first->cov_mode, s));
+      return MOPT_OK;
+    case kModelJit: {
+      const mopt::JitVariant *variant =
+          mopt::jitVariant(first->jit, jac_mode == MOPT_JAC_NUMERIC ? 2 : 1, first->cov_mode);
+      if (!variant) return fail(MOPT_ERR_INVALID_ARGUMENT, mopt::jitLastError());
+      MOPT_HIP_TRY(mopt::jitLaunchResidentSet(*variant, set, control, s));
+      return MOPT_OK;
+    }
+    default:
+      return fail(MOPT_ERR_UNSUPPORTED, "no one-launch resident sweep for this model");
+  }
 }
 
 int residentSweep(mopt_cost *c, int jac_mode, mopt::LmControl *control, hipStream_t s,

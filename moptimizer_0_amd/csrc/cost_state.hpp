@@ -239,9 +239,9 @@ int residentFinalizeMerged(mopt_cost *last, int rows, int row_length, mopt::LmCo
 // `step` non-NULL: this is the last cost of the problem, its finalize kernel also runs the LM step
 // the resident sweeps of all costs in one launch, where a kernel for that exists (reprojection
 // costs with one covariance form); first_row[k] = where cost k's partial rows start
-bool residentSetSupported(mopt_cost *const *costs, int num_costs);
-int residentSweepSet(mopt_cost *const *costs, int num_costs, const int *first_row,
-                     mopt::LmControl *control, hipStream_t s);
+bool residentSetSupported(mopt_cost *const *costs, int num_costs, const int *jac_modes);
+int residentSweepSet(mopt_cost *const *costs, int num_costs, const int *jac_modes,
+                     const int *first_row, mopt::LmControl *control, hipStream_t s);
 int residentSweep(mopt_cost *c, int jac_mode, mopt::LmControl *control, hipStream_t s,
                   unsigned long long base_sequence, const mopt::LmProblem *step = nullptr,
                   int own_index = 0, bool finalize = true);

@@ -63,7 +63,8 @@ enum FdRotationHome : int { kFdRotationLds = 0, kFdRotationRegisters = 1 };
 
 template <typename S, bool STREAMING, int COV, int HOME>
 __device__ __forceinline__ void p2pForwardDiffBody(const S *tiles, int num_tiles,
-                                                   const P2PSweepArgs<S> &A) {
+                                                   const P2PSweepArgs<S> &A, int block,
+                                                   int num_blocks) {
   constexpr int V = TileShape<S>::kVec;
   constexpr int NACC = (COV == kCovGeneral) ? kAccFull : kAccSym;
   __shared__ S Rlds[3][12];  // [c][a * 3 + k] = R(x + h_{3+c} e_{3+c})(a, k); 9 of 12 used
@@ -223,19 +224,19 @@ __device__ __forceinline__ void p2pForwardDiffBody(const S *tiles, int num_tiles
           point(robust, in, first + e);
         }
       }
-    });
+    }, block, num_blocks);
   };
   if (A.loss_kind == kLossGemanMcClure)
     sweep(std::true_type());
   else
     sweep(std::false_type());
-  blockReduceStore<NACC>(acc, A.partials + size_t(blockIdx.x) * NACC);
+  blockReduceStore<NACC>(acc, A.partials + size_t(block) * NACC);
 }
 
 template <typename S, bool STREAMING, int COV, int HOME>
 __global__ __launch_bounds__(kBlockThreads) void p2pForwardDiffKernel(const S *tiles, int num_tiles,
                                                                       const P2PSweepArgs<S> A) {
-  p2pForwardDiffBody<S, STREAMING, COV, HOME>(tiles, num_tiles, A);
+  p2pForwardDiffBody<S, STREAMING, COV, HOME>(tiles, num_tiles, A, blockIdx.x, gridDim.x);
 }
 
 template <typename S, bool STREAMING, int COV>
@@ -243,7 +244,21 @@ __global__ __launch_bounds__(kBlockThreads) void p2pForwardDiffResidentArgsKerne
     const P2PSweepArgs<S> *__restrict__ d_args, const LmControl *__restrict__ control) {
   if (control->done) return;
   const P2PSweepArgs<S> A = *d_args;
-  p2pForwardDiffBody<S, STREAMING, COV, kFdRotationLds>(A.tiles, A.num_tiles, A);
+  p2pForwardDiffBody<S, STREAMING, COV, kFdRotationLds>(A.tiles, A.num_tiles, A, blockIdx.x,
+                                                        gridDim.x);
+}
+
+// several forward-difference costs of one problem in one launch (workgroups [first_block[k],
+// first_block[k + 1]) sweep cost k)
+template <typename S, bool STREAMING, int COV>
+__global__ __launch_bounds__(kBlockThreads) void p2pForwardDiffResidentSetKernel(
+    const ResidentSweepSet set, const LmControl *__restrict__ control) {
+  if (control->done) return;
+  const int k = costOfBlock(set);
+  const P2PSweepArgs<S> A = *static_cast<const P2PSweepArgs<S> *>(set.args[k]);
+  p2pForwardDiffBody<S, STREAMING, COV, kFdRotationLds>(
+      A.tiles, A.num_tiles, A, int(blockIdx.x) - set.first_block[k],
+      set.first_block[k + 1] - set.first_block[k]);
 }
 
 }  // namespace
@@ -309,6 +324,37 @@ hipError_t launchForwardDiffResident(const P2PSweepArgs<S> *d_args, const LmCont
 #undef MOPT_LAUNCH_FD_RESIDENT
   return hipGetLastError();
 }
+template <typename S>
+hipError_t launchForwardDiffResidentSet(const ResidentSweepSet &set, const LmControl *control,
+                                        int cov_mode, const LaunchSite &site) {
+  const dim3 g(set.first_block[set.num_costs]), b(kBlockThreads);
+#define MOPT_LAUNCH_FD_SET(COV)                                                                   \
+  if (site.streaming)                                                                             \
+    hipLaunchKernelGGL((p2pForwardDiffResidentSetKernel<S, true, COV>), g, b, 0, site.stream, set, \
+                       control);                                                                  \
+  else                                                                                            \
+    hipLaunchKernelGGL((p2pForwardDiffResidentSetKernel<S, false, COV>), g, b, 0, site.stream,    \
+                       set, control)
+  switch (cov_mode) {
+    case kCovIdentity:
+      MOPT_LAUNCH_FD_SET(kCovIdentity);
+      break;
+    case kCovSymmetric:
+      MOPT_LAUNCH_FD_SET(kCovSymmetric);
+      break;
+    default:
+      MOPT_LAUNCH_FD_SET(kCovGeneral);
+      break;
+  }
+#undef MOPT_LAUNCH_FD_SET
+  return hipGetLastError();
+}
+template hipError_t launchForwardDiffResidentSet<float>(const ResidentSweepSet &, const LmControl *,
+                                                        int, const LaunchSite &);
+template hipError_t launchForwardDiffResidentSet<double>(const ResidentSweepSet &,
+                                                         const LmControl *, int,
+                                                         const LaunchSite &);
+
 template hipError_t launchForwardDiffResident<float>(const P2PSweepArgs<float> *, const LmControl *,
                                                      int, int, const LaunchSite &);
 template hipError_t launchForwardDiffResident<double>(const P2PSweepArgs<double> *,

@@ -121,7 +121,8 @@ struct NoLoss { static constexpr bool value = false; };
 // element would split its basic block and let the compiler sink one element's accumulation below
 // the next element's residual evaluations (then both elements' Jacobians are live at once).
 template <typename Loss>
-__device__ inline void sweep_elements(const JitArgs &A, const S *aux, double (&acc)[NACC]) {
+__device__ inline void sweep_elements(const JitArgs &A, const S *aux, double (&acc)[NACC], int block,
+                                      int num_blocks) {
 #if MODE == 2
   // the quotient (r+ - r) / h_j (linearization.h:105) as a product with 1 / h_j, formed once: M * N
   // fp64 divisions per element were a quarter of the forward-difference sweep's instructions (the
@@ -202,8 +203,8 @@ __device__ inline void sweep_elements(const JitArgs &A, const S *aux, double (&a
 #endif
   };
 
-  const long long step = (long long)gridDim.x * kBlock * VEC;
-  long long i = ((long long)blockIdx.x * kBlock + threadIdx.x) * VEC;
+  const long long step = (long long)num_blocks * kBlock * VEC;
+  long long i = ((long long)block * kBlock + threadIdx.x) * VEC;
   Pack cur[D > 0 ? D : 1], nxt[D > 0 ? D : 1];
   if (i < A.count) {
 #pragma unroll
@@ -253,7 +254,9 @@ __device__ inline void sweep_elements(const JitArgs &A, const S *aux, double (&a
   }
 }
 
-__device__ inline void sweep_body(const JitArgs &A) {
+// block / num_blocks: this workgroup's place among those sweeping this cost (the whole grid, or its
+// share of a launch that carries several costs)
+__device__ inline void sweep_body(const JitArgs &A, int block, int num_blocks) {
   // IBaseModel::setup (model.h:19-22): once per parameter vector, here once per workgroup and
   // parameter vector - x itself and, for forward differences, x + h_j e_j (the reference sets
   // up one clone of the model per perturbed vector, linearization.h:91-95).
@@ -272,13 +275,15 @@ __device__ inline void sweep_body(const JitArgs &A) {
 #pragma unroll
   for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
   if (MODE != 0 && A.loss_kind == 1)
-    sweep_elements<RobustLoss>(A, aux, acc);
+    sweep_elements<RobustLoss>(A, aux, acc, block, num_blocks);
   else
-    sweep_elements<NoLoss>(A, aux, acc);
-  block_reduce_store(acc, A.partials + (size_t)blockIdx.x * NACC);
+    sweep_elements<NoLoss>(A, aux, acc, block, num_blocks);
+  block_reduce_store(acc, A.partials + (size_t)block * NACC);
 }
 
-extern "C" __global__ __launch_bounds__(kBlock) void mopt_jit_sweep(const JitArgs A) { sweep_body(A); }
+extern "C" __global__ __launch_bounds__(kBlock) void mopt_jit_sweep(const JitArgs A) {
+  sweep_body(A, blockIdx.x, gridDim.x);
+}
 
 // Resident form for the device-resident LM (mopt_lm_minimize): the argument block — x and the
 // forward-difference steps in it rewritten by the LM step kernel for every trial point — is read
@@ -290,7 +295,23 @@ extern "C" __global__ __launch_bounds__(kBlock) void mopt_jit_sweep_resident(
     const JitArgs *__restrict__ d_args, const LmControl *__restrict__ control) {
   if (control->done) return;
   const JitArgs A = *d_args;
-  sweep_body(A);
+  sweep_body(A, blockIdx.x, gridDim.x);
+}
+
+// Several costs over this same model (same source, same shape) in one launch: workgroups
+// [first_block[k], first_block[k + 1]) sweep cost k (sweep.hpp ResidentSweepSet).
+struct ResidentSweepSet {
+  const void *args[4];
+  int first_block[5];
+  int num_costs;
+};
+extern "C" __global__ __launch_bounds__(kBlock) void mopt_jit_sweep_resident_set(
+    const ResidentSweepSet set, const LmControl *__restrict__ control) {
+  if (control->done) return;
+  int k = 0;
+  while (k + 1 < set.num_costs && (int)blockIdx.x >= set.first_block[k + 1]) ++k;
+  const JitArgs A = *(const JitArgs *)set.args[k];
+  sweep_body(A, (int)blockIdx.x - set.first_block[k], set.first_block[k + 1] - set.first_block[k]);
 }
 )JIT";
 
@@ -525,6 +546,12 @@ bool compileVariant(JitKernel &k, int mode, int cov_mode, JitVariant &out) {
     out.sweep = out.sweep_resident = nullptr;
     return false;
   }
+  // (the narrow sweep only; absent from the wide module)
+  if (hipModuleGetFunction(&out.sweep_resident_set, out.module, "mopt_jit_sweep_resident_set") !=
+      hipSuccess) {
+    (void)hipGetLastError();
+    out.sweep_resident_set = nullptr;
+  }
   return true;
 }
 
@@ -579,7 +606,7 @@ void jitRelease(JitKernel &k) {
   for (auto &v : k.variants) {
     if (v.module) (void)hipModuleUnload(v.module);
     v.module = nullptr;
-    v.sweep = v.sweep_resident = nullptr;
+    v.sweep = v.sweep_resident = v.sweep_resident_set = nullptr;
   }
 }
 
@@ -603,6 +630,21 @@ hipError_t jitLaunchResident(const JitVariant &v, const void *d_args, const LmCo
                     HIP_LAUNCH_PARAM_END};
   return hipModuleLaunchKernel(v.sweep_resident, unsigned(grid), 1, 1, kBlockThreads, 1, 1, 0, stream,
                                nullptr, config);
+}
+
+hipError_t jitLaunchResidentSet(const JitVariant &v, const ResidentSweepSet &set,
+                                const LmControl *control, hipStream_t stream) {
+  if (!v.sweep_resident_set) return hipErrorInvalidValue;
+  static_assert(kLmMaxCosts == 4, "the run-time compiled source declares ResidentSweepSet for 4 costs");
+  struct {
+    ResidentSweepSet set;
+    const LmControl *control;
+  } params = {set, control};
+  size_t size = sizeof params;
+  void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &params, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size,
+                    HIP_LAUNCH_PARAM_END};
+  return hipModuleLaunchKernel(v.sweep_resident_set, unsigned(set.first_block[set.num_costs]), 1, 1,
+                               kBlockThreads, 1, 1, 0, stream, nullptr, config);
 }
 
 }  // namespace mopt

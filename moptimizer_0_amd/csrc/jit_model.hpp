@@ -13,6 +13,7 @@ struct JitVariant {
   hipModule_t module = nullptr;
   hipFunction_t sweep = nullptr;
   hipFunction_t sweep_resident = nullptr;  // arguments from HBM, early exit (device-resident LM)
+  hipFunction_t sweep_resident_set = nullptr;  // several costs over this model in one launch
 };
 
 // One user model: its assembled source and the sweeps compiled from it so far.
@@ -70,6 +71,9 @@ hipError_t jitLaunch(const JitVariant &v, const void *args, size_t args_bytes, i
 // the resident entry point of the same module: (const JitArgs *d_args, const LmControl *control)
 hipError_t jitLaunchResident(const JitVariant &v, const void *d_args, const LmControl *control,
                              int grid, hipStream_t stream);
+// several costs created from the same source (same shape): one launch of the first one's module
+hipError_t jitLaunchResidentSet(const JitVariant &v, const ResidentSweepSet &set,
+                                const LmControl *control, hipStream_t stream);
 const char *jitLastError();
 
 }  // namespace mopt

@@ -134,7 +134,12 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
   }
   merged = merged && row_offset[num_costs] <= last->max_grid;
   problem.merged = merged ? 1 : 0;
-  const bool one_launch = merged && residentSetSupported(costs, num_costs);
+  static const bool set_enabled = [] {  // MOPT_LM_SET=0: a sweep launch per cost (for comparison)
+    const char *v = std::getenv("MOPT_LM_SET");
+    return !(v && v[0] == '0');
+  }();
+  const bool one_launch =
+      set_enabled && merged && residentSetSupported(costs, num_costs, jacobian_modes);
   for (int k = 0; k < num_costs; ++k) {
     rc = residentPrepare(costs[k], jacobian_modes[k], s, &problem.cost[k],
                          merged ? last->d_partials + size_t(row_offset[k]) * row_length : nullptr);
@@ -189,7 +194,7 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
     while (enqueued < max_points && enqueued - completed < window) {
       // per point: every cost's sweep + finalize; the last finalize also takes the LM step
       if (one_launch) {
-        rc = residentSweepSet(costs, num_costs, row_offset, problem.control, s);
+        rc = residentSweepSet(costs, num_costs, jacobian_modes, row_offset, problem.control, s);
         if (rc != MOPT_OK) return rc;
       }
       for (int k = 0; k < num_costs && !one_launch; ++k) {

@@ -258,6 +258,17 @@ struct ResidentSweepSet {
 };
 hipError_t launchReprojResidentSet(const ResidentSweepSet &set, const LmControl *control,
                                    int cov_mode, const LaunchSite &site);
+// the same for point2point costs evaluated literally (all in one Jacobian mode and covariance form)
+// and for the built-in scalar models (all of one kind, mode and covariance form)
+template <typename S>
+hipError_t launchP2PLiteralResidentSet(const ResidentSweepSet &set, const LmControl *control,
+                                       int jac_mode, int cov_mode, const LaunchSite &site);
+template <typename S>
+hipError_t launchForwardDiffResidentSet(const ResidentSweepSet &set, const LmControl *control,
+                                        int cov_mode, const LaunchSite &site);
+template <typename S>
+hipError_t launchScalarModelResidentSet(const ResidentSweepSet &set, const LmControl *control,
+                                        int model, int jac_mode, int cov_mode, hipStream_t stream);
 hipError_t launchReprojResident(const ReprojSweepArgs *d_args, const LmControl *control,
                                 int cov_mode, int grid, const LaunchSite &site);
 template <typename S>

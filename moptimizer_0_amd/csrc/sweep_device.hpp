@@ -76,12 +76,15 @@ __device__ __forceinline__ bool isCorrespondence(long long index, long long coun
 //    (vmcnt(0) again), because on the not-taken path the needed loads are the youngest.  So the
 //    prefetch is unconditional and, past the end, re-reads this workgroup's last tile (an L2 hit).
 // body(packs, first): packs[plane].v[e] is coordinate `plane` of correspondence first + e.
+// block / num_blocks: this workgroup's place among those sweeping this cost (a launch may carry the
+// workgroups of several costs: the *ResidentSetKernel forms); by default the whole grid.
 template <typename S, bool STREAMING, typename Body>
-__device__ __forceinline__ void sweepTiles(const S *tiles, int num_tiles, Body &&body) {
+__device__ __forceinline__ void sweepTiles(const S *tiles, int num_tiles, Body &&body, int block,
+                                           int num_blocks) {
   constexpr int V = TileShape<S>::kVec;
   constexpr int TP = TileShape<S>::kPoints;
-  const int stride = gridDim.x;
-  const int first_tile = blockIdx.x;
+  const int stride = num_blocks;
+  const int first_tile = block;
   if (first_tile >= num_tiles) return;
   const int mine = (num_tiles - first_tile + stride - 1) / stride;  // tiles of this workgroup
   const S *lane_base = tiles + threadIdx.x * V;
@@ -101,6 +104,11 @@ __device__ __forceinline__ void sweepTiles(const S *tiles, int num_tiles, Body &
     load(a, tileOf(i + 2));
     body(b, (long long)tileOf(i + 1) * TP + threadIdx.x * V);
   }
+}
+template <typename S, bool STREAMING, typename Body>
+__device__ __forceinline__ void sweepTiles(const S *tiles, int num_tiles, Body &&body) {
+  sweepTiles<S, STREAMING>(tiles, num_tiles, static_cast<Body &&>(body), int(blockIdx.x),
+                           int(gridDim.x));
 }
 
 __device__ __forceinline__ double waveSum(double v) {
@@ -156,6 +164,14 @@ __device__ __forceinline__ void blockReduceStore(double (&acc)[NACC], double *ou
   }
 }
 
+
+// Which cost of a ResidentSweepSet this workgroup sweeps: workgroups [first_block[k],
+// first_block[k + 1]) take cost k.
+__device__ __forceinline__ int costOfBlock(const ResidentSweepSet &set) {
+  int k = 0;
+  while (k + 1 < set.num_costs && int(blockIdx.x) >= set.first_block[k + 1]) ++k;
+  return k;
+}
 
 // moments / cost / forward-difference sweeps: (tiles, num_tiles, args) signature (the leading scalar
 // arguments are preloaded into SGPRs at wave launch); optionally a timestamped dispatch

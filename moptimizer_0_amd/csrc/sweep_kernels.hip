@@ -150,7 +150,8 @@ __device__ __forceinline__ void p2pPointLiteral(
 }
 
 template <typename S, int JAC, int COV>
-__device__ __forceinline__ void p2pLinearizeLiteralBody(const P2PSweepArgs<S> &A) {
+__device__ __forceinline__ void p2pLinearizeLiteralBody(const P2PSweepArgs<S> &A, int block,
+                                                        int num_blocks) {
   constexpr int NACC = (COV == kCovGeneral) ? kAccFull : kAccSym;
   constexpr int V = TileShape<S>::kVec;
   double acc[NACC];
@@ -165,14 +166,14 @@ __device__ __forceinline__ void p2pLinearizeLiteralBody(const P2PSweepArgs<S> &A
       const S q[3] = {ok ? cur[3].v[e] : S(0), ok ? cur[4].v[e] : S(0), ok ? cur[5].v[e] : S(0)};
       p2pPointLiteral<S, JAC, COV>(A, p, q, ok, acc);
     }
-  });
-  blockReduceStore<NACC>(acc, A.partials + size_t(blockIdx.x) * NACC);
+  }, block, num_blocks);
+  blockReduceStore<NACC>(acc, A.partials + size_t(block) * NACC);
 }
 
 template <typename S, int JAC, int COV>
 __global__ __launch_bounds__(kBlockThreads) void p2pLinearizeLiteralKernel(
     const P2PSweepArgs<S> A) {
-  p2pLinearizeLiteralBody<S, JAC, COV>(A);
+  p2pLinearizeLiteralBody<S, JAC, COV>(A, blockIdx.x, gridDim.x);
 }
 
 // Resident form (device-resident LM, sweep.hpp): the per-x constants come from HBM, where the
@@ -183,7 +184,20 @@ __global__ __launch_bounds__(kBlockThreads) void p2pLinearizeLiteralResidentKern
     const P2PSweepArgs<S> *__restrict__ d_args, const LmControl *__restrict__ control) {
   if (control->done) return;
   const P2PSweepArgs<S> A = *d_args;
-  p2pLinearizeLiteralBody<S, JAC, COV>(A);
+  p2pLinearizeLiteralBody<S, JAC, COV>(A, blockIdx.x, gridDim.x);
+}
+
+// The sweeps of several literally evaluated point2point costs of one problem in one launch (as
+// reprojResidentSetKernel below): the loop of levenberg_marquadt_dyn.cpp:48-60 pays one launch per
+// evaluated point, not one per cost.
+template <typename S, int JAC, int COV>
+__global__ __launch_bounds__(kBlockThreads) void p2pLinearizeLiteralResidentSetKernel(
+    const ResidentSweepSet set, const LmControl *__restrict__ control) {
+  if (control->done) return;
+  const int k = costOfBlock(set);
+  const P2PSweepArgs<S> A = *static_cast<const P2PSweepArgs<S> *>(set.args[k]);
+  p2pLinearizeLiteralBody<S, JAC, COV>(A, int(blockIdx.x) - set.first_block[k],
+                                       set.first_block[k + 1] - set.first_block[k]);
 }
 
 // ---- point-to-point, weighted moments --------------------------------------------------------
@@ -384,8 +398,7 @@ template <int COV>
 __global__ __launch_bounds__(kBlockThreads) void reprojResidentSetKernel(
     const ResidentSweepSet set, const LmControl *__restrict__ control) {
   if (control->done) return;
-  int k = 0;
-  while (k + 1 < set.num_costs && int(blockIdx.x) >= set.first_block[k + 1]) ++k;
+  const int k = costOfBlock(set);
   const ReprojSweepArgs A = *static_cast<const ReprojSweepArgs *>(set.args[k]);
   reprojBody<COV, false>(A, int(blockIdx.x) - set.first_block[k],
                          set.first_block[k + 1] - set.first_block[k]);
@@ -447,7 +460,8 @@ struct Powell {
 };
 
 template <typename S, template <typename> class ModelT, int JAC, int COV, bool COST_ONLY>
-__device__ __forceinline__ void scalarModelBody(const ScalarSweepArgs<S> &A) {
+__device__ __forceinline__ void scalarModelBody(const ScalarSweepArgs<S> &A, int block,
+                                                int num_blocks) {
   using Model = ModelT<S>;
   constexpr int N = Model::N, M = Model::M, D = Model::D;
   constexpr int NACC =
@@ -460,8 +474,8 @@ __device__ __forceinline__ void scalarModelBody(const ScalarSweepArgs<S> &A) {
   S inv_h[N];
 #pragma unroll
   for (int j = 0; j < N; ++j) inv_h[j] = S(1) / A.h[j];
-  for (long long i = (long long)blockIdx.x * kBlockThreads + threadIdx.x; i < A.count;
-       i += (long long)gridDim.x * kBlockThreads) {
+  for (long long i = (long long)block * kBlockThreads + threadIdx.x; i < A.count;
+       i += (long long)num_blocks * kBlockThreads) {
     S d[D > 0 ? D : 1];
 #pragma unroll
     for (int p = 0; p < D; ++p) d[p] = A.data[p * A.stride + i];
@@ -493,12 +507,12 @@ __device__ __forceinline__ void scalarModelBody(const ScalarSweepArgs<S> &A) {
       accumulateDense<S, M, N, COV>(J, r, w, rr, A.cov, acc);
     }
   }
-  blockReduceStore<NACC>(acc, A.partials + size_t(blockIdx.x) * NACC);
+  blockReduceStore<NACC>(acc, A.partials + size_t(block) * NACC);
 }
 
 template <typename S, template <typename> class ModelT, int JAC, int COV, bool COST_ONLY>
 __global__ __launch_bounds__(kBlockThreads) void scalarModelKernel(const ScalarSweepArgs<S> A) {
-  scalarModelBody<S, ModelT, JAC, COV, COST_ONLY>(A);
+  scalarModelBody<S, ModelT, JAC, COV, COST_ONLY>(A, blockIdx.x, gridDim.x);
 }
 
 template <typename S, template <typename> class ModelT, int JAC, int COV>
@@ -506,7 +520,19 @@ __global__ __launch_bounds__(kBlockThreads) void scalarModelResidentKernel(
     const ScalarSweepArgs<S> *__restrict__ d_args, const LmControl *__restrict__ control) {
   if (control->done) return;
   const ScalarSweepArgs<S> A = *d_args;
-  scalarModelBody<S, ModelT, JAC, COV, false>(A);
+  scalarModelBody<S, ModelT, JAC, COV, false>(A, blockIdx.x, gridDim.x);
+}
+
+// several costs over the same built-in model in one launch (tst/multiple_objectives.cpp:102-132
+// splits the curve fit's 67 observations over two costs)
+template <typename S, template <typename> class ModelT, int JAC, int COV>
+__global__ __launch_bounds__(kBlockThreads) void scalarModelResidentSetKernel(
+    const ResidentSweepSet set, const LmControl *__restrict__ control) {
+  if (control->done) return;
+  const int k = costOfBlock(set);
+  const ScalarSweepArgs<S> A = *static_cast<const ScalarSweepArgs<S> *>(set.args[k]);
+  scalarModelBody<S, ModelT, JAC, COV, false>(A, int(blockIdx.x) - set.first_block[k],
+                                              set.first_block[k + 1] - set.first_block[k]);
 }
 
 // ---- correspondence search (ICP update step) ---------------------------------------------------
@@ -1351,6 +1377,52 @@ template hipError_t launchP2PLiteralResident<double>(const P2PSweepArgs<double> 
                                                      const LmControl *, int, int, int,
                                                      const LaunchSite &);
 
+namespace {
+template <typename S, int JAC>
+hipError_t launchLiteralResidentSetCov(const ResidentSweepSet &set, const LmControl *control,
+                                       int cov_mode, const LaunchSite &site) {
+  const dim3 g(set.first_block[set.num_costs]), b(kBlockThreads);
+  switch (cov_mode) {
+    case kCovIdentity:
+      hipLaunchKernelGGL((p2pLinearizeLiteralResidentSetKernel<S, JAC, kCovIdentity>), g, b, 0,
+                         site.stream, set, control);
+      break;
+    case kCovSymmetric:
+      hipLaunchKernelGGL((p2pLinearizeLiteralResidentSetKernel<S, JAC, kCovSymmetric>), g, b, 0,
+                         site.stream, set, control);
+      break;
+    default:
+      hipLaunchKernelGGL((p2pLinearizeLiteralResidentSetKernel<S, JAC, kCovGeneral>), g, b, 0,
+                         site.stream, set, control);
+      break;
+  }
+  return hipGetLastError();
+}
+}  // namespace
+
+template <typename S>
+hipError_t launchP2PLiteralResidentSet(const ResidentSweepSet &set, const LmControl *control,
+                                       int jac_mode, int cov_mode, const LaunchSite &site) {
+  switch (jac_mode) {
+    case kJacAnalytic:
+      return launchLiteralResidentSetCov<S, kJacAnalytic>(set, control, cov_mode, site);
+    case kJacAnalyticTst:
+      return launchLiteralResidentSetCov<S, kJacAnalyticTst>(set, control, cov_mode, site);
+    case kJacNumeric:
+      return launchForwardDiffResidentSet<S>(set, control, cov_mode, site);
+    case kJacAnalyticLeft:
+      return launchLiteralResidentSetCov<S, kJacAnalyticLeft>(set, control, cov_mode, site);
+    case kJacAnalyticRight:
+      return launchLiteralResidentSetCov<S, kJacAnalyticRight>(set, control, cov_mode, site);
+    default:
+      return hipErrorInvalidValue;
+  }
+}
+template hipError_t launchP2PLiteralResidentSet<float>(const ResidentSweepSet &, const LmControl *,
+                                                       int, int, const LaunchSite &);
+template hipError_t launchP2PLiteralResidentSet<double>(const ResidentSweepSet &, const LmControl *,
+                                                        int, int, const LaunchSite &);
+
 hipError_t launchReprojResident(const ReprojSweepArgs *d_args, const LmControl *control,
                                 int cov_mode, int grid, const LaunchSite &site) {
   const dim3 g(grid), b(kBlockThreads);
@@ -1412,6 +1484,53 @@ hipError_t launchScalarResidentFor(const ScalarSweepArgs<S> *d_args, const LmCon
   return hipGetLastError();
 }
 }  // namespace
+
+namespace {
+template <typename S, template <typename> class ModelT>
+hipError_t launchScalarResidentSetFor(const ResidentSweepSet &set, const LmControl *control,
+                                      int jac_mode, int cov_mode, hipStream_t stream) {
+  const dim3 g(set.first_block[set.num_costs]), b(kBlockThreads);
+  const bool numeric = (jac_mode == kJacNumeric);
+#define MOPT_LAUNCH_SCALAR_SET(JAC, COV)                                                          \
+  hipLaunchKernelGGL((scalarModelResidentSetKernel<S, ModelT, JAC, COV>), g, b, 0, stream, set, \
+                     control)
+  switch (cov_mode) {
+    case kCovIdentity:
+      if (numeric) MOPT_LAUNCH_SCALAR_SET(kJacNumeric, kCovIdentity);
+      else MOPT_LAUNCH_SCALAR_SET(kJacAnalytic, kCovIdentity);
+      break;
+    case kCovSymmetric:
+      if (numeric) MOPT_LAUNCH_SCALAR_SET(kJacNumeric, kCovSymmetric);
+      else MOPT_LAUNCH_SCALAR_SET(kJacAnalytic, kCovSymmetric);
+      break;
+    default:
+      if (numeric) MOPT_LAUNCH_SCALAR_SET(kJacNumeric, kCovGeneral);
+      else MOPT_LAUNCH_SCALAR_SET(kJacAnalytic, kCovGeneral);
+      break;
+  }
+#undef MOPT_LAUNCH_SCALAR_SET
+  return hipGetLastError();
+}
+}  // namespace
+
+template <typename S>
+hipError_t launchScalarModelResidentSet(const ResidentSweepSet &set, const LmControl *control,
+                                        int model, int jac_mode, int cov_mode, hipStream_t stream) {
+  switch (model) {
+    case kScalarExpCurve:
+      return launchScalarResidentSetFor<S, ExpCurve>(set, control, jac_mode, cov_mode, stream);
+    case kScalarRational:
+      return launchScalarResidentSetFor<S, Rational>(set, control, jac_mode, cov_mode, stream);
+    case kScalarPowell:
+      return launchScalarResidentSetFor<S, Powell>(set, control, jac_mode, cov_mode, stream);
+    default:
+      return hipErrorInvalidValue;
+  }
+}
+template hipError_t launchScalarModelResidentSet<float>(const ResidentSweepSet &, const LmControl *,
+                                                        int, int, int, hipStream_t);
+template hipError_t launchScalarModelResidentSet<double>(const ResidentSweepSet &, const LmControl *,
+                                                         int, int, int, hipStream_t);
 
 template <typename S>
 hipError_t launchScalarModelResident(const ScalarSweepArgs<S> *d_args, const LmControl *control,

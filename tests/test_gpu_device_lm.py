@@ -431,5 +431,38 @@ def test_several_costs_in_every_combination_of_sweep_kinds(hip_lib):
     assert rep0["status"] == sh0 and np.abs(x0 - xh0).max() < 1e-9
     H2, b2, y2 = halves[0].linearize(xw, mo.JAC_ANALYTIC)
     assert np.array_equal(H, H2) and np.array_equal(b, b2) and y0 == y2
+
+    # (d) round 3: costs of one kind, mode and covariance form are also SWEPT by one launch — literal
+    #     point2point (analytic and forward differences, with a covariance), the built-in scalar
+    #     models of (b), and run-time compiled models created from the same source
+    cov = np.array([[2.0, 0.3, -0.1], [0.3, 0.5, 0.2], [-0.1, 0.2, 1.5]])
     for c in halves + [whole]:
+        c.set_kernel_variant(mo.KERNEL_LITERAL)
+        c.set_covariance(cov)
+    for jac in (mo.JAC_NUMERIC, mo.JAC_ANALYTIC_RIGHT):
+        manifold = "right" if jac == mo.JAC_ANALYTIC_RIGHT else False
+        xw2, repw2 = mo.capi.lm_minimize([whole], [jac], np.zeros(6), manifold=manifold)
+        x, rep = mo.capi.lm_minimize(halves, [jac] * 2, np.zeros(6), manifold=manifold)
+        # (two halves summed and the whole differ in the last bits of every sum: the pose is the
+        # same, the iteration at which the noise-level stop fires need not be)
+        assert rep["status"] in (CONVERGED, SMALL_DELTA, MAX_ITERATIONS), rep
+        assert np.abs(x - xw2).max() < 1e-7, (jac, x, xw2, rep, repw2)
+    # a pair in different modes shares the finalize but not the launch: still the same answer
+    x, rep = mo.capi.lm_minimize(halves, [mo.JAC_ANALYTIC, mo.JAC_NUMERIC], np.zeros(6))
+    xh, sh, ih = host_lm_sum(halves, [mo.JAC_ANALYTIC, mo.JAC_NUMERIC], np.zeros(6))
+    assert rep["status"] == sh and np.abs(x - xh).max() < 1e-7, (x, xh)
+    for c in halves + [whole]:
+        c.close()
+    body = "r[0] = d[1] - exp(x[0] * d[0] + x[1]);"
+    jac_body = "const S e = exp(x[0] * d[0] + x[1]); J[0] = -d[0] * e; J[1] = -e;"
+    parts = [mo.JitModelCost(2, 1, body, jac_body, planes=np.stack([t[a:b], y[a:b]]))
+             for a, b in ((0, 1500), (1500, 2600), (2600, 4000))]
+    one = mo.JitModelCost(2, 1, body, jac_body, planes=np.stack([t, y]))
+    for jac in (mo.JAC_ANALYTIC, mo.JAC_NUMERIC):
+        xo, repo = mo.capi.lm_minimize([one], [jac], np.zeros(2), max_iterations=50)
+        x, rep = mo.capi.lm_minimize(parts, [jac] * 3, np.zeros(2), max_iterations=50)
+        assert rep["status"] == repo["status"], (rep, repo)
+        assert np.abs(x - xo).max() < 1e-8, (jac, x, xo)
+        assert np.abs(x - np.array([0.3, 0.1])).max() < 1e-2
+    for c in parts + [one]:
         c.close()
