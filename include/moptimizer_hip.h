@@ -256,24 +256,6 @@ MOPT_API int mopt_cost_compute(mopt_cost *cost, const void *x, void *sum_sq);
  * speculating only while it pays: once more kept results have gone unused than used,
  * mopt_cost_compute goes back to the cost-only sweep. */
 MOPT_API int mopt_cost_set_speculation(mopt_cost *cost, int enabled);
-
-/* Pre-queued sweeps (off by default; point2point costs).  A blocking call spends 10 us between its
- * first launch call and the last workgroup of the sweep running — launch calls, and the dispatch of
- * a grid over 256 CUs — before any byte is read; a grid that is already resident and released by a
- * word the host stores gets there in 6.6 us (scripts/probes/gate_probe.cpp).  With this switch on,
- * every blocking mopt_cost_linearize (and mopt_cost_compute under speculation) that runs the moments
- * kernels queues, while its own sweep runs, the sweep + finalize of the NEXT call on a stream of the
- * cost's own: they wait — one workgroup polling a line of mapped host memory, the others a line of
- * device memory it relays to — until that call stores [R | t] at its x and the affine basis, and
- * publish its result like any other sweep.  Same kernels on the same inputs: the numbers are those
- * of the ordinary call bit for bit.  What it costs: between calls the waiting grid holds one workgroup
- * slot per CU.  Every wait is bounded: a pair that is not armed within 50 ms ends by itself; one whose
- * cost changed state (loss, covariance, data, kernel variant), was asked something else, or is older
- * than 20 ms when the next call arrives is abandoned (its kernels end at once, nothing is published)
- * and that call launches as usual.  ICP costs, linked costs, sharded costs and profiled sweeps are
- * never pre-queued. */
-MOPT_API int mopt_cost_set_prequeue(mopt_cost *cost, int enabled);
-MOPT_API int mopt_cost_prequeue_stats(const mopt_cost *cost, int64_t *armed, int64_t *abandoned);
 /* sweeps launched and calls answered from the kept result since creation */
 MOPT_API int mopt_cost_stats(const mopt_cost *cost, int64_t *sweeps, int64_t *cache_hits);
 

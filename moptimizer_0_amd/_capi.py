@@ -101,9 +101,6 @@ def load():
         "mopt_cost_stream": [ctypes.c_void_p, c_void_pp],
         "mopt_cost_synchronize": [ctypes.c_void_p],
         "mopt_cost_set_speculation": [ctypes.c_void_p, ctypes.c_int],
-        "mopt_cost_set_prequeue": [ctypes.c_void_p, ctypes.c_int],
-        "mopt_cost_prequeue_stats": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64),
-                                     ctypes.POINTER(ctypes.c_int64)],
         "mopt_costs_link": [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int],
         "mopt_cost_link_stats": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)],
         "mopt_cost_stats": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64),
@@ -265,15 +262,6 @@ class _CostBase:
 
     def set_speculation(self, enabled):
         check(load().mopt_cost_set_speculation(self._h, 1 if enabled else 0))
-
-    def set_prequeue(self, enabled):
-        """mopt_cost_set_prequeue: the next blocking linearization's kernels queued ahead of its x."""
-        check(load().mopt_cost_set_prequeue(self._h, 1 if enabled else 0))
-
-    def prequeue_stats(self):
-        armed, abandoned = ctypes.c_int64(0), ctypes.c_int64(0)
-        check(load().mopt_cost_prequeue_stats(self._h, ctypes.byref(armed), ctypes.byref(abandoned)))
-        return armed.value, abandoned.value
 
     def answered_ahead(self):
         """blocking calls answered by a sweep a linked cost had queued (mopt_costs_link)"""

@@ -577,13 +577,12 @@ namespace {
 // stores the results into mapped host memory and then releases `sequence` into the flag word;
 // the host polls that word.  The stream is queried now and then so that a faulted kernel turns
 // into an error instead of an endless wait.
-int waitPublished(mopt_cost *c, unsigned long long sequence, hipStream_t on = nullptr) {
+int waitPublished(mopt_cost *c, unsigned long long sequence) {
   unsigned long long spins = 0;
   const auto started = std::chrono::steady_clock::now();
-  const hipStream_t stream = on ? on : c->stream;
   while (__atomic_load_n(c->h_flag, __ATOMIC_ACQUIRE) != sequence) {
     if ((++spins & 0x3fff) == 0) {
-      const hipError_t q = hipStreamQuery(stream);
+      const hipError_t q = hipStreamQuery(c->stream);
       if (q == hipSuccess) {
         if (__atomic_load_n(c->h_flag, __ATOMIC_ACQUIRE) == sequence) break;
         return fail(MOPT_ERR_HIP, "stream drained without publishing a result");
@@ -651,136 +650,6 @@ mopt::PeerCombine nextPeerCombine(mopt_cost *c, int offset) {
   return pc;
 }
 
-// ---- pre-queued pair (mopt_cost_set_prequeue) --------------------------------------------------
-constexpr long long kGateDeviceTimeoutUs = 50000;  // the kernels give up after this long un-armed
-constexpr long long kGateHostBoundUs = 20000;      // the host never arms a pair older than this
-
-long long steadyMicros() {
-  return std::chrono::duration_cast<std::chrono::microseconds>(
-             std::chrono::steady_clock::now().time_since_epoch())
-      .count();
-}
-
-void gateStore(mopt::GateLine *gate, unsigned long long word) {
-  // payload (if any) is already written; word_tail, then word: see GateLine
-  __atomic_store_n(&gate->word_tail, word, __ATOMIC_RELEASE);
-  __atomic_store_n(&gate->word, word, __ATOMIC_RELEASE);
-}
-
-int prequeueEnsure(mopt_cost *c) {
-  auto &q = c->prequeue;
-  if (q.gate) return MOPT_OK;
-  MOPT_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&q.gate), sizeof(mopt::GateLine),
-                             hipHostMallocMapped | hipHostMallocCoherent));
-  std::memset(q.gate, 0, sizeof(mopt::GateLine));
-  MOPT_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&q.gate_dev), q.gate, 0));
-  void *relay = nullptr;
-  hipError_t e = hipExtMallocWithFlags(&relay, sizeof(mopt::GateLine), hipDeviceMallocUncached);
-  if (e != hipSuccess) {
-    (void)hipGetLastError();
-    e = hipExtMallocWithFlags(&relay, sizeof(mopt::GateLine), hipDeviceMallocFinegrained);
-  }
-  if (e != hipSuccess) return fail(MOPT_ERR_HIP, std::string("gate relay: ") + hipGetErrorString(e));
-  q.relay = static_cast<mopt::GateLine *>(relay);
-  MOPT_HIP_TRY(hipMemset(relay, 0, sizeof(mopt::GateLine)));
-  MOPT_HIP_TRY(hipDeviceSynchronize());
-  MOPT_HIP_TRY(acquireStream(c->device, &q.stream));
-  return MOPT_OK;
-}
-
-// Which sweeps a pre-queued pair can stand in for: the blocking linearization of a point2point cost
-// through the moments kernels, nothing attached to it that changes what is launched.
-template <typename S>
-bool prequeueEligible(const mopt_cost *c, bool cost_only, int jac_mode, const S *x) {
-  if (!c->prequeue.enabled || cost_only || c->model != kModelPoint2Point || c->matcher ||
-      c->profiling > 0 || c->launch_peers || !c->siblings.empty())
-    return false;
-  switch (c->variant) {
-    case MOPT_KERNEL_LITERAL: return false;
-    case MOPT_KERNEL_MOMENTS_ALWAYS: return true;
-    default: return !(jac_mode == MOPT_JAC_NUMERIC && hasSmallForwardStep<S>(x));
-  }
-}
-
-// Queue the pair for the NEXT call: everything but x is known now.
-template <typename S>
-int prequeueLaunch(mopt_cost *c) {
-  auto &q = c->prequeue;
-  int rc = prequeueEnsure(c);
-  if (rc != MOPT_OK) return rc;
-  mopt::P2PSweepArgs<S> args;
-  const S zero[kNumParams] = {0, 0, 0, 0, 0, 0};
-  fillP2PArgs<S>(c, zero, false, args);
-  const int grid = gridFor(c, blocksPerCu(1));
-  const size_t bytes = size_t(c->count) * 6 * size_t(c->scalar_bytes);
-  static const int force = envInt("MOPT_STREAMING_LOADS", 0);
-  const bool streaming = force == 2 || (force != 1 && bytes > (size_t(32) << 20));
-  int khz = 0;
-  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) != hipSuccess || khz <= 0)
-    khz = 100000;
-  const unsigned long long ticks = (unsigned long long)khz * (unsigned long long)kGateDeviceTimeoutUs / 1000ull;
-  const unsigned long long pair = ++q.pair;
-  const mopt::HostPublish pub = nextPublish(c, 0);
-  MOPT_HIP_TRY(mopt::launchP2PMomentsGated<S>(args, grid, streaming, q.gate_dev, q.relay, pair, ticks,
-                                              q.stream));
-  MOPT_HIP_TRY(mopt::launchFinalizeMomentsGated(c->d_partials, grid, q.gate_dev, q.relay, pair,
-                                                c->d_result, pub, q.stream));
-  q.pending = true;
-  q.publish_sequence = pub.sequence;
-  q.version = c->state_version;
-  q.queued_at_us = steadyMicros();
-  return MOPT_OK;
-}
-
-// The blocking linearization through the pair queued by the previous call (or, the first time and
-// after anything changed, through an ordinary launch), and the next pair queued while it runs.
-template <typename S>
-int prequeuedSweep(mopt_cost *c, int jac_mode, const S *x) {
-  auto &q = c->prequeue;
-  c->stat_sweeps += 1;
-  const bool usable = q.pending && q.version == c->state_version &&
-                      steadyMicros() - q.queued_at_us < kGateHostBoundUs;
-  if (!usable) {
-    prequeueAbandon(c);
-    mopt::HostPublish pub = nextPublish(c, 0);
-    int rc = linearizeAsyncImpl(c, jac_mode, x, c->d_result, c->stream, pub);
-    if (rc != MOPT_OK) return rc;
-    rc = prequeueLaunch<S>(c);  // for the next call, while this one runs
-    if (rc != MOPT_OK) return rc;
-    return waitPublished(c, pub.sequence);
-  }
-  // arm: [R | t] at x and the basis into the gate, then the words
-  mopt::P2PSweepArgs<S> args;
-  fillP2PArgs<S>(c, x, jac_mode == MOPT_JAC_NUMERIC, args);
-  mopt::AffineBasis basis;
-  fillBasis<S>(c, jac_mode, args, basis);
-  for (int k = 0; k < 7; ++k) q.gate->head[k] = double(args.T[0][k]);
-  for (int k = 7; k < 12; ++k) q.gate->tail[k - 7] = double(args.T[0][k]);
-  std::memcpy(q.gate->basis, &basis, sizeof basis);
-  const unsigned long long sequence = q.publish_sequence;
-  gateStore(q.gate, q.pair << 1);
-  q.pending = false;
-  q.stat_armed += 1;
-  // the next pair's two launch calls go out while this sweep runs (they queue behind its finalize)
-  int rc = prequeueLaunch<S>(c);
-  if (rc != MOPT_OK) return rc;
-  return waitPublished(c, sequence, q.stream);
-}
-
-}  // namespace
-
-namespace mopt_detail {
-void prequeueAbandon(mopt_cost *c) {
-  auto &q = c->prequeue;
-  if (!q.pending) return;
-  gateStore(q.gate, (q.pair << 1) | 1ull);
-  q.pending = false;
-  q.stat_abandoned += 1;
-}
-}  // namespace mopt_detail
-
-namespace {
-
 // One blocking sweep on the cost's own stream: kernels, the sum over the ranks of a sharded cost
 // (combine mode), and the published result in c->h_result[offset .. offset + count).
 int blockingSweep(mopt_cost *c, bool cost_only, int jac_mode, const void *x) {
@@ -829,19 +698,6 @@ int blockingSweep(mopt_cost *c, bool cost_only, int jac_mode, const void *x) {
       return MOPT_OK;
     }
     default: {
-      if (c->prequeue.enabled) {
-        const bool eligible =
-            c->scalar_bytes == 8
-                ? prequeueEligible<double>(c, cost_only, jac_mode, static_cast<const double *>(x))
-                : prequeueEligible<float>(c, cost_only, jac_mode, static_cast<const float *>(x));
-        if (eligible) {
-          c->stat_sweeps -= 1;  // counted there
-          return c->scalar_bytes == 8
-                     ? prequeuedSweep<double>(c, jac_mode, static_cast<const double *>(x))
-                     : prequeuedSweep<float>(c, jac_mode, static_cast<const float *>(x));
-        }
-        prequeueAbandon(c);  // another kind of sweep: do not leave a grid parked behind it
-      }
       mopt::HostPublish pub = nextPublish(c, offset);
       int rc = launch(pub);
       if (rc != MOPT_OK) return rc;
@@ -1361,14 +1217,7 @@ int commonCreate(mopt_cost *c, int device) {
 
 hipError_t quiesceCost(mopt_cost *c) {
   hipError_t first = hipSuccess;
-  if (c->prequeue.stream) {  // a waiting pair ends at once when abandoned; then nothing is in flight
-    prequeueAbandon(c);
-    first = hipStreamSynchronize(c->prequeue.stream);
-  }
-  if (c->stream) {
-    const hipError_t e = hipStreamSynchronize(c->stream);
-    if (first == hipSuccess) first = e;
-  }
+  if (c->stream) first = hipStreamSynchronize(c->stream);
   c->own_async_pending = false;
   if (c->foreign_pending && c->foreign_done) {
     const hipError_t e = hipEventSynchronize(c->foreign_done);
@@ -1401,9 +1250,6 @@ void destroyCost(mopt_cost *c) {
   }
   mopt::jitRelease(c->jit);
   releaseResident(c);
-  if (c->prequeue.gate) (void)hipHostFree(c->prequeue.gate);
-  if (c->prequeue.relay) (void)hipFree(c->prequeue.relay);
-  if (c->prequeue.stream) releaseStream(c->device, c->prequeue.stream);  // synchronised by quiesceCost
   deviceRelease(c->d_tiles);
   deviceRelease(c->d_partials);
   deviceRelease(c->d_result);
@@ -1829,7 +1675,6 @@ int mopt_cost_linearize_async(mopt_cost *c, int jacobian_mode, const void *x, do
   // hip_stream is the hipStream_t itself; NULL is HIP's null (legacy default) stream, which is
   // also what torch's default stream is
   const hipStream_t s = static_cast<hipStream_t>(hip_stream);
-  prequeueAbandon(c);  // the partial rows are about to be written from another stream
   mopt::PeerCombine pc;
   if (c->combine.mode == MOPT_COMBINE_PEER) {  // the sums of all ranks end up in d_result
     pc = nextPeerCombine(c, 0);
@@ -1844,7 +1689,6 @@ int mopt_cost_compute_async(mopt_cost *c, const void *x, double *d_sum_sq, void 
   if (!c || !x || !d_sum_sq) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
   MOPT_HIP_TRY(hipSetDevice(c->device));
   const hipStream_t s = static_cast<hipStream_t>(hip_stream);
-  prequeueAbandon(c);
   mopt::PeerCombine pc;
   if (c->combine.mode == MOPT_COMBINE_PEER) {
     pc = nextPeerCombine(c, costOffset(c));
@@ -2030,22 +1874,6 @@ int mopt_cost_set_speculation(mopt_cost *c, int enabled) {
   c->cache.valid = false;
   c->spec_kept_unused = false;
   c->spec_unused = c->spec_used = 0;
-  return MOPT_OK;
-}
-
-int mopt_cost_set_prequeue(mopt_cost *c, int enabled) {
-  if (!c) return fail(MOPT_ERR_INVALID_ARGUMENT, "cost is NULL");
-  if (enabled && c->model != kModelPoint2Point)
-    return fail(MOPT_ERR_UNSUPPORTED, "pre-queued sweeps exist for point2point costs");
-  if (!enabled) prequeueAbandon(c);
-  c->prequeue.enabled = enabled != 0;
-  return MOPT_OK;
-}
-
-int mopt_cost_prequeue_stats(const mopt_cost *c, int64_t *armed, int64_t *abandoned) {
-  if (!c) return fail(MOPT_ERR_INVALID_ARGUMENT, "cost is NULL");
-  if (armed) *armed = c->prequeue.stat_armed;
-  if (abandoned) *abandoned = c->prequeue.stat_abandoned;
   return MOPT_OK;
 }
 

@@ -191,21 +191,6 @@ struct mopt_cost {
   long long stat_prefetch_hits = 0;
   bool foreign_pending = false;
   bool own_async_pending = false;  // an asynchronous sweep was queued on this cost's own stream
-  // Pre-queued pair (mopt_cost_set_prequeue; sweep.hpp GateLine): the moments sweep + finalize of
-  // the next blocking call, queued on a stream of their own before its x is known.
-  struct Prequeue {
-    bool enabled = false;
-    bool pending = false;             // a pair is queued and neither armed nor abandoned
-    unsigned long long pair = 0;      // id of the pair last queued
-    unsigned long long publish_sequence = 0;
-    unsigned long long version = 0;   // state_version it was queued for
-    long long queued_at_us = 0;       // steady clock: a pair older than the host bound is not armed
-    mopt::GateLine *gate = nullptr;      // mapped host memory ...
-    mopt::GateLine *gate_dev = nullptr;  // ... as the device addresses it
-    mopt::GateLine *relay = nullptr;     // uncached device memory
-    hipStream_t stream = nullptr;
-    long long stat_armed = 0, stat_abandoned = 0;
-  } prequeue;
 
   int profiling = 0;  // 0 off, N > 0: bracket every N-th sweep launch with events
   long long profiling_tick = 0;
@@ -235,9 +220,6 @@ void deviceRelease(void *p);
 int commonCreate(mopt_cost *c, int device);  // device, stream, partial / result buffers
 // wait for everything enqueued for this cost, on its own stream and on callers' streams
 hipError_t quiesceCost(mopt_cost *c);
-// c_abi.cpp: give up the pre-queued pair of this cost, if one is waiting (its kernels end at once);
-// to be called wherever the cost's state or buffers change hands
-void prequeueAbandon(mopt_cost *c);
 void releaseCombine(mopt_cost *c);  // combine.cpp: unmaps / closes whatever was attached
 // c_abi.cpp, for the device-resident LM (lm.cpp): upload the static part of this cost's sweep
 // constants if it changed and describe the cost to the step kernel; enqueue one resident sweep +

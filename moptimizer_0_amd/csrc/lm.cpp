@@ -158,7 +158,6 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
   // So does a sweep queued ahead for a linked cost (mopt_costs_link) that nobody has consumed yet.
   for (int k = 0; k < num_costs; ++k) {
     mopt_cost *ck = costs[k];
-    prequeueAbandon(ck);  // a pair waiting for the next blocking call would sit on the CUs
     const bool other_stream = ck->stream != s;
     if (ck->foreign_pending || (other_stream && (ck->own_async_pending || ck->prefetch.pending)))
       MOPT_HIP_TRY(quiesceCost(ck));

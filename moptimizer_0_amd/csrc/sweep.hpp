@@ -165,27 +165,6 @@ struct PeerCombine {
   unsigned long long timeout_ticks = 0;  // of the 100 MHz wall clock; the wait is always bounded
 };
 
-// ---- pre-queued sweeps (mopt_cost_set_prequeue) ------------------------------------------------
-// A blocking sweep pays the launch path before its first load goes out: two launch calls, and the
-// dispatch of a grid over 256 CUs — 10.0 us from the launch call to the last workgroup running,
-// measured (scripts/probes/gate_probe.cpp).  A grid that is already resident and is released by a word
-// the host stores gets there in 6.6 us.  So the moments sweep + finalize of the NEXT call can be
-// queued before its x is known, on a stream of their own: workgroup 0 of the sweep waits for a gate
-// line in mapped host memory (the word and the 12 scalars of [R | t] at x; one poller — 256 pollers
-// saturate the PCIe read path: 48 us), relays them through a line of uncached device memory that
-// the other workgroups poll, and the sweep runs; the finalize reads the affine basis from the gate.
-// Every wait is bounded (timeout_ticks of the 100 MHz wall clock): a pair that is never armed — the
-// caller went away, or changed the cost's state, which abandons it — ends by itself and publishes
-// nothing.
-struct GateLine {
-  unsigned long long word;      // (pair << 1) | abandon; first line: written LAST by its producer
-  double head[7];               // T[0..6]
-  unsigned long long word_tail; // second 64-byte line: written before `word`; a reader accepts a
-  double tail[7];               // T[7..11] | unused            pair only when both words carry it
-  double basis[96];             // AffineBasis (81 doubles), read by the finalize kernel
-};
-static_assert(sizeof(GateLine) == 128 + 96 * 8, "GateLine layout");
-
 // ---- device-resident Levenberg-Marquardt (mopt_lm_minimize) ---------------------------------
 // The LM loop of src/levenberg_marquadt_dyn.cpp:34-119 with the iteration taken on the device:
 // after every sweep a one-workgroup step kernel reads the sums, solves the damped 6x6 system,
@@ -348,14 +327,6 @@ hipError_t launchFinalizeMoments(const double *partials, int grid, const AffineB
 hipError_t launchFinalizeCost(const double *partials, int grid, double *result,
                               const HostPublish &pub, hipStream_t stream,
                               const PeerCombine *peers = nullptr);
-// the gated pair (GateLine above): `args.T` is ignored, [R | t] comes through the gate
-template <typename S>
-hipError_t launchP2PMomentsGated(const P2PSweepArgs<S> &args, int grid, bool streaming,
-                                 const GateLine *gate, GateLine *relay, unsigned long long pair,
-                                 unsigned long long timeout_ticks, hipStream_t stream);
-hipError_t launchFinalizeMomentsGated(const double *partials, int grid, const GateLine *gate,
-                                      const GateLine *relay, unsigned long long pair, double *result,
-                                      const HostPublish &pub, hipStream_t stream);
 // Small parametric models: one launch computes the workgroup partial rows of the linearization
 // (or of the cost when cost_only); finish with launchFinalizeDense(n) / launchFinalizeCost.
 template <typename S>

@@ -932,26 +932,16 @@ __global__ __launch_bounds__(kFinalThreads) void finalizeDenseResidentKernel(
   }
 }
 
-// basis_fill / basis_value: the basis is still on its way (requested by the caller before this call):
-// thread t < 81 parks its double in basis_fill once the partial rows have been requested too.
 __device__ __forceinline__ unsigned long long finalizeMomentsBody(const double *partials, int grid,
                                                                   const AffineBasis &B,
                                                                   double *result,
                                                                   const HostPublish &pub,
                                                                   const PeerCombine &pc,
-                                                                  double *result_lds = nullptr,
-                                                                  AffineBasis *basis_fill = nullptr,
-                                                                  double basis_value = 0.0) {
+                                                                  double *result_lds = nullptr) {
   __shared__ double scratch[kFinalThreads];
   __shared__ double total[kMaxAccumulators];
   __shared__ double terms[36 * 16 + 6 * 4];
   columnTotals(partials, grid, kAccMoments, scratch, total);
-  if (basis_fill) {
-    constexpr int kBasisDoubles = int(sizeof(AffineBasis) / sizeof(double));
-    if (int(threadIdx.x) < kBasisDoubles)
-      reinterpret_cast<double *>(basis_fill)[threadIdx.x] = basis_value;
-    __syncthreads();
-  }
   const int t = threadIdx.x;
   if (t < 36 * 16) {
     const int o = t >> 4, ab = t & 15;
@@ -1045,95 +1035,6 @@ __global__ __launch_bounds__(kFinalThreads) void finalizeMomentsResidentKernel(
     __syncthreads();
     lmStepBody<S>(P, false, LmStart<S>(), own, own_index, true, state_word);
   }
-}
-
-// ---- pre-queued (gated) pair: sweep.hpp GateLine ----------------------------------------------
-__device__ __forceinline__ unsigned long long loadSystemWord(const unsigned long long *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ double uniformDouble(double v) {  // lane 0's value, in scalar registers
-  const long long bits = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_readfirstlane(int(bits));
-  const int hi = __builtin_amdgcn_readfirstlane(int(bits >> 32));
-  return __longlong_as_double((long long)(((unsigned long long)(unsigned int)hi << 32) |
-                                          (unsigned int)lo));
-}
-
-template <typename S, bool STREAMING>
-__global__ __launch_bounds__(kBlockThreads) void p2pMomentsGatedKernel(
-    const S *tiles, int num_tiles, const P2PSweepArgs<S> A, const GateLine *__restrict__ gate,
-    GateLine *__restrict__ relay, unsigned long long pair, unsigned long long timeout_ticks) {
-  __shared__ unsigned long long word_s;
-  __shared__ double T_s[12];
-  const int tid = threadIdx.x;
-  if (tid < 64) {
-    const unsigned long long started = wall_clock64();
-    unsigned long long word = (pair << 1) | 1ull;  // what a timeout leaves: abandoned
-    double mine = 0.0;
-    if (blockIdx.x == 0) {
-      // lanes 0..15: the two 64-byte lines of the gate (word | T[0..6] and word_tail | T[7..11]);
-      // the producer writes the payload, then word_tail, then word: both words of this pair = a
-      // consistent snapshot whichever line the read returned first
-      const unsigned long long *line = reinterpret_cast<const unsigned long long *>(gate);
-      for (;;) {
-        unsigned long long v = tid < 16 ? loadSystemWord(line + tid) : 0ull;
-        const unsigned long long w0 = __shfl(v, 0, 64), w1 = __shfl(v, 8, 64);
-        if (w0 == w1 && (w0 >> 1) == pair) {
-          word = w0;
-          mine = __longlong_as_double((long long)v);
-          break;
-        }
-        if (wall_clock64() - started > timeout_ticks) break;
-        __builtin_amdgcn_s_sleep(2);
-      }
-      // lane k holds T[k - 1] (k = 1..7) or T[k - 2] (k = 9..13): relay them, drained, then the word
-      const int slot = tid >= 1 && tid <= 7 ? tid - 1 : (tid >= 9 && tid <= 13 ? tid - 2 : -1);
-      if (!(word & 1ull) && slot >= 0) {
-        T_s[slot] = mine;
-        double *dst = slot < 7 ? relay->head + slot : relay->tail + (slot - 7);
-        storeSystem(dst, mine);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (tid == 0)
-        __hip_atomic_store(&relay->word, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    } else {
-      for (;;) {
-        unsigned long long w = tid == 0 ? loadSystemWord(&relay->word) : 0ull;
-        w = __shfl(w, 0, 64);
-        if ((w >> 1) == pair) {
-          word = w;
-          break;
-        }
-        if (wall_clock64() - started > 2 * timeout_ticks) break;
-        __builtin_amdgcn_s_sleep(4);
-      }
-      if (!(word & 1ull) && tid < 12)
-        T_s[tid] = loadSystem(tid < 7 ? relay->head + tid : relay->tail + (tid - 7));
-    }
-    if (tid == 0) word_s = word;
-  }
-  __syncthreads();
-  if (word_s & 1ull) return;  // abandoned, or never armed
-  P2PSweepArgs<S> B = A;
-#pragma unroll
-  for (int k = 0; k < 12; ++k) B.T[0][k] = S(uniformDouble(T_s[k]));
-  p2pMomentsBody<S, STREAMING>(tiles, num_tiles, B);
-}
-
-__global__ __launch_bounds__(kFinalThreads) void finalizeMomentsGatedKernel(
-    const double *partials, int grid, const GateLine *__restrict__ gate,
-    const GateLine *__restrict__ relay, unsigned long long pair, double *result,
-    const HostPublish pub) {
-  __shared__ unsigned long long word_s;
-  __shared__ AffineBasis B;
-  constexpr int kBasisDoubles = int(sizeof(AffineBasis) / sizeof(double));
-  // the basis is requested from the gate (host memory, one round trip) before anything else; it is
-  // complete: the sweep in front of this kernel has seen the pair's words, written after it
-  const double basis_value = int(threadIdx.x) < kBasisDoubles ? loadSystem(gate->basis + threadIdx.x) : 0.0;
-  if (threadIdx.x == 0) word_s = loadSystemWord(&relay->word);
-  __syncthreads();
-  if (word_s != (pair << 1)) return;  // the sweep did not run: nothing to publish
-  finalizeMomentsBody(partials, grid, B, result, pub, PeerCombine(), nullptr, &B, basis_value);
 }
 
 __global__ __launch_bounds__(kFinalThreads) void finalizeCostKernel(const double *partials,
@@ -1287,33 +1188,6 @@ hipError_t launchFinalizeMoments(const double *partials, int grid, const AffineB
                                  const PeerCombine *peers) {
   hipLaunchKernelGGL(finalizeMomentsKernel, dim3(1), dim3(kFinalThreads), 0, stream, partials,
                      grid, basis, result, pub, peers ? *peers : PeerCombine());
-  return hipGetLastError();
-}
-
-template <typename S>
-hipError_t launchP2PMomentsGated(const P2PSweepArgs<S> &args, int grid, bool streaming,
-                                 const GateLine *gate, GateLine *relay, unsigned long long pair,
-                                 unsigned long long timeout_ticks, hipStream_t stream) {
-  if (streaming)
-    hipLaunchKernelGGL((p2pMomentsGatedKernel<S, true>), dim3(grid), dim3(kBlockThreads), 0, stream,
-                       args.tiles, args.num_tiles, args, gate, relay, pair, timeout_ticks);
-  else
-    hipLaunchKernelGGL((p2pMomentsGatedKernel<S, false>), dim3(grid), dim3(kBlockThreads), 0, stream,
-                       args.tiles, args.num_tiles, args, gate, relay, pair, timeout_ticks);
-  return hipGetLastError();
-}
-template hipError_t launchP2PMomentsGated<float>(const P2PSweepArgs<float> &, int, bool,
-                                                 const GateLine *, GateLine *, unsigned long long,
-                                                 unsigned long long, hipStream_t);
-template hipError_t launchP2PMomentsGated<double>(const P2PSweepArgs<double> &, int, bool,
-                                                  const GateLine *, GateLine *, unsigned long long,
-                                                  unsigned long long, hipStream_t);
-
-hipError_t launchFinalizeMomentsGated(const double *partials, int grid, const GateLine *gate,
-                                      const GateLine *relay, unsigned long long pair, double *result,
-                                      const HostPublish &pub, hipStream_t stream) {
-  hipLaunchKernelGGL(finalizeMomentsGatedKernel, dim3(1), dim3(kFinalThreads), 0, stream, partials,
-                     grid, gate, relay, pair, result, pub);
   return hipGetLastError();
 }
 

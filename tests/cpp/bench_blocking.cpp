@@ -1,6 +1,6 @@
 // What the reference's LM loop sees from C++ (no Python in the way): wall time of blocking
 // linearize / computeCost calls on a HIP cost and of a full LevenbergMarquadtDynamic::minimize.
-//   bench_blocking [N = 10000000] [prequeue = 0|1]   (1: mopt_cost_set_prequeue on the cost)
+//   bench_blocking [N = 10000000]
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -18,7 +18,6 @@ using Clock = std::chrono::steady_clock;
 
 int main(int argc, char **argv) {
   const long n = argc > 1 ? std::atol(argv[1]) : 10000000L;
-  const int prequeue = argc > 2 ? std::atoi(argv[2]) : 0;
   std::vector<double> src(size_t(n) * 3), tgt(size_t(n) * 3);
   std::mt19937_64 gen(42);
   std::uniform_real_distribution<double> uni(0.0, 10.0);
@@ -39,8 +38,6 @@ int main(int argc, char **argv) {
     std::printf("N = %ld: cost construction (PCIe copy + re-layout) %.2f ms\n", n,
                 std::chrono::duration<double, std::milli>(Clock::now() - t0).count());
     mopt_cost_set_speculation(cost.handle(), 0);  // time real sweeps
-    if (prequeue) mopt_cost_set_prequeue(cost.handle(), 1);
-    std::printf("pre-queued sweeps: %s\n", prequeue ? "on" : "off");
     double x[6] = {0.5, -0.3, 0.2, 0.1, -0.2, 0.3}, H[36], b[6];
     for (int warm = 0; warm < 50; ++warm) cost.linearize(x, H, b);  // code objects loaded, clocks up
     const int reps = 300;
@@ -59,32 +56,6 @@ int main(int argc, char **argv) {
     std::printf("blocking linearize (forward differences): %.1f us/call = %.3e correspondences/s\n", lin_us,
                 n / (lin_us * 1e-6));
     std::printf("blocking computeCost:                     %.1f us/call\n", cost_us);
-    {  // the same linearize in the analytic mode, and with a caller that takes 3 us between calls
-      mh::CostFunctionAnalyticalDynamic<double> ana(model, 6, 3, int(n));
-      mopt_cost_set_speculation(ana.handle(), 0);
-      if (prequeue) mopt_cost_set_prequeue(ana.handle(), 1);
-      for (int warm = 0; warm < 50; ++warm) ana.linearize(x, H, b);
-      t0 = Clock::now();
-      for (int k = 0; k < reps; ++k) {
-        x[0] = 0.5 + 1e-4 * (k % 16);
-        ana.linearize(x, H, b);
-      }
-      std::printf("blocking linearize (analytic):            %.1f us/call\n",
-                  std::chrono::duration<double, std::micro>(Clock::now() - t0).count() / reps);
-      double busy = 0;
-      t0 = Clock::now();
-      for (int k = 0; k < reps; ++k) {
-        x[0] = 0.5 + 1e-4 * (k % 16);
-        ana.linearize(x, H, b);
-        const auto until = Clock::now() + std::chrono::microseconds(3);
-        while (Clock::now() < until) busy += 1;
-      }
-      std::printf("   with 3 us of caller work between calls: %.1f us/iteration (%g)\n",
-                  std::chrono::duration<double, std::micro>(Clock::now() - t0).count() / reps, busy * 0);
-      std::int64_t armed = 0, abandoned = 0;
-      mopt_cost_prequeue_stats(ana.handle(), &armed, &abandoned);
-      std::printf("   pairs armed %lld, abandoned %lld\n", (long long)armed, (long long)abandoned);
-    }
 
     for (int spec = 0; spec < 2; ++spec) {
       mopt_cost_set_speculation(cost.handle(), spec);
