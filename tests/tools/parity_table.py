@@ -16,10 +16,10 @@ for n in (1000, 100_000, 1_000_000):
     src, tgt = ds.synthetic_pair(n, seed=42, noise=0.01)
     cost = mo.Point2PointCost(src, tgt)
     for mode, mname in ((0, "analytic"), (1, "analytic, tst layout"), (3, "analytic, left perturbation"),
-                        (2, "forward differences")):
+                        (4, "analytic, right perturbation"), (2, "forward differences")):
         cc = ob.NUMERIC_DYN if mode == 2 else ob.ANALYTIC_DYN
-        layout = {1: ob.LAYOUT_TST, 3: ob.LAYOUT_LEFT}.get(mode, ob.LAYOUT_ROW_MAJOR)
-        for variant, vname in ((2, "moments"), (1, "literal")):
+        layout = {1: ob.LAYOUT_TST, 3: ob.LAYOUT_LEFT, 4: ob.LAYOUT_RIGHT}.get(mode, ob.LAYOUT_ROW_MAJOR)
+        for variant, vname in ((3, "moments"), (1, "literal")):
             cost.set_kernel_variant(variant)
             for x, xname in ((ds.X_ZERO, "0"), (ds.X_GENERIC, "generic")):
                 H, b, s = cost.linearize(x, mode)
@@ -35,16 +35,25 @@ print("|---|---|---|---|---|")
 rng = np.random.default_rng(5)
 src, tgt = ds.synthetic_pair(100_000, seed=42, noise=0.01)
 cost = mo.Point2PointCost(src, tgt)
+COVS = (("", None), (", symmetric covariance", np.array([[2.0, 0.3, -0.1], [0.3, 0.5, 0.2], [-0.1, 0.2, 1.5]])),
+        (", general covariance + Geman-McClure(100)", np.array([[2.0, 0.7, -0.1], [0.3, 0.5, 0.9], [-0.4, 0.2, 1.5]])))
 for scale in (1e-8, 1e-6, 1e-4, 1e-3, 1e-2, 1e-1, 1.0):
-    for variant, vname in ((2, "moments"), (1, "literal")):
-        cost.set_kernel_variant(variant)
-        wH = wb = 0.0
-        for _ in range(20):
-            x = rng.choice([-1.0, 1.0], 6) * scale * rng.uniform(0.3, 3.0, 6)
-            H, b, s = cost.linearize(x, 2)
-            Hr, br, sr = o.p2p_linearize(src, tgt, x, cost_class=ob.NUMERIC_DYN, layout=ob.LAYOUT_ROW_MAJOR)
-            wH, wb = max(wH, rel(H, Hr)), max(wb, rel(b, br))
-        print("| %.0e | %.1e | %s | %.1e | %.1e |" % (scale, 1.49e-8 * scale, vname, wH, wb), flush=True)
+    for variant, vname in ((3, "moments (MOMENTS_ALWAYS)"), (1, "literal"), (0, "AUTO")):
+        for cname, cov in COVS:
+            if cov is not None and variant != 1:
+                continue
+            loss = (1, 100.0) if "Geman" in cname else (0, 0.0)
+            cost.set_kernel_variant(variant)
+            cost.set_covariance(cov)
+            cost.set_loss(*loss)
+            wH = wb = 0.0
+            for _ in range(20):
+                x = rng.choice([-1.0, 1.0], 6) * scale * rng.uniform(0.3, 3.0, 6)
+                H, b, s = cost.linearize(x, 2)
+                Hr, br, sr = o.p2p_linearize(src, tgt, x, cost_class=ob.NUMERIC_DYN, layout=ob.LAYOUT_ROW_MAJOR,
+                                             cov=cov, loss_kind=loss[0], loss_param=loss[1])
+                wH, wb = max(wH, rel(H, Hr)), max(wb, rel(b, br))
+            print("| %.0e | %.1e | %s%s | %.1e | %.1e |" % (scale, 1.49e-8 * scale, vname, cname, wH, wb), flush=True)
 cost.close()
 
 print()
