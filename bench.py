@@ -537,7 +537,10 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
-            t = json.load(open(tpath)).get("%s_%s_n%d" % (args.mode, args.dtype, args.n))
+            # keyed by what was launched: "--variant literal" runs another kernel than the default
+            key = "%s%s_%s_n%d" % (args.mode, "_literal" if args.variant == "literal" else "",
+                                   args.dtype, args.n)
+            t = json.load(open(tpath)).get(key) if args.cov == "identity" and args.loss == "none" else None
             if t is not None:
                 # PMC counters need rocprofv3 --pmc passes of their own; what is reported here
                 # is the committed measurement of this same launch, not a reading of this run
