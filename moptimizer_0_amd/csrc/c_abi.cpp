@@ -284,8 +284,8 @@ int p2pLinearizeAsync(mopt_cost *c, int jac_mode, const S *x, double *d_result, 
   } else {
     const int grid = gridFor(c, blocksPerCu(2));
     const int nacc = c->cov_mode == mopt::kCovGeneral ? mopt::kAccFull : mopt::kAccSym;
-    // the forward-difference sweep takes dispatch timestamps like the moments sweep
-    SweepTimer timer(c, s, jac_mode == MOPT_JAC_NUMERIC);
+    // (tiled launch signature: dispatch timestamps like the moments sweep)
+    SweepTimer timer(c, s, true);
     MOPT_HIP_TRY(mopt::launchP2PLinearizeLiteral<S>(args, jac_mode, c->cov_mode, grid, timer.site));
     timer.stop();
     MOPT_HIP_TRY(

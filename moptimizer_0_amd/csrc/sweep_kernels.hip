@@ -25,9 +25,32 @@
 namespace mopt {
 namespace {
 
+// Which entries of a model's Jacobian are the literal zero, whatever the data: products with them
+// add nothing to any sum (for finite data not even in the last bit), so the accumulation below
+// leaves them out — the point-to-point patterns are half zeros, and an H entry none of whose terms
+// survives is never touched.  (A product with a literal 1 the compiler folds by itself; x * 0 it may
+// not.)
+struct DensePattern {
+  static constexpr bool zero(int, int) { return false; }
+};
+template <int JAC>
+struct P2PJacobianPattern {
+  static constexpr bool zero(int a, int j) {
+    if (JAC == kJacAnalyticTst) {
+      // {1,0,0,0,1,0}, {0,0,1,0,-z,y}, {z,0,-x,-y,x,0}  (tst/point2point.cpp:71-75 read row-major)
+      return (a == 0 && (j == 1 || j == 2 || j == 3 || j == 5)) ||
+             (a == 1 && (j == 0 || j == 1 || j == 3)) || (a == 2 && (j == 1 || j == 5));
+    }
+    if (j < 3) return a != j;                   // [ I3 | . ]
+    if (JAC == kJacAnalyticRight) return false;  // -R skew(p): dense
+    return a == j - 3;                           // -skew(.): zero diagonal
+  }
+};
+
 // acc += w J^T S J (upper triangle, or all n*n entries when S is not symmetric), w J^T S r, r^T r.
-// J is m x n (row index = output), cov row-major m x m.  FULL selects the n*n form.
-template <typename S, int M, int N, int COV, int NACC>
+// J is m x n (row index = output), cov row-major m x m.  NACC selects the n*n form.  In fp64 every
+// sum is a chain of fused multiply-adds straight into its accumulator.
+template <typename S, int M, int N, int COV, typename Pattern = DensePattern, int NACC>
 __device__ __forceinline__ void accumulateDense(const S (&J)[M][N], const S (&r)[M], S w, S rr,
                                                 const S *cov, double (&acc)[NACC]) {
   S SJ[M][N];
@@ -46,7 +69,8 @@ __device__ __forceinline__ void accumulateDense(const S (&J)[M][N], const S (&r)
       for (int j = 0; j < N; ++j) {
         S v = 0;
 #pragma unroll
-        for (int c = 0; c < M; ++c) v += cov[a * M + c] * J[c][j];
+        for (int c = 0; c < M; ++c)
+          if (!Pattern::zero(c, j)) v += cov[a * M + c] * J[c][j];
         SJ[a][j] = v;
       }
       S v = 0;
@@ -59,29 +83,44 @@ __device__ __forceinline__ void accumulateDense(const S (&J)[M][N], const S (&r)
 #pragma unroll
   for (int a = 0; a < M; ++a)
 #pragma unroll
-    for (int i = 0; i < N; ++i) wJ[a][i] = w * J[a][i];
+    for (int i = 0; i < N; ++i) wJ[a][i] = Pattern::zero(a, i) ? S(0) : w * J[a][i];
 
   constexpr bool kFull = (NACC == N * N + N + 1);
   constexpr int kNH = kFull ? N * N : N * (N + 1) / 2;
   static_assert(NACC == kNH + N + 1, "accumulator count does not match the matrix form");
+  // (S J)(a, j) is structurally zero only under the identity covariance
+  auto term = [&](double &dst, S &partial, S x, S y) {
+    if constexpr (sizeof(S) == 8)
+      dst = __builtin_fma(double(x), double(y), dst);
+    else
+      partial += x * y;
+  };
 #pragma unroll
   for (int j = 0; j < N; ++j) {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       if (!kFull && i > j) continue;
-      S v = 0;
-#pragma unroll
-      for (int a = 0; a < M; ++a) v += wJ[a][i] * SJ[a][j];
       const int k = kFull ? (j * N + i) : (j * (j + 1) / 2 + i);
-      acc[k] += double(v);
+      S partial = 0;
+      bool any = false;
+#pragma unroll
+      for (int a = 0; a < M; ++a) {
+        if (Pattern::zero(a, i) || (COV == kCovIdentity && Pattern::zero(a, j))) continue;
+        term(acc[k], partial, wJ[a][i], SJ[a][j]);
+        any = true;
+      }
+      if (sizeof(S) == 4 && any) acc[k] += double(partial);
     }
   }
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    S v = 0;
+    S partial = 0;
 #pragma unroll
-    for (int a = 0; a < M; ++a) v += wJ[a][i] * Sr[a];
-    acc[kNH + i] += double(v);
+    for (int a = 0; a < M; ++a) {
+      if (Pattern::zero(a, i)) continue;
+      term(acc[kNH + i], partial, wJ[a][i], Sr[a]);
+    }
+    if (sizeof(S) == 4) acc[kNH + i] += double(partial);
   }
   acc[kNH + N] += double(rr);
 }
@@ -146,10 +185,11 @@ __device__ __forceinline__ void p2pPointLiteral(
   }
   const S rr = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
   const S w = lossWeight<S>(A.loss_kind, A.loss_param, rr);
-  accumulateDense<S, 3, 6, COV>(J, r, valid ? w : S(0), valid ? rr : S(0), A.cov, acc);
+  accumulateDense<S, 3, 6, COV, P2PJacobianPattern<JAC>>(J, r, valid ? w : S(0), valid ? rr : S(0),
+                                                          A.cov, acc);
 }
 
-template <typename S, int JAC, int COV>
+template <typename S, int JAC, int COV, bool STREAMING = false>
 __device__ __forceinline__ void p2pLinearizeLiteralBody(const P2PSweepArgs<S> &A, int block,
                                                         int num_blocks) {
   constexpr int NACC = (COV == kCovGeneral) ? kAccFull : kAccSym;
@@ -158,7 +198,7 @@ __device__ __forceinline__ void p2pLinearizeLiteralBody(const P2PSweepArgs<S> &A
 #pragma unroll
   for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
 
-  sweepTiles<S, false>(A.tiles, A.num_tiles, [&](const Pack<S>(&cur)[6], long long first) {
+  sweepTiles<S, STREAMING>(A.tiles, A.num_tiles, [&](const Pack<S>(&cur)[6], long long first) {
 #pragma unroll
     for (int e = 0; e < V; ++e) {
       const S p[3] = {cur[0].v[e], cur[1].v[e], cur[2].v[e]};
@@ -170,10 +210,15 @@ __device__ __forceinline__ void p2pLinearizeLiteralBody(const P2PSweepArgs<S> &A
   blockReduceStore<NACC>(acc, A.partials + size_t(block) * NACC);
 }
 
-template <typename S, int JAC, int COV>
+// (tiles / num_tiles repeat the first members of A as preloaded leading arguments, as in the moments
+// sweep; STREAMING: non-temporal loads once the data exceed the aggregate L2)
+template <typename S, int JAC, int COV, bool STREAMING>
 __global__ __launch_bounds__(kBlockThreads) void p2pLinearizeLiteralKernel(
-    const P2PSweepArgs<S> A) {
-  p2pLinearizeLiteralBody<S, JAC, COV>(A, blockIdx.x, gridDim.x);
+    const S *tiles, int num_tiles, const P2PSweepArgs<S> A) {
+  P2PSweepArgs<S> B = A;
+  B.tiles = tiles;
+  B.num_tiles = num_tiles;
+  p2pLinearizeLiteralBody<S, JAC, COV, STREAMING>(B, blockIdx.x, gridDim.x);
 }
 
 // Resident form (device-resident LM, sweep.hpp): the per-x constants come from HBM, where the
@@ -1104,14 +1149,18 @@ hipError_t launchSweep(Kernel kernel, int grid, const LaunchSite &site, const Ar
 template <typename S, int JAC>
 hipError_t launchLiteralCov(const P2PSweepArgs<S> &args, int cov_mode, int grid,
                             const LaunchSite &site) {
+#define MOPT_LAUNCH_LITERAL(COV)                                                                   \
+  (site.streaming ? launchTiled(p2pLinearizeLiteralKernel<S, JAC, COV, true>, grid, site, args)   \
+                  : launchTiled(p2pLinearizeLiteralKernel<S, JAC, COV, false>, grid, site, args))
   switch (cov_mode) {
     case kCovIdentity:
-      return launchSweep(p2pLinearizeLiteralKernel<S, JAC, kCovIdentity>, grid, site, args);
+      return MOPT_LAUNCH_LITERAL(kCovIdentity);
     case kCovSymmetric:
-      return launchSweep(p2pLinearizeLiteralKernel<S, JAC, kCovSymmetric>, grid, site, args);
+      return MOPT_LAUNCH_LITERAL(kCovSymmetric);
     default:
-      return launchSweep(p2pLinearizeLiteralKernel<S, JAC, kCovGeneral>, grid, site, args);
+      return MOPT_LAUNCH_LITERAL(kCovGeneral);
   }
+#undef MOPT_LAUNCH_LITERAL
 }
 
 }  // namespace
