@@ -18,6 +18,7 @@
 #include "moptimizer_amd/cost_function_hip.hpp"
 #include "moptimizer_amd/levenberg_marquadt_device.hpp"
 #include "moptimizer_caller/levenberg_marquadt.hpp"
+#include "moptimizer_amd/so3.hpp"
 
 #include "curve_data.inc"
 
@@ -173,6 +174,108 @@ static void cameraCalibration() {
   }
 }
 
+// tst/state_model.cpp:83-112 — a 15-parameter, 15-output model with one residual block — with
+// `LevenbergMarquadtDevice<double> lm(15)` where the reference says `LevenbergMarquadtDynamic<double>
+// lm(15)` (round 3: the loop's state, its solve and its report hold n <= 16).  The reference's test asserts
+// nothing; the solve must return the fixed state, and the device loop the host loop's answer.
+static void stateModel() {
+  const char *residual = R"SRC(
+  auto Exp = [](const S *w, S (&R)[9]) {
+    const S t = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    for (int k = 0; k < 9; ++k) R[k] = (k % 4 == 0) ? S(1) : S(0);
+    if (t > S(10) * S(2.220446049250313e-16)) {
+      const S a[3] = {w[0] / t, w[1] / t, w[2] / t};
+      const S K[9] = {0, -a[2], a[1], a[2], 0, -a[0], -a[1], a[0], 0};
+      const S s = sin(t), c1 = S(1) - cos(t);
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+          S kk = 0;
+          for (int k = 0; k < 3; ++k) kk += K[i * 3 + k] * K[k * 3 + j];
+          R[i * 3 + j] = ((i == j ? S(1) : S(0)) + s * K[i * 3 + j]) + c1 * kk;
+        }
+    }
+  };
+  S R0[9], R[9], rel[9];
+  Exp(d, R0);
+  Exp(x, R);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      S v = 0;
+      for (int k = 0; k < 3; ++k) v += R0[k * 3 + i] * R[k * 3 + j];
+      rel[i * 3 + j] = v;
+    }
+  const S trace = rel[0] + rel[4] + rel[8];
+  const S theta = (trace > S(3.0 - 1e-6)) ? S(0) : acos(S(0.5) * (trace - S(1)));
+  const S K[3] = {rel[7] - rel[5], rel[2] - rel[6], rel[3] - rel[1]};
+  const S k = (fabs(theta) < S(0.001)) ? S(0.5) : S(0.5) * theta / sin(theta);
+  for (int i = 0; i < 3; ++i) r[i] = k * K[i];
+  for (int i = 0; i < 12; ++i) r[3 + i] = x[3 + i] - d[3 + i];
+)SRC";
+  double x_init[15] = {0.6, 0.8, 0.3, -0.4, 0.11, -0.9};  // :88
+  const double start[15] = {0.1, 0.2, 0.3, 0.4, 0.5, 0.6};  // :89
+  std::vector<const double *> planes;
+  for (int p = 0; p < 15; ++p) planes.push_back(&x_init[p]);
+  auto model = std::make_shared<mh::JitDeviceModel<double>>(15, 15, residual, "", planes);
+  mh::CostFunctionNumericalDynamic<double> cost(model, 15, 15, 1);        // :101
+  double x[15];
+  solveBoth<double>("StateModel.Optimize (n = m = 15)", {&cost}, 15, start, 0, x, 1e-7);
+  for (int i = 0; i < 15; ++i) {
+    char label[64];
+    std::snprintf(label, sizeof label, "  StateModel.Optimize x[%d] vs the fixed state", i);
+    expectNear(label, x[i], x_init[i], 1e-7);
+  }
+}
+
+// A registration from a start 2.5 rad off under the SE(3) update composed on the RIGHT — R <- R Exp(dw),
+// t <- t + dt, the form of the reference's own sketches (tst/manifold.cpp:47, tst/state_model.cpp:28-34;
+// its optimizer leaves the manifold update a TODO, levenberg_marquadt_dyn.cpp:82-83) — device loop against
+// the host loop with the same update, both over CostFunctionAnalyticalRightHip.
+static void rightManifold() {
+  const int n_points = 4000;
+  std::vector<double> src(size_t(n_points) * 3), tgt(size_t(n_points) * 3);
+  unsigned long long state = 88172645463325252ull;
+  auto uniform = [&]() {  // xorshift: the data only have to be the same for both loops
+    state ^= state << 13; state ^= state >> 7; state ^= state << 17;
+    return double(state >> 11) / 9007199254740992.0;
+  };
+  const double pose[6] = {10.5, 10.2, 0.1, 0.38994502377414, 0.31542006718654, 0.54962215934141};
+  double T[16];
+  moptimizer::so3::convert6DOFParameterToMatrix<double>(pose, T);
+  for (int i = 0; i < n_points; ++i) {
+    for (int k = 0; k < 3; ++k) src[3 * i + k] = 10.0 * uniform();
+    for (int r = 0; r < 3; ++r)
+      tgt[3 * i + r] = T[0 * 4 + r] * src[3 * i] + T[1 * 4 + r] * src[3 * i + 1] +
+                       T[2 * 4 + r] * src[3 * i + 2] + T[3 * 4 + r];
+  }
+  auto model = std::make_shared<mh::Point2PointDeviceModel<double>>(src.data(), tgt.data(), size_t(n_points));
+  mh::CostFunctionAnalyticalRightHip<double> cost(model, 6, 3, n_points);
+  // start: the pose with its rotation vector scaled far off and the translation shifted
+  const double start[6] = {11.5, 11.2, 1.1, -1.2, 0.9, -0.4};
+  std::vector<double> xh(start, start + 6), xd(start, start + 6);
+  LevenbergMarquadtDynamic<double> host(6);
+  mh::LevenbergMarquadtDevice<double> device(6);
+  host.setMaximumIterations(100);
+  device.setMaximumIterations(100);
+  host.setManifoldUpdate(2);
+  device.setRightManifoldUpdate(true);
+  host.addCost(&cost);
+  device.addCost(&cost);
+  const OptimizationStatus sh = host.minimize(xh.data());
+  const OptimizationStatus sd = device.minimize(xd.data());
+  expectTrue("RightManifold: device status == host status", sd == sh);
+  double Rh[16], Rd[16], Rt[16];
+  moptimizer::so3::convert6DOFParameterToMatrix<double>(xh.data(), Rh);
+  moptimizer::so3::convert6DOFParameterToMatrix<double>(xd.data(), Rd);
+  moptimizer::so3::convert6DOFParameterToMatrix<double>(pose, Rt);
+  for (int k = 0; k < 12; ++k) {
+    char label[96];
+    std::snprintf(label, sizeof label, "RightManifold: T[%d] device vs host loop", k);
+    expectNear(label, Rd[k], Rh[k], 1e-9);
+    std::snprintf(label, sizeof label, "  RightManifold: T[%d] vs the generating pose", k);
+    expectNear(label, Rd[k], Rt[k], 1e-7);
+  }
+}
+
 static void errors() {
   mh::LevenbergMarquadtDevice<double> lm(2);
   bool threw = false;
@@ -209,6 +312,8 @@ int main() {
     simpleModelFloat();
     multipleObjectives();
     cameraCalibration();
+    stateModel();
+    rightManifold();
     errors();
   } catch (const std::exception &e) {
     std::printf("FAIL exception: %s\n", e.what());
