@@ -99,9 +99,15 @@ def run(args):
 
     subjects = [
         Subject("p2p/auto", mo.Point2PointCost(src, tgt), mo.Point2PointCost(src, tgt),
-                [mo.JAC_ANALYTIC, mo.JAC_NUMERIC, mo.JAC_ANALYTIC_LEFT]),
+                [mo.JAC_ANALYTIC, mo.JAC_NUMERIC, mo.JAC_ANALYTIC_LEFT, mo.JAC_ANALYTIC_RIGHT]),
         Subject("p2p/literal", mo.Point2PointCost(src[:9000], tgt[:9000]),
-                mo.Point2PointCost(src[:9000], tgt[:9000]), [mo.JAC_ANALYTIC, mo.JAC_NUMERIC]),
+                mo.Point2PointCost(src[:9000], tgt[:9000]),
+                [mo.JAC_ANALYTIC, mo.JAC_NUMERIC, mo.JAC_ANALYTIC_RIGHT]),
+        # a second literally evaluated cost: with the first one it is swept by one launch in the
+        # device-resident solves that pick both in the same mode (round 3)
+        Subject("p2p/literal-b", mo.Point2PointCost(src[9000:20000], tgt[9000:20000]),
+                mo.Point2PointCost(src[9000:20000], tgt[9000:20000]),
+                [mo.JAC_ANALYTIC, mo.JAC_NUMERIC, mo.JAC_ANALYTIC_RIGHT]),
         Subject("camera/a", mo.ReprojectionCost(pts[:8000], pix[:8000]),
                 mo.ReprojectionCost(pts[:8000], pix[:8000]), [mo.JAC_NUMERIC]),
         Subject("camera/b", mo.ReprojectionCost(pts[8000:], pix[8000:]),
@@ -113,8 +119,9 @@ def run(args):
     icp = Subject("icp", mo.IcpCost(src[:6000], tgt_cloud, 2.0), mo.IcpCost(src[:6000], tgt_cloud, 2.0),
                   [mo.JAC_ANALYTIC, mo.JAC_NUMERIC])
     subjects.append(icp)
-    subjects[1].cost.set_kernel_variant(mo.KERNEL_LITERAL)
-    subjects[1].twin.set_kernel_variant(mo.KERNEL_LITERAL)
+    for k in (1, 2):
+        subjects[k].cost.set_kernel_variant(mo.KERNEL_LITERAL)
+        subjects[k].twin.set_kernel_variant(mo.KERNEL_LITERAL)
     curve = Subject("curve", mo.ScalarModelCost(mo.capi.MODEL_EXP_CURVE, t, y),
                     mo.ScalarModelCost(mo.capi.MODEL_EXP_CURVE, t, y), [mo.JAC_NUMERIC])
     pose = [s for s in subjects]          # the 6-parameter costs share parameter vectors
@@ -191,6 +198,9 @@ def run(args):
             group = [family[i] for i in rng.permutation(len(family))[:rng.integers(1, len(family) + 1)]]
             modes = [g.jac_modes[-1] if g.name.startswith("camera") else g.jac_modes[0] for g in group]
             modes = [m if m != mo.JAC_ANALYTIC_LEFT else mo.JAC_ANALYTIC for m in modes]
+            if not cameras and rng.random() < 0.5:
+                # the literally evaluated costs in forward differences: still one launch for the pair
+                modes = [mo.JAC_NUMERIC if g.name.startswith("p2p/literal") else m for g, m in zip(group, modes)]
             # (the reprojection problem from within its basin: far from it the robust loss saturates and
             # the iterates become a noise amplifier, which compares rounding, not code paths)
             x0 = (np.array([-0.01, 0.02, -0.058, 0.018, -0.0013, 0.027]) + 0.003 * rng.standard_normal(6)
