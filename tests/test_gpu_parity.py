@@ -82,14 +82,14 @@ def cloud_1k():
 @pytest.mark.parametrize("variant", [1, 2])
 def test_p2p_1k_matches_committed_golden_vectors(hip_lib, variant):
     """The HIP path against tests/golden/p2p_1k_golden.npz alone (no oracle library in the loop):
-    24 point2point configurations (3 Jacobian modes x 2 poses x 2 losses x 2 covariances), the
+    80 point2point configurations (5 Jacobian modes x 2 poses x 2 losses x 4 covariances), the
     reference's five camera correspondences, and the LM end point on the 1 k cloud."""
     from tests.golden import make_p2p_golden as mk
     g = np.load(os.path.join(ds.GOLDEN, "p2p_1k_golden.npz"))
     src, tgt = ds.synthetic_pair(1000, seed=42, noise=0.01)
     cost = hip_lib.Point2PointCost(src, tgt)
     cost.set_kernel_variant(variant)
-    mode_of = {"analytic": 0, "analytic_tst": 1, "numeric": 2}
+    mode_of = mk.JAC_MODE
     for m, xn, ln, cn in mk.cases():
         lk, lp = mk.LOSSES[ln]
         cost.set_loss(lk, lp)
