@@ -959,7 +959,10 @@ int residentSweepSet(mopt_cost *const *costs, int num_costs, const int *jac_mode
   for (int k = 0; k < num_costs; ++k) {
     set.args[k] = costs[k]->d_lm_args;
     set.first_block[k] = first_row[k];
-    bytes += size_t(costs[k]->count) * 40;
+    // bytes the launch streams: 40 per reprojection element, 6 scalars per correspondence
+    bytes += costs[k]->model == kModelReprojection
+                 ? size_t(costs[k]->count) * 40
+                 : size_t(costs[k]->count) * 6 * size_t(costs[k]->scalar_bytes);
   }
   set.first_block[num_costs] = first_row[num_costs];
   mopt::LaunchSite site;
