@@ -20,7 +20,7 @@ if [ "$1" = "build" ]; then
       -c moptimizer_0_amd/csrc/$f.cpp -o $OUT/$f.o
   done
   $HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT/libmoptimizer_hip.so $OUT/*.o \
-    build/obj/sweep_kernels.o build/obj/icp_grid.o build/obj/lm_kernels.o \
+    build/obj/sweep_kernels.o build/obj/fd_kernels.o build/obj/icp_grid.o build/obj/lm_kernels.o \
     -L/opt/rocm/lib -lrccl -lhiprtc -lpthread -lrt -Wl,-rpath,/opt/rocm/lib
   for t in dropin_point2point dropin_models dropin_device_lm; do
     $CLANG -O1 -g -std=c++17 $SAN -Iinclude -Ioracle -Itests/support -o $OUT/$t tests/cpp/$t.cpp \
