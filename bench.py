@@ -30,10 +30,10 @@ Prints ONE JSON line on rank 0 (contract in the task statement) including
                  for every transport measured (config.collective names the headline's)
 
 Order for N > 1: attach every transport (host slots, peer slots, RCCL) | headline pass | kernel-
-time pass | RCCL pass | CPU baseline — from there the line is complete — then the comparison
-passes (other transports, no combine, the 10 M strong-scaling split).  A watchdog covers it all:
-firing before the line is complete it ends the rank with exit code 3 and no line; after, it
-prints the line as it stands ("extras_incomplete") and ends the rank.
+time pass | CPU baseline — from there the line can stand — | RCCL pass | the comparison passes
+(other transports, no combine, the 10 M strong-scaling split).  A watchdog covers it all: firing
+before the line can stand it ends the rank with exit code 3 and no line; after, it prints the line
+as it is ("extras_incomplete", "note" naming the stage it was in) and ends the rank.
 """
 import argparse
 import json
@@ -609,6 +609,19 @@ def main():
         line["by_collective"] = per
         line["roofline"]["step_frac_by_collective"] = {collective: per[collective]["step_frac"]}
 
+    # ---- CPU baseline: rank 0's host cores, every world size -----------------------------------
+    progress["stage"] = "cpu baseline"
+    if rank == 0:
+        line["cpu_baseline"] = (cpu_baseline(src_host, tgt_host, ds.X_GENERIC, jac_mode, args.cpu_seconds)
+                                if keep_host else None)
+    if world > 1:
+        dist.barrier()  # the others wait here, not inside a combine with a 5 s limit
+    # From here on the watchdog reports the line as it stands instead of failing: the headline
+    # measurement, its kernel time and the CPU baseline are in it.  The RCCL pass comes next — it is the
+    # one path that has never run with more than one rank before this very run, and a collective that
+    # never completes must not take the measurement already made down with it.
+    progress["complete"] = True
+
     # ---- RCCL: part of the measurement proper, whatever the headline transport ------------------
     if world > 1:
         progress["stage"] = "RCCL pass"
@@ -621,10 +634,17 @@ def main():
                          "ranks_min_over_ranks": int(t[0].item()),
                          "ranks_max_over_ranks": -int(t[1].item()),
                          "spans_all_ranks": int(t[0].item()) == world == -int(t[1].item())})
+            # in the line before the pass starts: should the watchdog have to report from inside it, the
+            # line still says that the communicator spanned the ranks and that its pass did not finish
+            info["timed_pass"] = "not finished"
+            line["rccl"] = info
+            line["config"]["rccl_ranks"] = ranks_here
             if collective == "rccl":
                 info.update(per["rccl"])
+                info["timed_pass"] = "the headline pass"
             else:
                 r = guarded_pass(cost, "rccl", args.steps, args.warmup, min(settle, 200))
+                info["timed_pass"] = "done" if r is not None else "failed"
                 if r is not None:
                     per["rccl"] = as_step_sees_it(r[0] / args.steps * 1e3)
                     info.update(per["rccl"])
@@ -635,15 +655,6 @@ def main():
             info["reason"] = rccl_note
         line["rccl"] = info
         line["config"]["rccl_ranks"] = info.get("ranks")
-
-    # ---- CPU baseline: rank 0's host cores, every world size -----------------------------------
-    progress["stage"] = "cpu baseline"
-    if rank == 0:
-        line["cpu_baseline"] = (cpu_baseline(src_host, tgt_host, ds.X_GENERIC, jac_mode, args.cpu_seconds)
-                                if keep_host else None)
-    if world > 1:
-        dist.barrier()  # the others wait here, not inside a combine with a 5 s limit
-    progress["complete"] = True  # from here on the watchdog reports instead of failing
 
     if world > 1 and not args.no_compare:
         # every other way of adding the ranks' sums, and no combine at all, K steps each
