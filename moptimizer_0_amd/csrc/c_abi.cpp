@@ -282,7 +282,10 @@ int p2pLinearizeAsync(mopt_cost *c, int jac_mode, const S *x, double *d_result, 
     timer.stop();
     MOPT_HIP_TRY(mopt::launchFinalizeMoments(c->d_partials, grid, basis, d_result, pub, s, c->launch_peers));
   } else {
-    const int grid = gridFor(c, blocksPerCu(2));
+    // forward differences: two workgroups per CU (VALU-heavy: the second wave per SIMD pays); the
+    // analytic patterns stream like the moments sweep: one (70.8 vs 72.1 us at 10 M, and half the
+    // partial rows for the finalize kernel)
+    const int grid = gridFor(c, blocksPerCu(jac_mode == MOPT_JAC_NUMERIC ? 2 : 1));
     const int nacc = c->cov_mode == mopt::kCovGeneral ? mopt::kAccFull : mopt::kAccSym;
     // (tiled launch signature: dispatch timestamps like the moments sweep)
     SweepTimer timer(c, s, true);
