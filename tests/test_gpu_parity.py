@@ -62,7 +62,7 @@ def oracle_ref(oracle, src, tgt, x, jac_mode, **kw):
     """The reference computation a jacobian_mode stands for."""
     if jac_mode == 2:
         return oracle.p2p_linearize(src, tgt, x, cost_class=ob.NUMERIC_DYN, **kw)
-    layout = {1: ob.LAYOUT_TST, 3: ob.LAYOUT_LEFT}.get(jac_mode, ob.LAYOUT_ROW_MAJOR)
+    layout = {1: ob.LAYOUT_TST, 3: ob.LAYOUT_LEFT, 4: ob.LAYOUT_RIGHT}.get(jac_mode, ob.LAYOUT_ROW_MAJOR)
     return oracle.p2p_linearize(src, tgt, x, cost_class=ob.ANALYTIC_DYN, layout=layout, **kw)
 
 
@@ -295,6 +295,66 @@ def test_full_size_properties(hip_lib):
     assert rel_err(Hm, Hn) < 1e-6 and rel_err(bm, bn) < 1e-6 and abs(sm - sn) < 1e-12 * sn
 
 
+def test_metric_size_properties_10M(hip_lib):
+    """The metric's own size, 10 M correspondences (BASELINE.json), where the CPU restatement would take
+    minutes: size-independent properties of every sweep the round-3 kernels serve.
+      * the three evaluations of the analytic linearization agree (moments, literal);
+      * forward differences evaluated as the reference does agree with the moments form where that
+        meets the bar (|x_j| >= 0.1), under Sigma = I, a symmetric and a non-symmetric covariance;
+      * linearity in the covariance: H(a S1 + b S2) = a H(S1) + b H(S2), b likewise (identity,
+        symmetric and general kernels against each other);
+      * additivity over a split of the index range; the exact translation block under Sigma = I."""
+    mo = hip_lib
+    import torch
+    n = 10_000_000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    src = torch.rand((n, 3), generator=g, device="cuda", dtype=torch.float64) * 10.0
+    tgt = src + 0.05 * torch.randn((n, 3), generator=g, device="cuda", dtype=torch.float64) + 0.3
+    torch.cuda.synchronize()
+
+    def make(lo, hi):
+        return mo.Point2PointCost(src[lo:hi].contiguous().data_ptr() if (lo, hi) != (0, n) else src.data_ptr(),
+                                  tgt[lo:hi].contiguous().data_ptr() if (lo, hi) != (0, n) else tgt.data_ptr(),
+                                  device_ptrs=True, count=hi - lo)
+
+    whole = make(0, n)
+    x = ds.X_GENERIC
+    S1 = np.array([[2.0, 0.3, -0.1], [0.3, 0.5, 0.2], [-0.1, 0.2, 1.5]])
+    S2 = np.array([[1.0, 0.7, 0.0], [-0.2, 0.8, 0.9], [-0.4, 0.1, 0.6]])
+
+    def lin(cost, mode, variant, cov=None):
+        cost.set_kernel_variant(variant)
+        cost.set_covariance(cov)
+        return cost.linearize(x, mode)
+
+    Hm, bm, sm = lin(whole, mo.JAC_ANALYTIC, mo.KERNEL_MOMENTS)
+    Hl, bl, sl = lin(whole, mo.JAC_ANALYTIC, mo.KERNEL_LITERAL)
+    assert rel_err(Hl, Hm) < 1e-11 and rel_err(bl, bm) < 1e-11 and abs(sl - sm) < 1e-11 * sm
+    assert np.allclose(np.diag(Hm)[:3], n, rtol=0, atol=1e-5)
+    for cov in (None, S1, S2):
+        Hf, bf, sf = lin(whole, mo.JAC_NUMERIC, mo.KERNEL_LITERAL, cov)
+        Hq, bq, sq = lin(whole, mo.JAC_NUMERIC, mo.KERNEL_MOMENTS_ALWAYS, cov)
+        assert rel_err(Hf, Hq) < 1e-6 and rel_err(bf, bq) < 1e-6 and abs(sf - sq) < 1e-12 * sq
+    for mode in (mo.JAC_NUMERIC, mo.JAC_ANALYTIC_RIGHT):
+        H1, b1, _ = lin(whole, mode, mo.KERNEL_LITERAL, S1)
+        H2, b2, _ = lin(whole, mode, mo.KERNEL_LITERAL, S2)
+        H3, b3, _ = lin(whole, mode, mo.KERNEL_LITERAL, 0.5 * S1 - 2.0 * S2)
+        Hi, bi, _ = lin(whole, mode, mo.KERNEL_LITERAL, None)
+        He, be, _ = lin(whole, mode, mo.KERNEL_LITERAL, np.eye(3) + 0.25 * S1)
+        assert rel_err(H3, 0.5 * H1 - 2.0 * H2) < 1e-10 and rel_err(b3, 0.5 * b1 - 2.0 * b2) < 1e-10
+        assert rel_err(He, Hi + 0.25 * H1) < 1e-10 and rel_err(be, bi + 0.25 * b1) < 1e-10
+    k = 3_771_233
+    a, c = make(0, k), make(k, n)
+    for mode, variant, cov in ((mo.JAC_NUMERIC, mo.KERNEL_LITERAL, S1), (mo.JAC_ANALYTIC, mo.KERNEL_LITERAL, None)):
+        H, b, s = lin(whole, mode, variant, cov)
+        Ha, ba, sa = lin(a, mode, variant, cov)
+        Hc, bc, sc = lin(c, mode, variant, cov)
+        assert rel_err(Ha + Hc, H) < 1e-11 and rel_err(ba + bc, b) < 1e-11 and abs(sa + sc - s) < 1e-11 * s
+    for cst in (whole, a, c):
+        cst.close()
+
+
 def test_single_rank_communicator(hip_lib, oracle, cloud_1k):
     """mopt_cost_comm_init_rank with one rank runs the very sequence N ranks run — sweep, finalize,
     ncclAllReduce on the cost's stream, publish kernel, host flag — so RCCL linkage, stream order
@@ -474,7 +534,7 @@ def test_hundred_million_correspondences(hip_lib):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("jac_mode", [0, 1, 2])
+@pytest.mark.parametrize("jac_mode", [0, 1, 2, 3, 4])
 def test_p2p_float32_all_modes_against_float_oracle(hip_lib, oracle, jac_mode):
     """fp32 instantiation against the reference's own fp32 arithmetic (oracle run in float, as
     CostFunction*Dynamic<float>, src/cost_function_*_dyn.cpp:32).  At 1 k points the reference's
@@ -485,10 +545,18 @@ def test_p2p_float32_all_modes_against_float_oracle(hip_lib, oracle, jac_mode):
     cost = hip_lib.Point2PointCost(src, tgt, dtype=np.float32)
     cost.set_loss(1, 100.0)
     cc = ob.NUMERIC_DYN if jac_mode == 2 else ob.ANALYTIC_DYN
-    layout = ob.LAYOUT_TST if jac_mode == 1 else ob.LAYOUT_ROW_MAJOR
+    layout = {1: ob.LAYOUT_TST, 3: ob.LAYOUT_LEFT, 4: ob.LAYOUT_RIGHT}.get(jac_mode, ob.LAYOUT_ROW_MAJOR)
     want = oracle.p2p_linearize(src, tgt, x, cost_class=cc, layout=layout, loss_kind=1,
                                 loss_param=100.0, dtype=np.float32)
     tol = 2e-3 if jac_mode == 2 else 2e-5
+    for variant in (hip_lib.KERNEL_AUTO, hip_lib.KERNEL_LITERAL):   # moments; per-point literal / forward-difference kernels
+        cost.set_kernel_variant(variant)
+        check(cost.linearize(x, jac_mode), tuple(np.asarray(v, dtype=np.float64) for v in want), tol=tol)
+    # ... and under a symmetric covariance (fp32 forward differences: the LDS form of the kernel)
+    cov = np.array([[2.0, 0.3, -0.1], [0.3, 0.5, 0.2], [-0.1, 0.2, 1.5]], dtype=np.float32)
+    cost.set_covariance(cov)
+    want = oracle.p2p_linearize(src, tgt, x, cost_class=cc, layout=layout, loss_kind=1,
+                                loss_param=100.0, cov=cov, dtype=np.float32)
     check(cost.linearize(x, jac_mode), tuple(np.asarray(v, dtype=np.float64) for v in want), tol=tol)
 
 
@@ -850,6 +918,12 @@ def test_baseline_configs_2_and_3_full_size_against_oracle(hip_lib, oracle, jac_
     want = oracle.p2p_cost(src, tgt, ds.X_GENERIC)
     cost.set_speculation(False)
     assert abs(cost.compute_cost(ds.X_GENERIC) - want) <= REL * want
+    if variant == 1:   # the per-point kernels under a covariance and the robust loss, at full size
+        cov = np.array([[2.0, 0.3, -0.1], [0.3, 0.5, 0.2], [-0.1, 0.2, 1.5]])
+        cost.set_covariance(cov)
+        cost.set_loss(1, 100.0)
+        check(cost.linearize(ds.X_GENERIC, jac_mode),
+              oracle_ref(oracle, src, tgt, ds.X_GENERIC, jac_mode, cov=cov, loss_kind=1, loss_param=100.0))
 
 
 def test_parallel_cost_test_of_the_reference(hip_lib, oracle):
