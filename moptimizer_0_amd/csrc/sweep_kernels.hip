@@ -863,20 +863,26 @@ __device__ __forceinline__ void columnTotals(const double *partials, int grid, i
   const int t = threadIdx.x;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   if (t < stride) {
-    // the grids of this library give a thread at most 8 rows (256 rows x 23 values over 1012
-    // threads: 6): all of its loads are issued before the first one is used — one memory round
-    // trip; larger grids continue in batches of four
-    double v[8];
+    // the common grids give a thread at most 16 rows (256 rows x 23 values over 1012 threads: 6;
+    // the two-workgroups-per-CU sweeps, 512 rows x 28: 15): all of its loads are issued before the
+    // first one is used — one memory round trip (batches of 8 paid two there: 5.2 -> 4.8 us on one
+    // box); 512 rows x 43 (23 per thread) continues in batches of four — a batch of 24 measured the
+    // same within noise for it and slower for the others
+    constexpr int kBatch = 16;
+    double v[kBatch];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < kBatch; ++k) {
       const int idx = t + k * stride;
       v[k] = idx < total_elems ? partials[idx] : 0.0;
     }
-    s0 = v[0] + v[4];
-    s1 = v[1] + v[5];
-    s2 = v[2] + v[6];
-    s3 = v[3] + v[7];
-    int idx = t + 8 * stride;
+#pragma unroll
+    for (int k = 0; k < kBatch; k += 4) {
+      s0 += v[k];
+      s1 += v[k + 1];
+      s2 += v[k + 2];
+      s3 += v[k + 3];
+    }
+    int idx = t + kBatch * stride;
     for (; idx + 3 * stride < total_elems; idx += 4 * stride) {
       const double a = partials[idx], b = partials[idx + stride], c = partials[idx + 2 * stride],
                    d = partials[idx + 3 * stride];
