@@ -33,6 +33,11 @@ struct LmState {
   unsigned long long steps;  // step-kernel runs: the host's progress word
 };
 
+// two words per thread of a stored LmState, requested ahead of use (lmPrefetchState)
+struct LmStateWords {
+  unsigned int lo, hi;
+};
+
 template <typename S>
 struct LmStart {
   S x[kMaxWideParams];
@@ -524,14 +529,15 @@ __device__ __forceinline__ void storeReport(double *p, double v) {
 //   own_result  H | b | sum_sq of cost `own_index` in LDS when the caller has just finalized it in
 //               this same launch (its copy in HBM may not be visible to this workgroup yet);
 //               nullptr when every cost's result comes from HBM
-//   state_word  word `threadIdx.x` of the stored state, loaded by the caller ahead of its own work
-//               so that the round trip overlaps it (ignored when `prefetched` is false)
+//   state_words words `threadIdx.x` (+ blockDim.x) of the stored state, loaded by the caller ahead
+//               of its own work so that the round trip overlaps it (ignored when `prefetched` is
+//               false)
 // (forced inline: as a real call the by-value kernel arguments it takes by reference — 1.2 KB of
 // LmProblem — are first copied to scratch by every lane of the 1024-thread workgroup: 60 us)
 template <typename S, int NMAX>
 __device__ __forceinline__ void lmStepBodyFor(const LmProblem &P, bool init, const LmStart<S> &start,
                               const double *own_result, int own_index, bool prefetched,
-                              unsigned int state_word) {
+                              LmStateWords state_words) {
 #ifdef MOPT_LM_TIMING
   __shared__ unsigned long long tick[8];
 #define MOPT_TICK(i) if (threadIdx.x == 0) tick[i] = wall_clock64()
@@ -554,7 +560,9 @@ __device__ __forceinline__ void lmStepBodyFor(const LmProblem &P, bool init, con
   constexpr int kStateWords = int(sizeof(LmState<S, NMAX>) / sizeof(unsigned int));
   if (!init) {
     if (prefetched) {
-      if (tid < kStateWords) reinterpret_cast<unsigned int *>(&st)[tid] = state_word;
+      if (tid < kStateWords) reinterpret_cast<unsigned int *>(&st)[tid] = state_words.lo;
+      if (tid + int(blockDim.x) < kStateWords)
+        reinterpret_cast<unsigned int *>(&st)[tid + blockDim.x] = state_words.hi;
     } else {
       for (int i = tid; i < kStateWords; i += blockDim.x)
         reinterpret_cast<unsigned int *>(&st)[i] = reinterpret_cast<const unsigned int *>(stored)[i];
@@ -822,24 +830,31 @@ __device__ __forceinline__ void lmStepBodyFor(const LmProblem &P, bool init, con
 #undef MOPT_TICK
 }
 
-// Word `threadIdx.x` of the stored state, for lmStepBody's `state_word`.
+// Words `threadIdx.x` and `threadIdx.x + blockDim.x` of the stored state (LmStateWords), for
+// lmStepBody's `state_words` (the largest state, 16 fp64 parameters, is 654 words: a workgroup of
+// >= 327 threads).
 template <typename S>
-__device__ __forceinline__ unsigned int lmPrefetchState(const LmProblem &P) {
+__device__ __forceinline__ LmStateWords lmPrefetchState(const LmProblem &P) {
   const int words = P.n <= kMaxParams ? int(sizeof(LmState<S, kMaxParams>) / sizeof(unsigned int))
                                       : int(sizeof(LmState<S, kMaxWideParams>) / sizeof(unsigned int));
-  return int(threadIdx.x) < words ? reinterpret_cast<const unsigned int *>(P.state)[threadIdx.x]
-                                  : 0u;
+  // unconditional loads from clamped indices: under a branch they would be waited for on the spot
+  const unsigned int *state = reinterpret_cast<const unsigned int *>(P.state);
+  const int lo = int(threadIdx.x), hi = int(threadIdx.x + blockDim.x);
+  LmStateWords w;
+  w.lo = state[lo < words ? lo : 0];
+  w.hi = state[hi < words ? hi : 0];
+  return w;
 }
 
 // The step for this problem's parameter count (see LmState).
 template <typename S>
 __device__ __forceinline__ void lmStepBody(const LmProblem &P, bool init, const LmStart<S> &start,
                            const double *own_result, int own_index, bool prefetched,
-                           unsigned int state_word) {
+                           LmStateWords state_words) {
   if (P.n <= kMaxParams)
-    lmStepBodyFor<S, kMaxParams>(P, init, start, own_result, own_index, prefetched, state_word);
+    lmStepBodyFor<S, kMaxParams>(P, init, start, own_result, own_index, prefetched, state_words);
   else
-    lmStepBodyFor<S, kMaxWideParams>(P, init, start, own_result, own_index, prefetched, state_word);
+    lmStepBodyFor<S, kMaxWideParams>(P, init, start, own_result, own_index, prefetched, state_words);
 }
 
 }  // namespace

@@ -23,7 +23,7 @@ template <typename S>
 __global__ __launch_bounds__(128) void lmStepKernel(const LmProblem P, int init,
                                                     const LmStart<S> start) {
   if (!init && P.control->done) return;
-  lmStepBody<S>(P, init != 0, start, nullptr, -1, false, 0u);
+  lmStepBody<S>(P, init != 0, start, nullptr, -1, false, LmStateWords());
 }
 
 template <typename Args>

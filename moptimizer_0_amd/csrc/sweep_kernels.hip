@@ -772,6 +772,12 @@ __global__ void relayoutReprojKernel(const double *__restrict__ pts, const int *
 // independent and in flight together — the kernel costs about one memory round trip, not one
 // per row.  Column totals are then formed in a fixed order (bitwise reproducible).
 constexpr int kFinalThreads = 1024;
+// The resident finalize kernels that run the LM step in the same launch: 512 threads, so that a
+// lane has 256 VGPRs — under the 128 of a 1024-thread workgroup the step's register-held solve
+// spilled 434 VGPRs to scratch on its one busy lane.  (The width of a one-workgroup kernel costs
+// nothing measurable: scripts/probes/finalize_width_probe.cpp.)  At least n^2 + n + 1 = 273
+// threads: one per published value of a 16-parameter problem.
+constexpr int kStepThreads = 512;
 constexpr int kMaxAccumulators = 288;  // n <= 16 (run-time compiled wide models): n*n + n + 1 <= 273
 
 // Write-through store at system scope (sc0 sc1): straight to mapped host memory, nothing left
@@ -811,10 +817,14 @@ __device__ __forceinline__ double loadSystem(const double *p) {
 // each, sleeps between polls, gives up after timeout_ticks (the wait must end on every path: a
 // peer that never arrives turns into kStatusPeerTimeout and NaN sums, not into a hung GPU), and
 // then adds the G slots in rank order.
+// (`sequence_add`: the resident kernels' trial count on top of pc.sequence — a separate argument,
+// because a modified copy of `pc` is a private array indexed by lane: scratch for every launch)
 __device__ __forceinline__ double peerCombine(const PeerCombine &pc, int count, double v,
-                                              unsigned long long *status) {
+                                              unsigned long long *status,
+                                              unsigned long long sequence_add = 0) {
   *status = 0;
   if (pc.num_ranks <= 0) return v;
+  const unsigned long long sequence = pc.sequence + sequence_add;
   __shared__ double *peer_block[kMaxPeers];
   __shared__ int timed_out;
   const int tid = threadIdx.x;
@@ -822,7 +832,7 @@ __device__ __forceinline__ double peerCombine(const PeerCombine &pc, int count, 
   if (tid < kMaxPeers) peer_block[tid] = pc.blocks[tid < G ? tid : 0];
   if (tid == 0) timed_out = 0;
   __syncthreads();
-  const size_t mine = slotIndex(pc.sequence, G, pc.rank);
+  const size_t mine = slotIndex(sequence, G, pc.rank);
   if (tid < count)
     for (int p = 0; p < G; ++p) storeSystem(peer_block[p] + mine + pc.offset + tid, v);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -830,11 +840,11 @@ __device__ __forceinline__ double peerCombine(const PeerCombine &pc, int count, 
   double *own = peer_block[pc.rank];
   if (tid < G) {
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(peer_block[tid] + mine + kSlotFlag),
-                       pc.sequence, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                       sequence, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned long long *flag = reinterpret_cast<const unsigned long long *>(
-        own + slotIndex(pc.sequence, G, tid) + kSlotFlag);
+        own + slotIndex(sequence, G, tid) + kSlotFlag);
     const unsigned long long started = wall_clock64();
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < pc.sequence) {
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < sequence) {
       if (wall_clock64() - started > pc.timeout_ticks) {
         timed_out = 1;
         break;
@@ -846,7 +856,7 @@ __device__ __forceinline__ double peerCombine(const PeerCombine &pc, int count, 
   double total = 0.0;
   if (tid < count)
     for (int k = 0; k < G; ++k)
-      total += loadSystem(own + slotIndex(pc.sequence, G, k) + pc.offset + tid);
+      total += loadSystem(own + slotIndex(sequence, G, k) + pc.offset + tid);
   if (timed_out) {
     *status = kStatusPeerTimeout;
     total = __builtin_nan("");
@@ -854,46 +864,84 @@ __device__ __forceinline__ double peerCombine(const PeerCombine &pc, int count, 
   return total;
 }
 
+// K rows of one thread (t, t + stride, ...; zeros past the end) added up.  The K loads are issued
+// together from clamped indices and fenced from the selects that zero the rows past the end: a load
+// under a branch gets its own wait, and left alone the scheduler interleaves loads and selects
+// (reusing vcc) — either way a batch became 3-4 dependent round trips.
+template <int K>
+__device__ __forceinline__ double columnBatch(const double *partials, int t, int stride,
+                                              int total_elems) {
+  int at[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int idx = t + k * stride;
+    at[k] = idx < total_elems ? idx : t;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  double v[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = partials[at[k]];
+  __builtin_amdgcn_sched_barrier(0);
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < K; ++k) s[k & 3] += (t + k * stride) < total_elems ? v[k] : 0.0;
+  return (s[0] + s[1]) + (s[2] + s[3]);
+}
+
+struct NoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+
+// Column sums of the `grid` partial rows of `nacc` values -> total[0 .. nacc).  `parked` runs once
+// per thread after the thread's rows have been requested and added and before the first barrier:
+// the place where a resident kernel puts values it requested *before* this call (basis, LM state)
+// into LDS, so that their round trip overlaps the rows'.
+template <int T, typename Parked = NoHook>
 __device__ __forceinline__ void columnTotals(const double *partials, int grid, int nacc,
-                                             double (&scratch)[kFinalThreads],
-                                             double (&total)[kMaxAccumulators]) {
-  const int per_col = kFinalThreads / nacc;  // threads per column
+                                             double (&scratch)[T],
+                                             double (&total)[kMaxAccumulators],
+                                             Parked parked = Parked()) {
+  const int per_col = T / nacc;  // threads per column
   const int stride = per_col * nacc;
   const int total_elems = grid * nacc;
   const int t = threadIdx.x;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  // rows per thread, the same for all — 1024 threads: 256 rows x 23 values: 6; the two-workgroups-
+  // per-CU sweeps, 512 rows x 28: 15, x 43: 23; 512 threads: 12, 29, 47 — each a single batch, one
+  // memory round trip; larger grids continue in batches of four
+  const int rows = (total_elems + stride - 1) / stride;
+  constexpr bool kRoomy = T <= 512;  // 256 VGPRs a lane: batches of 32 and 48 fit
+  double sum = 0.0;
   if (t < stride) {
-    // the common grids give a thread at most 16 rows (256 rows x 23 values over 1012 threads: 6;
-    // the two-workgroups-per-CU sweeps, 512 rows x 28: 15): all of its loads are issued before the
-    // first one is used — one memory round trip (batches of 8 paid two there: 5.2 -> 4.8 us on one
-    // box); 512 rows x 43 (23 per thread) continues in batches of four — a batch of 24 measured the
-    // same within noise for it and slower for the others
-    constexpr int kBatch = 16;
-    double v[kBatch];
-#pragma unroll
-    for (int k = 0; k < kBatch; ++k) {
-      const int idx = t + k * stride;
-      v[k] = idx < total_elems ? partials[idx] : 0.0;
+    if (rows <= 6) {
+      sum = columnBatch<6>(partials, t, stride, total_elems);
+    } else if (rows <= 12) {
+      sum = columnBatch<12>(partials, t, stride, total_elems);
+    } else if (rows <= 16) {
+      sum = columnBatch<16>(partials, t, stride, total_elems);
+    } else if (rows <= 24) {
+      sum = columnBatch<24>(partials, t, stride, total_elems);
+    } else if (kRoomy && rows <= 32) {
+      sum = columnBatch<kRoomy ? 32 : 4>(partials, t, stride, total_elems);
+    } else if (kRoomy && rows <= 48) {
+      sum = columnBatch<kRoomy ? 48 : 4>(partials, t, stride, total_elems);
+    } else {
+      sum = columnBatch<24>(partials, t, stride, total_elems);
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      int idx = t + 24 * stride;
+      for (; idx + 3 * stride < total_elems; idx += 4 * stride) {
+        const double a = partials[idx], b = partials[idx + stride], c = partials[idx + 2 * stride],
+                     d = partials[idx + 3 * stride];
+        s0 += a;
+        s1 += b;
+        s2 += c;
+        s3 += d;
+      }
+      for (; idx < total_elems; idx += stride) s0 += partials[idx];
+      sum += (s0 + s1) + (s2 + s3);
     }
-#pragma unroll
-    for (int k = 0; k < kBatch; k += 4) {
-      s0 += v[k];
-      s1 += v[k + 1];
-      s2 += v[k + 2];
-      s3 += v[k + 3];
-    }
-    int idx = t + kBatch * stride;
-    for (; idx + 3 * stride < total_elems; idx += 4 * stride) {
-      const double a = partials[idx], b = partials[idx + stride], c = partials[idx + 2 * stride],
-                   d = partials[idx + 3 * stride];
-      s0 += a;
-      s1 += b;
-      s2 += c;
-      s3 += d;
-    }
-    for (; idx < total_elems; idx += stride) s0 += partials[idx];
   }
-  scratch[t] = (s0 + s1) + (s2 + s3);
+  parked();
+  scratch[t] = sum;
   __syncthreads();
   if (t < nacc) {
     double v = 0.0;
@@ -905,14 +953,18 @@ __device__ __forceinline__ void columnTotals(const double *partials, int grid, i
 
 // rows of [upper triangle or full H | b | sum_sq] over n parameters -> H (n x n column-major) | b |
 // sum_sq.  nacc tells the form: n(n+1)/2 + n + 1 (symmetric) or n*n + n + 1 (full).
+template <int T, typename Parked = NoHook>
 __device__ __forceinline__ unsigned long long finalizeDenseBody(const double *partials, int grid,
                                                                 int nacc, int n, double *result,
                                                                 const HostPublish &pub,
                                                                 const PeerCombine &pc,
-                                                                double *result_lds = nullptr) {
-  __shared__ double scratch[kFinalThreads];
+                                                                double *result_lds = nullptr,
+                                                                Parked parked = Parked(),
+                                                                unsigned long long sequence_add = 0) {
+  static_assert(T >= kMaxWideParams * kMaxWideParams + kMaxWideParams + 1, "one thread per value");
+  __shared__ double scratch[T];
   __shared__ double total[kMaxAccumulators];
-  columnTotals(partials, grid, nacc, scratch, total);
+  columnTotals<T>(partials, grid, nacc, scratch, total, parked);
   const int k = threadIdx.x;
   const int count = n * n + n + 1;
   double v = 0.0;
@@ -932,7 +984,7 @@ __device__ __forceinline__ unsigned long long finalizeDenseBody(const double *pa
     }
   }
   unsigned long long status;
-  v = peerCombine(pc, count, v, &status);
+  v = peerCombine(pc, count, v, &status, sequence_add);
   if (k < count) {
     result[k] = v;
     if (result_lds) result_lds[k] = v;
@@ -946,7 +998,7 @@ __global__ __launch_bounds__(kFinalThreads) void finalizeDenseKernel(const doubl
                                                                       double *result,
                                                                       const HostPublish pub,
                                                                       const PeerCombine pc) {
-  finalizeDenseBody(partials, grid, nacc, n, result, pub, pc);
+  finalizeDenseBody<kFinalThreads>(partials, grid, nacc, n, result, pub, pc);
 }
 
 // Resident forms (device-resident LM): nothing goes to the host, the peer-combine sequence number
@@ -965,37 +1017,42 @@ struct StepScalar<4> {
 };
 
 template <int STEP>
-__global__ __launch_bounds__(kFinalThreads) void finalizeDenseResidentKernel(
+__global__ __launch_bounds__(kStepThreads) void finalizeDenseResidentKernel(
     const double *partials, int grid, int nacc, int n, double *result, LmControl *control,
     PeerCombine pc, const LmProblem P, int own_index) {
   if (control->done) return;
   using S = typename StepScalar<STEP>::type;
-  unsigned int state_word = 0;
-  if constexpr (STEP != 0) state_word = lmPrefetchState<S>(P);
+  LmStateWords state_words = {0u, 0u};
+  if constexpr (STEP != 0) state_words = lmPrefetchState<S>(P);
   __shared__ double own[kSlotData];
-  pc.sequence += (unsigned long long)control->trial;
-  const unsigned long long status =
-      finalizeDenseBody(partials, grid, nacc, n, result, HostPublish(), pc, own);
+  const unsigned long long status = finalizeDenseBody<kStepThreads>(
+      partials, grid, nacc, n, result, HostPublish(), pc, own, NoHook(),
+      (unsigned long long)control->trial);
   if (status && threadIdx.x == 0) control->pad[0] = int(status);  // a rank went missing
   if constexpr (STEP != 0) {
     __syncthreads();
-    lmStepBody<S>(P, false, LmStart<S>(), own, own_index, true, state_word);
+    lmStepBody<S>(P, false, LmStart<S>(), own, own_index, true, state_words);
   }
 }
 
+template <int T, typename Parked = NoHook>
 __device__ __forceinline__ unsigned long long finalizeMomentsBody(const double *partials, int grid,
                                                                   const AffineBasis &B,
                                                                   double *result,
                                                                   const HostPublish &pub,
                                                                   const PeerCombine &pc,
-                                                                  double *result_lds = nullptr) {
-  __shared__ double scratch[kFinalThreads];
+                                                                  double *result_lds = nullptr,
+                                                                  Parked parked = Parked(),
+                                                                  unsigned long long sequence_add = 0) {
+  __shared__ double scratch[T];
   __shared__ double total[kMaxAccumulators];
   __shared__ double terms[36 * 16 + 6 * 4];
-  columnTotals(partials, grid, kAccMoments, scratch, total);
+  columnTotals<T>(partials, grid, kAccMoments, scratch, total, parked);
   const int t = threadIdx.x;
-  if (t < 36 * 16) {
-    const int o = t >> 4, ab = t & 15;
+  // 36 x 16 products for H, 6 x 4 for b: one per thread, in trips of T
+  for (int item = t; item < 36 * 16 + 24; item += T) {
+  if (item < 36 * 16) {
+    const int o = item >> 4, ab = item & 15;
     const int i = o % 6, j = o / 6;
     int a = ab >> 2, b = ab & 3;
     double form = 0.0;
@@ -1013,9 +1070,9 @@ __device__ __forceinline__ unsigned long long finalizeMomentsBody(const double *
     }
     // (0,0)=0 (0,b)=b (1,1)=4 (1,2)=5 (1,3)=6 (2,2)=7 (2,3)=8 (3,3)=9
     const int wi = a == 0 ? b : (a == 1 ? 3 + b : (a == 2 ? 5 + b : 9));
-    terms[t] = total[wi] * form;
-  } else if (t < 36 * 16 + 24) {
-    const int u = t - 36 * 16;
+    terms[item] = total[wi] * form;
+  } else {
+    const int u = item - 36 * 16;
     const int i = u >> 2, a = u & 3;
     double g = 0.0;
 #pragma unroll
@@ -1026,7 +1083,8 @@ __device__ __forceinline__ unsigned long long finalizeMomentsBody(const double *
         sv += B.cov[r * 3 + c] * (a == 0 ? total[10 + c] : total[13 + 3 * (a - 1) + c]);
       g += B.J[a][r * 6 + i] * sv;
     }
-    terms[t] = g;
+    terms[item] = g;
+  }
   }
   __syncthreads();
   double v = 0.0;
@@ -1043,7 +1101,7 @@ __device__ __forceinline__ unsigned long long finalizeMomentsBody(const double *
     }
   }
   unsigned long long status;
-  v = peerCombine(pc, kResultDoubles, v, &status);
+  v = peerCombine(pc, kResultDoubles, v, &status, sequence_add);
   if (t < kResultDoubles) {
     result[t] = v;
     if (result_lds) result_lds[t] = v;
@@ -1058,33 +1116,48 @@ __global__ __launch_bounds__(kFinalThreads) void finalizeMomentsKernel(const dou
                                                                         double *result,
                                                                         const HostPublish pub,
                                                                         const PeerCombine pc) {
-  finalizeMomentsBody(partials, grid, B, result, pub, pc);
+  finalizeMomentsBody<kFinalThreads>(partials, grid, B, result, pub, pc);
 }
 
 template <int STEP>
-__global__ __launch_bounds__(kFinalThreads) void finalizeMomentsResidentKernel(
+__global__ __launch_bounds__(kStepThreads) void finalizeMomentsResidentKernel(
     const double *partials, int grid, const AffineBasis *__restrict__ d_basis, double *result,
-    LmControl *control, PeerCombine pc, const LmProblem P, int own_index) {
+    LmControl *control, const PeerCombine pc, const LmProblem P, int own_index) {
+#ifdef MOPT_LM_TIMING
+  const unsigned long long tick_entry = wall_clock64();
+#endif
   if (control->done) return;
+#ifdef MOPT_LM_TIMING
+  const unsigned long long tick_control = wall_clock64();
+#endif
   using S = typename StepScalar<STEP>::type;
-  unsigned int state_word = 0;
-  if constexpr (STEP != 0) state_word = lmPrefetchState<S>(P);
-  // the basis is requested now and parked in LDS after the partial rows have been requested too
+  LmStateWords state_words = {0u, 0u};
+  if constexpr (STEP != 0) state_words = lmPrefetchState<S>(P);
+  // the basis is requested now and parked in LDS once the partial rows have been requested too
+  // (columnTotals' hook): one round trip for state, basis and rows together
   constexpr int kBasisDoubles = int(sizeof(AffineBasis) / sizeof(double));
-  const double basis_value = int(threadIdx.x) < kBasisDoubles
-                                 ? reinterpret_cast<const double *>(d_basis)[threadIdx.x]
-                                 : 0.0;
+  const double basis_value = reinterpret_cast<const double *>(
+      d_basis)[int(threadIdx.x) < kBasisDoubles ? int(threadIdx.x) : 0];  // unconditional: no wait
   __shared__ AffineBasis B;
   __shared__ double own[kSlotData];
-  if (int(threadIdx.x) < kBasisDoubles) reinterpret_cast<double *>(&B)[threadIdx.x] = basis_value;
-  __syncthreads();
-  pc.sequence += (unsigned long long)control->trial;
-  const unsigned long long status =
-      finalizeMomentsBody(partials, grid, B, result, HostPublish(), pc, own);
+  const auto park_basis = [&]() {
+    if (int(threadIdx.x) < kBasisDoubles) reinterpret_cast<double *>(&B)[threadIdx.x] = basis_value;
+  };
+#ifdef MOPT_LM_TIMING
+  const unsigned long long tick_basis = wall_clock64();
+#endif
+  const unsigned long long status = finalizeMomentsBody<kStepThreads>(
+      partials, grid, B, result, HostPublish(), pc, own, park_basis,
+      (unsigned long long)control->trial);
   if (status && threadIdx.x == 0) control->pad[0] = int(status);
+#ifdef MOPT_LM_TIMING
+  if (threadIdx.x == 0)
+    printf("finalize: control word %llu, basis + state in LDS %llu, sums contracted %llu (x10 ns)\n",
+           tick_control - tick_entry, tick_basis - tick_control, wall_clock64() - tick_basis);
+#endif
   if constexpr (STEP != 0) {
     __syncthreads();
-    lmStepBody<S>(P, false, LmStart<S>(), own, own_index, true, state_word);
+    lmStepBody<S>(P, false, LmStart<S>(), own, own_index, true, state_words);
   }
 }
 
@@ -1616,7 +1689,7 @@ hipError_t launchFinalizeDenseResident(const double *partials, int grid, int nac
   if (n < 1 || n > kMaxWideParams || (nacc != n * (n + 1) / 2 + n + 1 && nacc != n * n + n + 1))
     return hipErrorInvalidValue;
   const PeerCombine pc = peers ? *peers : PeerCombine();
-  const dim3 g(1), b(kFinalThreads);
+  const dim3 g(1), b(kStepThreads);
   if (!step)
     hipLaunchKernelGGL(finalizeDenseResidentKernel<0>, g, b, 0, stream, partials, grid, nacc, n,
                        result, control, pc, LmProblem(), 0);
@@ -1635,7 +1708,7 @@ hipError_t launchFinalizeMomentsResident(const double *partials, int grid,
                                          const PeerCombine *peers, const LmProblem *step,
                                          int own_index, int scalar_bytes) {
   const PeerCombine pc = peers ? *peers : PeerCombine();
-  const dim3 g(1), b(kFinalThreads);
+  const dim3 g(1), b(kStepThreads);
   if (!step)
     hipLaunchKernelGGL(finalizeMomentsResidentKernel<0>, g, b, 0, stream, partials, grid, d_basis,
                        result, control, pc, LmProblem(), 0);
