@@ -64,13 +64,17 @@ enum FdRotationHome : int { kFdRotationLds = 0, kFdRotationRegisters = 1 };
 template <typename S, bool STREAMING, int COV, int HOME>
 __device__ __forceinline__ void p2pForwardDiffBody(const S *tiles, int num_tiles,
                                                    const P2PSweepArgs<S> &A, int block,
-                                                   int num_blocks) {
+                                                   int num_blocks,
+                                                   const P2PSweepArgs<S> &in_memory) {
   constexpr int V = TileShape<S>::kVec;
   constexpr int NACC = (COV == kCovGeneral) ? kAccFull : kAccSym;
   __shared__ S Rlds[3][12];  // [c][a * 3 + k] = R(x + h_{3+c} e_{3+c})(a, k); 9 of 12 used
   if (threadIdx.x < 27) {
+    // the one access indexed by lane: from the arguments where they lie in memory (kernel
+    // arguments, or the resident forms' block in HBM) — indexing a by-value copy by lane puts the
+    // whole 840-byte struct into every lane's scratch
     const int c = threadIdx.x / 9, ak = threadIdx.x % 9;
-    Rlds[c][ak] = A.T[4 + c][(ak / 3) * 4 + ak % 3];
+    Rlds[c][ak] = in_memory.T[4 + c][(ak / 3) * 4 + ak % 3];
   }
   __syncthreads();
   S Rreg[3][9];
@@ -236,16 +240,21 @@ __device__ __forceinline__ void p2pForwardDiffBody(const S *tiles, int num_tiles
 template <typename S, bool STREAMING, int COV, int HOME>
 __global__ __launch_bounds__(kBlockThreads) void p2pForwardDiffKernel(const S *tiles, int num_tiles,
                                                                       const P2PSweepArgs<S> A) {
-  p2pForwardDiffBody<S, STREAMING, COV, HOME>(tiles, num_tiles, A, blockIdx.x, gridDim.x);
+  p2pForwardDiffBody<S, STREAMING, COV, HOME>(tiles, num_tiles, A, blockIdx.x, gridDim.x, A);
 }
+
+// the rotation entries' home as in launchForwardDiff
+template <typename S, int COV>
+constexpr int kFdHomeFor = (sizeof(S) == 8 && COV != kCovGeneral) ? int(kFdRotationRegisters)
+                                                                  : int(kFdRotationLds);
 
 template <typename S, bool STREAMING, int COV>
 __global__ __launch_bounds__(kBlockThreads) void p2pForwardDiffResidentArgsKernel(
     const P2PSweepArgs<S> *__restrict__ d_args, const LmControl *__restrict__ control) {
   if (control->done) return;
   const P2PSweepArgs<S> A = *d_args;
-  p2pForwardDiffBody<S, STREAMING, COV, kFdRotationLds>(A.tiles, A.num_tiles, A, blockIdx.x,
-                                                        gridDim.x);
+  p2pForwardDiffBody<S, STREAMING, COV, kFdHomeFor<S, COV>>(A.tiles, A.num_tiles, A, blockIdx.x,
+                                                            gridDim.x, *d_args);
 }
 
 // several forward-difference costs of one problem in one launch (workgroups [first_block[k],
@@ -255,10 +264,11 @@ __global__ __launch_bounds__(kBlockThreads) void p2pForwardDiffResidentSetKernel
     const ResidentSweepSet set, const LmControl *__restrict__ control) {
   if (control->done) return;
   const int k = costOfBlock(set);
-  const P2PSweepArgs<S> A = *static_cast<const P2PSweepArgs<S> *>(set.args[k]);
-  p2pForwardDiffBody<S, STREAMING, COV, kFdRotationLds>(
+  const P2PSweepArgs<S> *d_args = static_cast<const P2PSweepArgs<S> *>(set.args[k]);
+  const P2PSweepArgs<S> A = *d_args;
+  p2pForwardDiffBody<S, STREAMING, COV, kFdHomeFor<S, COV>>(
       A.tiles, A.num_tiles, A, int(blockIdx.x) - set.first_block[k],
-      set.first_block[k + 1] - set.first_block[k]);
+      set.first_block[k + 1] - set.first_block[k], *d_args);
 }
 
 }  // namespace
