@@ -219,7 +219,10 @@ MOPT_API int mopt_scalar_model_create(mopt_cost **out, int device, int scalar_by
  * (host memory, or device memory with MOPT_INPUT_DEVICE); copied once.  Everything else (loss,
  * covariance, numeric differentiation with the reference's step, the returned unweighted cost,
  * speculation, async calls, communicators) is that of the built-in models.  A body that does not
- * compile returns MOPT_ERR_INVALID_ARGUMENT with the compiler log in mopt_last_error(). */
+ * compile returns MOPT_ERR_INVALID_ARGUMENT with the compiler log in mopt_last_error().  With
+ * MOPT_JIT_DUMP_DIR=<dir> in the environment every compiled code object is also written to
+ * <dir>/mopt_jit_n<n>_m<m>_s<bytes>_mode<k>_cov<c>[_wide].co (for llvm-objdump / llvm-readelf
+ * --notes: the registers, spills and scratch a model's sweep came out with). */
 MOPT_API int mopt_jit_model_create(mopt_cost **out, int device, int scalar_bytes, int n_params,
                                    int n_outputs, int n_planes, int n_aux, const char *setup_body,
                                    const char *residual_body, const char *jacobian_body,

@@ -18,6 +18,7 @@
 #include <hip/hiprtc.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -534,6 +535,18 @@ bool compileVariant(JitKernel &k, int mode, int cov_mode, JitVariant &out) {
   std::vector<char> code(code_size);
   hiprtcGetCode(prog, code.data());
   hiprtcDestroyProgram(&prog);
+  // MOPT_JIT_DUMP_DIR=<dir>: keep every compiled code object (n, m, mode, covariance form in the
+  // name) for llvm-objdump / llvm-readelf --notes — register counts, spills, scratch of a model
+  if (const char *dir = getenv("MOPT_JIT_DUMP_DIR")) {
+    const std::string path = std::string(dir) + "/mopt_jit_n" + std::to_string(k.n_params) + "_m" +
+                             std::to_string(k.n_outputs) + "_s" + std::to_string(k.scalar_bytes) +
+                             "_mode" + std::to_string(mode) + "_cov" + std::to_string(cov_mode) +
+                             (k.wide ? "_wide" : "") + ".co";
+    if (FILE *f = fopen(path.c_str(), "wb")) {
+      fwrite(code.data(), 1, code.size(), f);
+      fclose(f);
+    }
+  }
   if (hipModuleLoadData(&out.module, code.data()) != hipSuccess) {
     jitError() = "hipModuleLoadData failed for the compiled model";
     return false;
