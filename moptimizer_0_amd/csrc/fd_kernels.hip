@@ -59,7 +59,9 @@ __device__ __forceinline__ void accDot3(double &acc, const S (&a)[3], const S (&
 //                         in LDS — 30 reads per point — that return path, not the VALU, set the pace
 //                         at 88-97 us for 10 M points)
 //   kFdRotationRegisters  54 VGPRs per lane, loaded once
-enum FdRotationHome : int { kFdRotationLds = 0, kFdRotationRegisters = 1 };
+//   kFdRotationMixed      two of the three perturbed rotations in registers (36 VGPRs), the third
+//                         re-read from LDS: what fits next to the 43 accumulators of the general form
+enum FdRotationHome : int { kFdRotationLds = 0, kFdRotationRegisters = 1, kFdRotationMixed = 2 };
 
 template <typename S, bool STREAMING, int COV, int HOME>
 __device__ __forceinline__ void p2pForwardDiffBody(const S *tiles, int num_tiles,
@@ -77,13 +79,14 @@ __device__ __forceinline__ void p2pForwardDiffBody(const S *tiles, int num_tiles
     Rlds[c][ak] = in_memory.T[4 + c][(ak / 3) * 4 + ak % 3];
   }
   __syncthreads();
-  S Rreg[3][9];
-  if constexpr (HOME == kFdRotationRegisters) {
+  // kFdRotationMixed: the first two perturbed rotations in registers (36 VGPRs), the third re-read
+  // from LDS — for the general covariance form, whose 43 accumulators leave no room for all three
+  constexpr int kInRegs = HOME == kFdRotationRegisters ? 3 : (HOME == kFdRotationMixed ? 2 : 0);
+  S Rreg[kInRegs ? kInRegs : 1][9];
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+  for (int c = 0; c < kInRegs; ++c)
 #pragma unroll
-      for (int k = 0; k < 9; ++k) Rreg[c][k] = Rlds[c][k];
-  }
+    for (int k = 0; k < 9; ++k) Rreg[c][k] = Rlds[c][k];
 
   double acc[NACC];
 #pragma unroll
@@ -116,9 +119,9 @@ __device__ __forceinline__ void p2pForwardDiffBody(const S *tiles, int num_tiles
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       S Rc[9];
-      if constexpr (HOME == kFdRotationRegisters) {
+      if (c < kInRegs) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) Rc[k] = Rreg[c][k];
+        for (int k = 0; k < 9; ++k) Rc[k] = Rreg[c < kInRegs ? c : 0][k];
       } else {
         asm volatile("" ::: "memory");  // from LDS here, not from registers kept alive
 #pragma unroll
@@ -245,8 +248,9 @@ __global__ __launch_bounds__(kBlockThreads) void p2pForwardDiffKernel(const S *t
 
 // the rotation entries' home as in launchForwardDiff
 template <typename S, int COV>
-constexpr int kFdHomeFor = (sizeof(S) == 8 && COV != kCovGeneral) ? int(kFdRotationRegisters)
-                                                                  : int(kFdRotationLds);
+constexpr int kFdHomeFor = sizeof(S) == 8 ? (COV != kCovGeneral ? int(kFdRotationRegisters)
+                                                                : int(kFdRotationMixed))
+                                          : int(kFdRotationLds);
 
 template <typename S, bool STREAMING, int COV>
 __global__ __launch_bounds__(kBlockThreads) void p2pForwardDiffResidentArgsKernel(
@@ -277,23 +281,23 @@ template <typename S>
 hipError_t launchForwardDiff(const P2PSweepArgs<S> &args, int cov_mode, int grid,
                              const LaunchSite &site) {
   // fp64: identity / symmetric covariance leave room for the 54 VGPRs (206 / 220 in all: two waves
-  // per SIMD either way); the general form (43 accumulators) and fp32 (whose LDS reads are half the
-  // size) re-read from LDS.  MOPT_FD_ROTATION_HOME=0|1 overrides (tuning).
+  // per SIMD either way); the general form (43 accumulators) for 36 of them (244: the third perturbed
+  // rotation re-read from LDS; 106 -> 101 us at 10 M); fp32 (whose LDS reads are half the size)
+  // re-reads everything from LDS.  MOPT_FD_ROTATION_HOME=0|1|2 overrides (tuning).
   static const int forced = [] {
     const char *e = getenv("MOPT_FD_ROTATION_HOME");
     return e ? atoi(e) : -1;
   }();
-  const int home = forced >= 0 ? forced
-                               : ((sizeof(S) == 8 && cov_mode != kCovGeneral) ? int(kFdRotationRegisters)
-                                                                              : int(kFdRotationLds));
-#define MOPT_LAUNCH_FD(COV)                                                                        \
-  (home == kFdRotationRegisters                                                                    \
-       ? (site.streaming                                                                           \
-              ? launchTiled(p2pForwardDiffKernel<S, true, COV, kFdRotationRegisters>, grid, site, args)  \
-              : launchTiled(p2pForwardDiffKernel<S, false, COV, kFdRotationRegisters>, grid, site, args)) \
-       : (site.streaming                                                                           \
-              ? launchTiled(p2pForwardDiffKernel<S, true, COV, kFdRotationLds>, grid, site, args)  \
-              : launchTiled(p2pForwardDiffKernel<S, false, COV, kFdRotationLds>, grid, site, args)))
+  const int home = forced >= 0 ? forced : (sizeof(S) == 8 ? (cov_mode != kCovGeneral ? int(kFdRotationRegisters)
+                                                                                   : int(kFdRotationMixed))
+                                                          : int(kFdRotationLds));
+#define MOPT_LAUNCH_FD_HOME(COV, HOME)                                                        \
+  (site.streaming ? launchTiled(p2pForwardDiffKernel<S, true, COV, HOME>, grid, site, args)      \
+                  : launchTiled(p2pForwardDiffKernel<S, false, COV, HOME>, grid, site, args))
+#define MOPT_LAUNCH_FD(COV)                                                                      \
+  (home == kFdRotationRegisters ? MOPT_LAUNCH_FD_HOME(COV, kFdRotationRegisters)                 \
+   : home == kFdRotationMixed   ? MOPT_LAUNCH_FD_HOME(COV, kFdRotationMixed)                     \
+                                : MOPT_LAUNCH_FD_HOME(COV, kFdRotationLds))
   switch (cov_mode) {
     case kCovIdentity:
       return MOPT_LAUNCH_FD(kCovIdentity);
@@ -303,6 +307,7 @@ hipError_t launchForwardDiff(const P2PSweepArgs<S> &args, int cov_mode, int grid
       return MOPT_LAUNCH_FD(kCovGeneral);
   }
 #undef MOPT_LAUNCH_FD
+#undef MOPT_LAUNCH_FD_HOME
 }
 template hipError_t launchForwardDiff<float>(const P2PSweepArgs<float> &, int, int, const LaunchSite &);
 template hipError_t launchForwardDiff<double>(const P2PSweepArgs<double> &, int, int,
