@@ -60,8 +60,10 @@ __device__ __forceinline__ void accDot3(double &acc, const S (&a)[3], const S (&
 //                         at 88-97 us for 10 M points)
 //   kFdRotationRegisters  54 VGPRs per lane, loaded once
 //   kFdRotationMixed      two of the three perturbed rotations in registers (36 VGPRs), the third
-//                         re-read from LDS: what fits next to the 43 accumulators of the general form
-enum FdRotationHome : int { kFdRotationLds = 0, kFdRotationRegisters = 1, kFdRotationMixed = 2 };
+//                         re-read from LDS
+//   kFdRotationMixedPlus  + six of the third one's nine entries: 256 VGPRs, what fits next to the 43
+//                         accumulators of the general form at two waves per SIMD
+enum FdRotationHome : int { kFdRotationLds = 0, kFdRotationRegisters = 1, kFdRotationMixed = 2, kFdRotationMixedPlus = 3 };
 
 template <typename S, bool STREAMING, int COV, int HOME>
 __device__ __forceinline__ void p2pForwardDiffBody(const S *tiles, int num_tiles,
@@ -81,12 +83,17 @@ __device__ __forceinline__ void p2pForwardDiffBody(const S *tiles, int num_tiles
   __syncthreads();
   // kFdRotationMixed: the first two perturbed rotations in registers (36 VGPRs), the third re-read
   // from LDS — for the general covariance form, whose 43 accumulators leave no room for all three
-  constexpr int kInRegs = HOME == kFdRotationRegisters ? 3 : (HOME == kFdRotationMixed ? 2 : 0);
+  constexpr int kInRegs = HOME == kFdRotationRegisters ? 3 : (HOME >= kFdRotationMixed ? 2 : 0);
+  // kFdRotationMixedPlus: + the first kExtra entries of the third rotation
+  constexpr int kExtra = HOME == kFdRotationMixedPlus ? 6 : 0;
   S Rreg[kInRegs ? kInRegs : 1][9];
+  S Rextra[kExtra ? kExtra : 1];
 #pragma unroll
   for (int c = 0; c < kInRegs; ++c)
 #pragma unroll
     for (int k = 0; k < 9; ++k) Rreg[c][k] = Rlds[c][k];
+#pragma unroll
+  for (int k = 0; k < kExtra; ++k) Rextra[k] = Rlds[2][k];
 
   double acc[NACC];
 #pragma unroll
@@ -125,7 +132,7 @@ __device__ __forceinline__ void p2pForwardDiffBody(const S *tiles, int num_tiles
       } else {
         asm volatile("" ::: "memory");  // from LDS here, not from registers kept alive
 #pragma unroll
-        for (int k = 0; k < 9; ++k) Rc[k] = Rlds[c][k];
+        for (int k = 0; k < 9; ++k) Rc[k] = (k < kExtra) ? Rextra[k < kExtra ? k : 0] : Rlds[c][k];
       }
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
@@ -249,7 +256,7 @@ __global__ __launch_bounds__(kBlockThreads) void p2pForwardDiffKernel(const S *t
 // the rotation entries' home as in launchForwardDiff
 template <typename S, int COV>
 constexpr int kFdHomeFor = sizeof(S) == 8 ? (COV != kCovGeneral ? int(kFdRotationRegisters)
-                                                                : int(kFdRotationMixed))
+                                                                : int(kFdRotationMixedPlus))
                                           : int(kFdRotationLds);
 
 template <typename S, bool STREAMING, int COV>
@@ -281,15 +288,16 @@ template <typename S>
 hipError_t launchForwardDiff(const P2PSweepArgs<S> &args, int cov_mode, int grid,
                              const LaunchSite &site) {
   // fp64: identity / symmetric covariance leave room for the 54 VGPRs (206 / 220 in all: two waves
-  // per SIMD either way); the general form (43 accumulators) for 36 of them (244: the third perturbed
-  // rotation re-read from LDS; 106 -> 101 us at 10 M); fp32 (whose LDS reads are half the size)
-  // re-reads everything from LDS.  MOPT_FD_ROTATION_HOME=0|1|2 overrides (tuning).
+  // per SIMD either way); the general form (43 accumulators) for 48 of them (256: three entries of
+  // the third perturbed rotation re-read from LDS; all from LDS 106 us at 10 M, two rotations in
+  // registers 100.5-101.3, this 99.5); fp32 (whose LDS reads are half the size) re-reads everything
+  // from LDS.  MOPT_FD_ROTATION_HOME=0|1|2|3 overrides (tuning).
   static const int forced = [] {
     const char *e = getenv("MOPT_FD_ROTATION_HOME");
     return e ? atoi(e) : -1;
   }();
   const int home = forced >= 0 ? forced : (sizeof(S) == 8 ? (cov_mode != kCovGeneral ? int(kFdRotationRegisters)
-                                                                                   : int(kFdRotationMixed))
+                                                                                   : int(kFdRotationMixedPlus))
                                                           : int(kFdRotationLds));
 #define MOPT_LAUNCH_FD_HOME(COV, HOME)                                                        \
   (site.streaming ? launchTiled(p2pForwardDiffKernel<S, true, COV, HOME>, grid, site, args)      \
@@ -297,6 +305,7 @@ hipError_t launchForwardDiff(const P2PSweepArgs<S> &args, int cov_mode, int grid
 #define MOPT_LAUNCH_FD(COV)                                                                      \
   (home == kFdRotationRegisters ? MOPT_LAUNCH_FD_HOME(COV, kFdRotationRegisters)                 \
    : home == kFdRotationMixed   ? MOPT_LAUNCH_FD_HOME(COV, kFdRotationMixed)                     \
+   : home == kFdRotationMixedPlus ? MOPT_LAUNCH_FD_HOME(COV, kFdRotationMixedPlus)               \
                                 : MOPT_LAUNCH_FD_HOME(COV, kFdRotationLds))
   switch (cov_mode) {
     case kCovIdentity:
