@@ -39,6 +39,9 @@ typedef MOPT_S S;
 #define COVSYM (COV != 2)    /* S symmetric -> H symmetric, upper triangle only */
 #define NH (COVSYM ? N * (N + 1) / 2 : N * N)
 #define NACC (MODE == 0 ? 1 : NH + N + 1)
+/* forward differences, fp64 (two elements per pack), per-x values in LDS, a small Jacobian: the two
+   elements of a pack evaluated side by side (sweep_elements) */
+#define PAIRED (MODE == 2 && MOPT_S_BYTES == 8 && AUX > 0 && M * N <= 18)
 
 struct JitArgs {
   const S *data;       // planes: data[p * stride + i]
@@ -132,44 +135,16 @@ __device__ inline void sweep_elements(const JitArgs &A, const S *aux, double (&a
 #pragma unroll
   for (int j = 0; j < N; ++j) inv_h[j] = S(1) / A.h[j];
 #endif
-  // one element: residual, Jacobian (supplied or by forward differences), loss weight, the sums
-  auto element = [&](const S (&d)[D > 0 ? D : 1], bool valid) {
-    // the per-x values stay in LDS: without this the compiler keeps all (N + 1) * AUX of them in
-    // registers across the loop
-    asm volatile("" ::: "memory");
-    S r[M];
-    user_residual(A.x, aux, d, r);
-    S rr = 0;
-#pragma unroll
-    for (int a = 0; a < M; ++a) rr += r[a] * r[a];
-    rr = valid ? rr : S(0);
-#if MODE == 0
-    acc[0] += (double)rr;
-#else
-    S J[M * N];  // row-major, as IBaseModel::f_df fills it
-#if MODE == 2
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-      S xp[N];
-#pragma unroll
-      for (int k = 0; k < N; ++k) xp[k] = A.x[k];
-      xp[j] += A.h[j];                                   // linearization.h:89
-      asm volatile("" ::: "memory");                     // fetch this vector's per-x values now
-      S rp[M];
-      user_residual(xp, aux + (1 + j) * AUX, d, rp);
-#pragma unroll
-      for (int a = 0; a < M; ++a) J[a * N + j] = (rp[a] - r[a]) * inv_h[j];   // :105
-    }
-#else
-    user_jacobian(A.x, aux, d, J);
-#endif
+#if MODE != 0
+  // w J^T S J, w J^T S r, r^T r of one element into the sums (linearization.h:113-115, :150-152)
+  auto accumulate = [&](const S (&r)[M], S rr, const S (&J)[M * N], bool valid) {
     S w = 1;
     if (Loss::value) {
       const S den = rr + A.loss_param;
       w = (A.loss_param * A.loss_param) / (den * den);
     }
     w = valid ? w : S(0);
-    // w J^T S J, w J^T S r (linearization.h:113-115, :150-152); under the identity covariance S J is J
+    // under the identity covariance S J is J
     S wJ[M * N];
 #pragma unroll
     for (int q = 0; q < M * N; ++q) wJ[q] = w * J[q];
@@ -201,8 +176,87 @@ __device__ inline void sweep_elements(const JitArgs &A, const S *aux, double (&a
 #pragma unroll
     for (int i2 = 0; i2 < N; ++i2) acc_dot(acc[NH + i2], wJ + i2, N, Sr, 1);
     acc[NH + N] += (double)rr;
+  };
+#endif
+  // one element: residual, Jacobian (supplied or by forward differences), loss weight, the sums
+  auto element = [&](const S (&d)[D > 0 ? D : 1], bool valid) {
+    // the per-x values stay in LDS: without this the compiler keeps all (N + 1) * AUX of them in
+    // registers across the loop
+    asm volatile("" ::: "memory");
+    S r[M];
+    user_residual(A.x, aux, d, r);
+    S rr = 0;
+#pragma unroll
+    for (int a = 0; a < M; ++a) rr += r[a] * r[a];
+    rr = valid ? rr : S(0);
+#if MODE == 0
+    acc[0] += (double)rr;
+#else
+    S J[M * N];  // row-major, as IBaseModel::f_df fills it
+#if MODE == 2
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      S xp[N];
+#pragma unroll
+      for (int k = 0; k < N; ++k) xp[k] = A.x[k];
+      xp[j] += A.h[j];                                   // linearization.h:89
+      asm volatile("" ::: "memory");                     // fetch this vector's per-x values now
+      S rp[M];
+      user_residual(xp, aux + (1 + j) * AUX, d, rp);
+#pragma unroll
+      for (int a = 0; a < M; ++a) J[a * N + j] = (rp[a] - r[a]) * inv_h[j];   // :105
+    }
+#else
+    user_jacobian(A.x, aux, d, J);
+#endif
+    accumulate(r, rr, J, valid);
 #endif
   };
+#if PAIRED
+  // Forward differences over a model with per-x values (setup output): every evaluation of the
+  // residual reads its parameter vector's values from LDS, all lanes the same address — and such a
+  // read still returns 1 KiB to the wave, so (N + 1) * AUX of them per element set the pace (the
+  // point2point model written as a user model: 84 values, 143 us for 10 M elements).  The two
+  // elements of a lane's pack are therefore evaluated side by side, parameter vector by parameter
+  // vector, on one read of the values; their Jacobians are live together (2 M N registers more),
+  // which is why this form is kept to small M N.
+  auto element_pair = [&](const S (&d0)[D > 0 ? D : 1], const S (&d1)[D > 0 ? D : 1], bool valid0,
+                          bool valid1) {
+    asm volatile("" ::: "memory");
+    S r0[M], r1[M];
+    user_residual(A.x, aux, d0, r0);
+    user_residual(A.x, aux, d1, r1);
+    S rr0 = 0, rr1 = 0;
+#pragma unroll
+    for (int a = 0; a < M; ++a) {
+      rr0 += r0[a] * r0[a];
+      rr1 += r1[a] * r1[a];
+    }
+    rr0 = valid0 ? rr0 : S(0);
+    rr1 = valid1 ? rr1 : S(0);
+    S J0[M * N], J1[M * N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      S xp[N];
+#pragma unroll
+      for (int k = 0; k < N; ++k) xp[k] = A.x[k];
+      xp[j] += A.h[j];                                   // linearization.h:89
+      asm volatile("" ::: "memory");                     // fetch this vector's per-x values now
+      S rp0[M], rp1[M];
+      user_residual(xp, aux + (1 + j) * AUX, d0, rp0);
+      user_residual(xp, aux + (1 + j) * AUX, d1, rp1);
+#pragma unroll
+      for (int a = 0; a < M; ++a) {
+        J0[a * N + j] = (rp0[a] - r0[a]) * inv_h[j];   // :105
+        J1[a * N + j] = (rp1[a] - r1[a]) * inv_h[j];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    accumulate(r0, rr0, J0, valid0);
+    __builtin_amdgcn_sched_barrier(0);
+    accumulate(r1, rr1, J1, valid1);
+  };
+#endif
 
   const long long step = (long long)num_blocks * kBlock * VEC;
   long long i = ((long long)block * kBlock + threadIdx.x) * VEC;
@@ -235,6 +289,19 @@ __device__ inline void sweep_elements(const JitArgs &A, const S *aux, double (&a
         for (int k = 1; k < VEC; ++k) d[p] = (valid && e == k) ? cur[p].v[k] : d[p];
       }
       element(d, valid);
+    }
+#elif PAIRED
+    {
+      const bool valid1 = i + 1 < A.count;
+      S d0[D > 0 ? D : 1], d1[D > 0 ? D : 1];
+#pragma unroll
+      for (int p = 0; p < D; ++p) {
+        d0[p] = cur[p].v[0];
+        d1[p] = valid1 ? cur[p].v[1] : cur[p].v[0];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      element_pair(d0, d1, true, valid1);
+      __builtin_amdgcn_sched_barrier(0);
     }
 #else
 #pragma unroll
