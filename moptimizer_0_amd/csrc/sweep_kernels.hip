@@ -875,7 +875,7 @@ __device__ __forceinline__ double columnBatch(const double *partials, int t, int
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const int idx = t + k * stride;
-    at[k] = idx < total_elems ? idx : t;
+    at[k] = idx < total_elems ? idx : 0;  // (row 0 exists whatever the grid)
   }
   __builtin_amdgcn_sched_barrier(0);
   double v[K];
