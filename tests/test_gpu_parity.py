@@ -168,6 +168,28 @@ def test_ragged_sizes(hip_lib, oracle, n):
     assert abs(c - want) <= REL * abs(want)
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 1023, 1025, 4097, 30_011])
+def test_ragged_sizes_float32_forward_differences(hip_lib, oracle, n):
+    """The fp32 forward-difference sweep takes the four points of a pack as two pairs in packed
+    arithmetic: counts that end inside a pair or a pack, under the identity and a symmetric
+    covariance (the paired forms) and a general one (the per-point loop), against the reference's
+    float arithmetic (oracle run in float)."""
+    src, tgt = ds.synthetic_pair(n, seed=n + 7, noise=0.02, dtype=np.float32)
+    x = np.array([0.5, -0.3, 0.2, 0.1, -0.2, 0.3], dtype=np.float32)
+    cost = hip_lib.Point2PointCost(src, tgt, dtype=np.float32)
+    cost.set_kernel_variant(hip_lib.KERNEL_LITERAL)
+    covs = (None, np.array([[2.0, 0.3, -0.1], [0.3, 0.5, 0.2], [-0.1, 0.2, 1.5]], dtype=np.float32),
+            np.array([[2.0, 0.7, -0.1], [0.3, 0.5, 0.9], [-0.4, 0.2, 1.5]], dtype=np.float32))
+    for cov in covs:
+        cost.set_covariance(cov)
+        for loss in ((0, 0.0), (1, 100.0)):
+            cost.set_loss(*loss)
+            want = oracle.p2p_linearize(src, tgt, x, cost_class=ob.NUMERIC_DYN, layout=ob.LAYOUT_ROW_MAJOR,
+                                        loss_kind=loss[0], loss_param=loss[1], cov=cov, dtype=np.float32)
+            check(cost.linearize(x, 2), tuple(np.asarray(v, dtype=np.float64) for v in want), tol=2e-3)
+    cost.close()
+
+
 def test_p2p_100k_all_modes(hip_lib, oracle):
     src, tgt = ds.synthetic_pair(100_000, seed=3, noise=0.02)
     cost = hip_lib.Point2PointCost(src, tgt)
