@@ -56,8 +56,12 @@ __device__ __forceinline__ PointPair keepValid(PairValid valid, PointPair x) {
   return PointPair{valid.a ? x.x : 0.0f, valid.b ? x.y : 0.0f};
 }
 // c * a + b with a scalar constant c
-__device__ __forceinline__ double fmaConst(double c, double a, double b) { return __builtin_fma(c, a, b); }
-__device__ __forceinline__ float fmaConst(float c, float a, float b) { return __builtin_fmaf(c, a, b); }
+__device__ __forceinline__ double fmaConst(double c, double a, double b) {
+  return __builtin_fma(c, a, b);
+}
+__device__ __forceinline__ float fmaConst(float c, float a, float b) {
+  return __builtin_fmaf(c, a, b);
+}
 __device__ __forceinline__ PointPair fmaConst(float c, PointPair a, PointPair b) {
   return __builtin_elementwise_fma(PointPair{c, c}, a, b);
 }
@@ -66,8 +70,11 @@ __device__ __forceinline__ PointPair fmaConst(float c, PointPair a, PointPair b)
 // reference's float instantiation does, and the running sum is fp64 — or, where the sums are formed
 // in fp32 first (a `float` or PointPair accumulator, below), one fp32 FMA
 template <typename Acc, typename X>
+constexpr bool kPairInto = __is_same(Acc, PointPair) && __is_same(X, PointPair);
+
+template <typename Acc, typename X>
 __device__ __forceinline__ void accFma(Acc &acc, X a, X b) {
-  if constexpr (sizeof(Acc) == sizeof(PointPair) && sizeof(X) == sizeof(PointPair) && !__is_same(X, double))
+  if constexpr (kPairInto<Acc, X>)
     acc = __builtin_elementwise_fma(a, b, acc);
   else if constexpr (sizeof(Acc) == 4)
     acc = __builtin_fmaf(a, b, acc);
@@ -78,7 +85,7 @@ __device__ __forceinline__ void accFma(Acc &acc, X a, X b) {
 }
 template <typename Acc, typename X>
 __device__ __forceinline__ void accDot3(Acc &acc, const X (&a)[3], const X (&b)[3]) {
-  if constexpr (sizeof(Acc) == sizeof(PointPair) && sizeof(X) == sizeof(PointPair) && !__is_same(X, double)) {
+  if constexpr (kPairInto<Acc, X>) {
     acc = __builtin_elementwise_fma(
         a[2], b[2], __builtin_elementwise_fma(a[1], b[1], __builtin_elementwise_fma(a[0], b[0], acc)));
   } else if constexpr (sizeof(Acc) == 4) {
@@ -104,7 +111,12 @@ __device__ __forceinline__ void accDot3(Acc &acc, const X (&a)[3], const X (&b)[
 //                         re-read from LDS
 //   kFdRotationMixedPlus  + six of the third one's nine entries: 256 VGPRs, what fits next to the 43
 //                         accumulators of the general form at two waves per SIMD
-enum FdRotationHome : int { kFdRotationLds = 0, kFdRotationRegisters = 1, kFdRotationMixed = 2, kFdRotationMixedPlus = 3 };
+enum FdRotationHome : int {
+  kFdRotationLds = 0,
+  kFdRotationRegisters = 1,
+  kFdRotationMixed = 2,
+  kFdRotationMixedPlus = 3
+};
 
 template <typename S, bool STREAMING, int COV, int HOME>
 __device__ __forceinline__ void p2pForwardDiffBody(const S *tiles, int num_tiles,
@@ -218,8 +230,9 @@ __device__ __forceinline__ void p2pForwardDiffBody(const S *tiles, int num_tiles
       for (int a = 0; a < 3; ++a) {
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-          wSA[c][a] = w * fmaConst(A.cov[a * 3 + 2], Acol[c][2],
-                                   fmaConst(A.cov[a * 3 + 1], Acol[c][1], A.cov[a * 3 + 0] * Acol[c][0]));
+          wSA[c][a] =
+              w * fmaConst(A.cov[a * 3 + 2], Acol[c][2],
+                           fmaConst(A.cov[a * 3 + 1], Acol[c][1], A.cov[a * 3 + 0] * Acol[c][0]));
 #pragma unroll
         for (int j = 0; j < 3; ++j) Swd[j][a] = A.cov[a * 3 + j] * wd[j];  // S(a, j) w d_j
         wSr[a] = fmaConst(A.cov[a * 3 + 2], wr[2],
@@ -279,10 +292,10 @@ __device__ __forceinline__ void p2pForwardDiffBody(const S *tiles, int num_tiles
 #pragma unroll
           for (int half = 0; half < 2; ++half) {
             __builtin_amdgcn_sched_barrier(0);  // one pair after the other
-            const PointPair in[6] = {
-                PointPair{cur[0].v[2 * half], cur[0].v[2 * half + 1]}, PointPair{cur[1].v[2 * half], cur[1].v[2 * half + 1]},
-                PointPair{cur[2].v[2 * half], cur[2].v[2 * half + 1]}, PointPair{cur[3].v[2 * half], cur[3].v[2 * half + 1]},
-                PointPair{cur[4].v[2 * half], cur[4].v[2 * half + 1]}, PointPair{cur[5].v[2 * half], cur[5].v[2 * half + 1]}};
+            PointPair in[6];
+#pragma unroll
+            for (int pl = 0; pl < 6; ++pl)
+              in[pl] = PointPair{cur[pl].v[2 * half], cur[pl].v[2 * half + 1]};
             point(robust, in, first + 2 * half, pair_sums);
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -364,9 +377,10 @@ hipError_t launchForwardDiff(const P2PSweepArgs<S> &args, int cov_mode, int grid
     const char *e = getenv("MOPT_FD_ROTATION_HOME");
     return e ? atoi(e) : -1;
   }();
-  const int home = forced >= 0 ? forced : (sizeof(S) == 8 ? (cov_mode != kCovGeneral ? int(kFdRotationRegisters)
-                                                                                   : int(kFdRotationMixedPlus))
-                                                          : int(kFdRotationLds));
+  const int by_form = sizeof(S) == 8 ? (cov_mode != kCovGeneral ? int(kFdRotationRegisters)
+                                                                : int(kFdRotationMixedPlus))
+                                     : int(kFdRotationLds);
+  const int home = forced >= 0 ? forced : by_form;
 #define MOPT_LAUNCH_FD_HOME(COV, HOME)                                                        \
   (site.streaming ? launchTiled(p2pForwardDiffKernel<S, true, COV, HOME>, grid, site, args)      \
                   : launchTiled(p2pForwardDiffKernel<S, false, COV, HOME>, grid, site, args))
