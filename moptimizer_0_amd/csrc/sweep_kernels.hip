@@ -50,9 +50,12 @@ struct P2PJacobianPattern {
 // acc += w J^T S J (upper triangle, or all n*n entries when S is not symmetric), w J^T S r, r^T r.
 // J is m x n (row index = output), cov row-major m x m.  NACC selects the n*n form.  In fp64 every
 // sum is a chain of fused multiply-adds straight into its accumulator.
-template <typename S, int M, int N, int COV, typename Pattern = DensePattern, int NACC>
+// `Acc`: double, or float where the caller adds the points of a pack in fp32 first and promotes
+// their sum (the fp32 point-to-point sweep: a conversion and an fp64 add per entry and point
+// otherwise).
+template <typename S, int M, int N, int COV, typename Pattern = DensePattern, typename Acc, int NACC>
 __device__ __forceinline__ void accumulateDense(const S (&J)[M][N], const S (&r)[M], S w, S rr,
-                                                const S *cov, double (&acc)[NACC]) {
+                                                const S *cov, Acc (&acc)[NACC]) {
   S SJ[M][N];
   S Sr[M];
   if (COV == kCovIdentity) {
@@ -89,8 +92,11 @@ __device__ __forceinline__ void accumulateDense(const S (&J)[M][N], const S (&r)
   constexpr int kNH = kFull ? N * N : N * (N + 1) / 2;
   static_assert(NACC == kNH + N + 1, "accumulator count does not match the matrix form");
   // (S J)(a, j) is structurally zero only under the identity covariance
-  auto term = [&](double &dst, S &partial, S x, S y) {
-    if constexpr (sizeof(S) == 8)
+  constexpr bool kDirect = sizeof(S) == 8 || sizeof(Acc) == 4;  // one FMA per term into acc
+  auto term = [&](Acc &dst, S &partial, S x, S y) {
+    if constexpr (sizeof(Acc) == 4)
+      dst = __builtin_fmaf(x, y, dst);
+    else if constexpr (sizeof(S) == 8)
       dst = __builtin_fma(double(x), double(y), dst);
     else
       partial += x * y;
@@ -109,7 +115,7 @@ __device__ __forceinline__ void accumulateDense(const S (&J)[M][N], const S (&r)
         term(acc[k], partial, wJ[a][i], SJ[a][j]);
         any = true;
       }
-      if (sizeof(S) == 4 && any) acc[k] += double(partial);
+      if (!kDirect && any) acc[k] += double(partial);
     }
   }
 #pragma unroll
@@ -120,16 +126,16 @@ __device__ __forceinline__ void accumulateDense(const S (&J)[M][N], const S (&r)
       if (Pattern::zero(a, i)) continue;
       term(acc[kNH + i], partial, wJ[a][i], Sr[a]);
     }
-    if (sizeof(S) == 4) acc[kNH + i] += double(partial);
+    if (!kDirect) acc[kNH + i] += double(partial);
   }
-  acc[kNH + N] += double(rr);
+  acc[kNH + N] += Acc(rr);
 }
 
 // ---- point-to-point, literal evaluation ------------------------------------------------------
-template <typename S, int JAC, int COV>
+template <typename S, int JAC, int COV, typename Acc>
 __device__ __forceinline__ void p2pPointLiteral(
     const P2PSweepArgs<S> &A, const S (&p)[3], const S (&q)[3], bool valid,
-    double (&acc)[(COV == kCovGeneral) ? kAccFull : kAccSym]) {
+    Acc (&acc)[(COV == kCovGeneral) ? kAccFull : kAccSym]) {
   S r[3];
   p2pResidual<S>(A.T[0], p, q, r);
   S J[3][6];
@@ -198,13 +204,27 @@ __device__ __forceinline__ void p2pLinearizeLiteralBody(const P2PSweepArgs<S> &A
 #pragma unroll
   for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
 
+  // fp32: the four points of a pack are added in fp32 and their sums promoted once per pack
+  using Local = typename std::conditional<sizeof(S) == 8, double, float>::type;
   sweepTiles<S, STREAMING>(A.tiles, A.num_tiles, [&](const Pack<S>(&cur)[6], long long first) {
+    Local loc[sizeof(S) == 8 ? 1 : NACC];
+    if constexpr (sizeof(S) == 4) {
+#pragma unroll
+      for (int k = 0; k < NACC; ++k) loc[k] = 0.0f;
+    }
 #pragma unroll
     for (int e = 0; e < V; ++e) {
       const S p[3] = {cur[0].v[e], cur[1].v[e], cur[2].v[e]};
       const bool ok = isCorrespondence(first + e, A.count, cur[3].v[e]);
       const S q[3] = {ok ? cur[3].v[e] : S(0), ok ? cur[4].v[e] : S(0), ok ? cur[5].v[e] : S(0)};
-      p2pPointLiteral<S, JAC, COV>(A, p, q, ok, acc);
+      if constexpr (sizeof(S) == 8)
+        p2pPointLiteral<S, JAC, COV>(A, p, q, ok, acc);
+      else
+        p2pPointLiteral<S, JAC, COV>(A, p, q, ok, loc);
+    }
+    if constexpr (sizeof(S) == 4) {
+#pragma unroll
+      for (int k = 0; k < NACC; ++k) acc[k] += double(loc[k]);
     }
   }, block, num_blocks);
   blockReduceStore<NACC>(acc, A.partials + size_t(block) * NACC);
