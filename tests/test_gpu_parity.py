@@ -776,6 +776,21 @@ P2P_JIT_JACOBIAN = """
 """
 
 
+def test_jit_code_objects_can_be_kept(hip_lib, tmp_path, monkeypatch):
+    """MOPT_JIT_DUMP_DIR keeps every compiled sweep as a gfx950 code object (moptimizer_hip.h,
+    mopt_jit_model_create): one per sweep kind and covariance form actually used."""
+    monkeypatch.setenv("MOPT_JIT_DUMP_DIR", str(tmp_path))
+    t = np.linspace(0.0, 1.0, 300)
+    jit = hip_lib.JitModelCost(2, 1, "r[0] = d[1] - exp(x[0] * d[0] + x[1]);",
+                               planes=np.stack([t, np.exp(0.3 * t)]))
+    jit.linearize(np.array([0.1, 0.0]), 2)
+    jit.close()
+    kept = sorted(f.name for f in tmp_path.iterdir())
+    assert "mopt_jit_n2_m1_s8_mode0_cov0.co" in kept and "mopt_jit_n2_m1_s8_mode2_cov0.co" in kept, kept
+    for name in kept:
+        assert (tmp_path / name).read_bytes()[:4] == b"\x7fELF", name
+
+
 def test_jit_model_with_setup_reproduces_point2point(hip_lib, oracle):
     """The path's own model written by a user: setup(x) builds [R | t] once per parameter vector
     (and per forward-difference vector) as tst/point2point.cpp:31 does, residual and Jacobian are
