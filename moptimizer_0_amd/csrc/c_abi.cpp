@@ -369,7 +369,7 @@ int reprojLinearizeAsync(mopt_cost *c, int jac_mode, const double *x, double *d_
   fillReprojArgs(c, x, true, args);
   const int grid = gridFor(c, blocksPerCu(2));
   const int nacc = c->cov_mode == mopt::kCovGeneral ? mopt::kAccFull : mopt::kAccSym;
-  SweepTimer timer(c, s);
+  SweepTimer timer(c, s, true);
   MOPT_HIP_TRY(mopt::launchReprojLinearize(args, c->cov_mode, grid, timer.site));
   timer.stop();
   MOPT_HIP_TRY(
@@ -382,7 +382,7 @@ int reprojCostAsync(mopt_cost *c, const double *x, double *d_sum, hipStream_t s,
   mopt::ReprojSweepArgs args;
   fillReprojArgs(c, x, false, args);
   const int grid = gridFor(c, blocksPerCu(2));
-  SweepTimer timer(c, s);
+  SweepTimer timer(c, s, true);
   MOPT_HIP_TRY(mopt::launchReprojCost(args, grid, timer.site));
   timer.stop();
   MOPT_HIP_TRY(mopt::launchFinalizeCost(c->d_partials, grid, d_sum, pub, s, c->launch_peers));
@@ -945,7 +945,12 @@ bool residentSetSupported(mopt_cost *const *costs, int num_costs, const int *jac
         if (c->scalar_model != first->scalar_model) return false;
         break;
       case kModelJit:
-        if (c->jit.wide || c->jit.source != first->jit.source) return false;
+        // the shape reaches the compiler as -D options, not as source text: two costs with the same
+        // bodies and another m, plane or aux count are different kernels
+        if (c->jit.wide || c->jit.source != first->jit.source ||
+            c->jit.n_params != first->jit.n_params || c->jit.n_outputs != first->jit.n_outputs ||
+            c->jit.n_planes != first->jit.n_planes || c->jit.n_aux != first->jit.n_aux)
+          return false;
         break;
       default:
         return false;
@@ -1150,6 +1155,7 @@ int launchPublishedSweep(mopt_cost *c, bool cost_only, int jac_mode, const void 
 int waitPublishedSweep(mopt_cost *c, unsigned long long sequence) {
   return waitPublished(c, sequence);
 }
+
 mopt::HostPublish nextHostPublish(mopt_cost *c, int offset) { return nextPublish(c, offset); }
 int waitHostPublished(mopt_cost *c, unsigned long long sequence) { return waitPublished(c, sequence); }
 }  // namespace mopt_detail
@@ -1749,6 +1755,21 @@ bool computeRunsLinearization(const mopt_cost *c) {
   return c->speculate && c->last_jac_mode >= 0 && speculationPays(c);
 }
 
+// What a linked cost's own call at this x is going to want (as prefetchSiblings decides it): false
+// when nothing is to be queued for it.
+bool siblingWants(mopt_cost *s, bool linearize_call, const void *x, bool *cost_only, int *mode) {
+  *cost_only = false;
+  *mode = s->last_jac_mode;
+  if (linearize_call) {
+    if (*mode < 0 || (s->speculate && cacheMatches(s, x, *mode))) return false;
+  } else {
+    if (s->speculate && cacheMatches(s, x, -1)) return false;
+    *cost_only = !computeRunsLinearization(s);
+    if (*cost_only) *mode = 0;
+  }
+  return !prefetchMatches(s, x, *cost_only, *mode);  // (else already in flight)
+}
+
 // `c` has just been asked at x (`linearize_call`: for a linearization, else for a cost): queue for
 // every linked cost the sweep its own call at this x is going to want.  A guess that turns out
 // wrong costs one unused sweep; failures here are left for the sibling's own call to report.
@@ -1758,15 +1779,8 @@ void prefetchSiblings(mopt_cost *c, bool linearize_call, const void *x) {
         s->n_params != c->n_params)
       continue;
     bool cost_only = false;
-    int mode = s->last_jac_mode;
-    if (linearize_call) {
-      if (mode < 0 || (s->speculate && cacheMatches(s, x, mode))) continue;
-    } else {
-      if (s->speculate && cacheMatches(s, x, -1)) continue;
-      cost_only = !computeRunsLinearization(s);
-      if (cost_only) mode = 0;
-    }
-    if (prefetchMatches(s, x, cost_only, mode)) continue;  // already in flight
+    int mode = 0;
+    if (!siblingWants(s, linearize_call, x, &cost_only, &mode)) continue;
     if (hipSetDevice(s->device) != hipSuccess) continue;
     unsigned long long sequence = 0;
     if (launchPublishedSweep(s, cost_only, mode, x, &sequence) != MOPT_OK) {

@@ -132,7 +132,11 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
     row_offset[k + 1] = row_offset[k] + residentGrid(costs[k]);
     for (int j = 0; j < k; ++j) merged = merged && costs[j] != costs[k];
   }
-  merged = merged && row_offset[num_costs] <= last->max_grid;
+  // all rows must fit the last cost's buffer in doubles, not only in rows: a wide model's row is up
+  // to 273 values against the kPartialRowSlots the buffer is sized by
+  merged = merged && row_offset[num_costs] <= last->max_grid &&
+           size_t(row_offset[num_costs]) * size_t(row_length) <=
+               size_t(last->max_grid) * mopt_detail::kPartialRowSlots;
   problem.merged = merged ? 1 : 0;
   static const bool set_enabled = [] {  // MOPT_LM_SET=0: a sweep launch per cost (for comparison)
     const char *v = std::getenv("MOPT_LM_SET");

@@ -28,8 +28,8 @@ struct TileShape {
   static constexpr int kP2PScalars = kPoints * kP2PPlanes;
 };
 // Reprojection elements: planes px | py | pz | pw (fp64) followed by interleaved int32 (u, v)
-// pairs; 512 elements per tile, 20 KiB, 40 B per element.
-constexpr int kReprojTilePoints = kBlockThreads * 2;
+// pairs; 256 elements per tile — one per lane of a workgroup —, 10 KiB, 40 B per element.
+constexpr int kReprojTilePoints = kBlockThreads;
 constexpr int kReprojTileBytes = kReprojTilePoints * (4 * 8 + 2 * 4);
 
 enum JacMode : int { kJacAnalytic = 0, kJacAnalyticTst = 1, kJacNumeric = 2, kJacAnalyticLeft = 3,

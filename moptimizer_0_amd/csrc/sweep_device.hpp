@@ -12,6 +12,23 @@
 namespace mopt {
 namespace {
 
+// In-kernel time stamps for the diagnostic builds under scripts/probes/ (they define
+// MOPT_STAMP_WORDS and include a kernel source whole): wave 0 of a workgroup stores the 100 MHz
+// wall clock at point k into a buffer of its own that nothing else reads.  The library's build has
+// no stamp in it.
+#ifdef MOPT_STAMP_WORDS
+__device__ unsigned long long *g_stamp_buffer;
+#define MOPT_STAMP(k)                                                                              \
+  do {                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    if (threadIdx.x == 0)                                                                          \
+      g_stamp_buffer[size_t(blockIdx.x) * MOPT_STAMP_WORDS + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+  } while (0)
+#else
+#define MOPT_STAMP(k) ((void)0)
+#endif
+
 template <typename S>
 struct alignas(16) Pack {
   S v[16 / sizeof(S)];
@@ -125,15 +142,18 @@ __device__ __forceinline__ double waveSum(double v) {
 // (conflict-free ds_write_b64, row of 64 lanes per value, rows padded to 72 doubles so that four
 // consecutive value-rows tile the 64 banks), then thread (k, part) adds the 4 waves x 8 lanes of
 // value k whose lane index is = part (mod 8) and the 8 parts are combined with three xor
-// shuffles.  Order of additions is fixed, so the row is reproducible bit for bit.  Values are
-// processed in chunks of 23 to bound LDS at 53 KB per workgroup.
+// shuffles.  Order of additions is fixed, so the row is reproducible bit for bit.  Rows of up to 32
+// values (one per 8 threads of a 256-thread workgroup) go through in one pass — the 28 of a
+// symmetric linearization in 64.5 KB of LDS, one pair of barriers instead of two —, longer ones in
+// chunks of 23 (53 KB per workgroup).
 constexpr int kReduceChunk = 23;
+constexpr int kReduceOnePass = 32;
 constexpr int kReduceRow = 72;
 
-template <int NACC>
+template <int NACC, int THREADS = kBlockThreads>
 __device__ __forceinline__ void blockReduceStore(double (&acc)[NACC], double *out_row) {
-  constexpr int kWaves = kBlockThreads / 64;
-  constexpr int kChunk = NACC < kReduceChunk ? NACC : kReduceChunk;
+  constexpr int kWaves = THREADS / 64;
+  constexpr int kChunk = NACC <= kReduceOnePass ? NACC : kReduceChunk;
   constexpr int kPasses = (NACC + kChunk - 1) / kChunk;
   __shared__ double lds[kWaves][kChunk][kReduceRow];
   const int lane = threadIdx.x & 63;

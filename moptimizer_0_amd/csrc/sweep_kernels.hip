@@ -378,10 +378,6 @@ __global__ __launch_bounds__(kBlockThreads) void p2pCostKernel(const S *tiles, i
 }
 
 // ---- reprojection (camera calibration), fp64, forward differences ------------------------------
-struct alignas(16) Int4Pack {
-  int v[4];
-};
-
 __device__ __forceinline__ void reprojResidual(const double (&Mx)[12], const double (&P)[4],
                                                double u, double v, double (&r)[2]) {
   // as written, no fused multiply-adds: the CPU restatement evaluates the same four products and
@@ -396,56 +392,122 @@ __device__ __forceinline__ void reprojResidual(const double (&Mx)[12], const dou
   r[1] = v - (o[1] / o[2]);  // :39
 }
 
+// Seven 3x4 projections at x and x + h_j e_j are 84 fp64 constants: as kernel arguments they asked
+// for 180 scalar registers against ~100, and every reproj* linearize kernel spilled 128-148 of them
+// (v_readlane / v_writelane around each use; rounds 1-3).  As in fd_kernels.hip the six perturbed
+// projections live in LDS: 72 lanes copy them once per workgroup from where the arguments lie in
+// memory (`in_memory`: the kernel-argument segment, or the resident forms' block in HBM), and each is
+// read (same-address reads: broadcasts) while the one before it is being used.  The projection at x,
+// the step reciprocals, the covariance and the loss stay in scalar registers (~50).  The tile's loads
+// are issued before that copy, so the two latencies overlap.  Per element the arithmetic is the
+// reference's: seven residuals with both divisions each, twelve quotients (linearization.h:101-107),
+// contraction off.
+//
+// One element per lane, 256 per tile: the arithmetic of an element is one long dependent chain
+// (≈ 400 fp64 instructions, 14 divisions), so what a sweep of BASELINE config 5 costs is that chain
+// once per workgroup — with two elements per lane (tiles of 512, rounds 1-3) it ran twice, or
+// interleaved in > 300 registers; measured in one process (scripts/probes/reproj_stamps.cpp,
+// profiles/r4_reproj_forms.txt): 4.8 us per 40 k / 60 k elements against 5.7 (interleaved) and 6.1
+// (one after the other) where an empty launch of the same grid takes 4.2, and 134 against 138 and
+// 151 us at 4 M elements.
 // block / num_blocks: this workgroup's place among those sweeping this cost (a launch may carry
-// the workgroups of several costs: reprojResidentSetKernel)
+// the workgroups of several costs: reprojResidentSetKernel); the cost's partial rows are num_blocks.
 template <int COV, bool COST_ONLY>
-__device__ __forceinline__ void reprojBody(const ReprojSweepArgs &A, int block, int num_blocks) {
+__device__ __forceinline__ void reprojBody(const ReprojSweepArgs &A, int block, int num_blocks,
+                                           const ReprojSweepArgs &in_memory) {
   constexpr int NACC = COST_ONLY ? 1 : ((COV == kCovGeneral) ? kAccFull : kAccSym);
+  MOPT_STAMP(0);
+  __shared__ double Mlds[kNumParams][12];
   double acc[NACC];
 #pragma unroll
   for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
 
-  for (int tile = block; tile < A.num_tiles; tile += num_blocks) {
+  struct Element {
+    double P[4], u, v;
+  };
+  auto loadElement = [&](int tile) {
     const unsigned char *tb = A.tiles + size_t(tile) * kReprojTileBytes;
-    const double *planes = reinterpret_cast<const double *>(tb) + threadIdx.x * 2;
-    Pack<double> pk[4];
+    const double *planes = reinterpret_cast<const double *>(tb) + threadIdx.x;
+    const int2 px = reinterpret_cast<const int2 *>(tb + size_t(4) * kReprojTilePoints * 8)[threadIdx.x];
+    Element el;
 #pragma unroll
-    for (int pl = 0; pl < 4; ++pl) pk[pl] = loadPack<double>(planes + pl * kReprojTilePoints);
-    const Int4Pack px = *reinterpret_cast<const Int4Pack *>(
-        tb + size_t(4) * kReprojTilePoints * 8 + threadIdx.x * 16);
-    const long long first = (long long)tile * kReprojTilePoints + threadIdx.x * 2;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const double P[4] = {pk[0].v[e], pk[1].v[e], pk[2].v[e], pk[3].v[e]};
-      const double u = double(px.v[2 * e + 0]);
-      const double v = double(px.v[2 * e + 1]);
-      const bool valid = first + e < A.count;
+    for (int pl = 0; pl < 4; ++pl) el.P[pl] = planes[pl * kReprojTilePoints];
+    el.u = double(px.x);
+    el.v = double(px.y);
+    return el;
+  };
+
+  // this workgroup's tiles: block, block + num_blocks, ...; the next one is loaded before the
+  // arithmetic of the current one (unconditionally — past the end the last one again, an L2 hit:
+  // a conditional prefetch makes the compiler wait for everything at the join, sweep_device.hpp)
+  int tile = block;
+  const int last = tile < A.num_tiles ? tile + ((A.num_tiles - 1 - tile) / num_blocks) * num_blocks : tile;
+  Element el{};
+  if (tile < A.num_tiles) el = loadElement(tile);
+  if constexpr (!COST_ONLY) {
+    // the one access indexed by lane goes to memory, not to a by-value copy (which would put the
+    // whole struct into every lane's scratch)
+    if (threadIdx.x < kNumParams * 12) (&Mlds[0][0])[threadIdx.x] = (&in_memory.M[1][0])[threadIdx.x];
+    __syncthreads();
+  }
+  MOPT_STAMP(1);
+  // `robust`: the loss kind is taken out of the element (a branch inside splits the basic block, and
+  // the compiler then sinks the seven residuals below it, behind the LDS reads of all six projections)
+  auto sweep = [&](auto robust) {
+    for (; tile < A.num_tiles; tile += num_blocks) {
+      const bool valid = (long long)tile * kReprojTilePoints + threadIdx.x < A.count;
+      const Element nx = loadElement(tile + num_blocks <= last ? tile + num_blocks : last);
       double r[2];
-      reprojResidual(A.M[0], P, u, v, r);
+      reprojResidual(A.M[0], el.P, el.u, el.v, r);
       const double rr = r[0] * r[0] + r[1] * r[1];
+      MOPT_STAMP(2);
       if constexpr (COST_ONLY) {
         acc[0] += valid ? rr : 0.0;
       } else {
         double J[2][6];
+        // one perturbed projection after the other (all seven residuals interleaved need > 256
+        // registers), each read from LDS while the one before it is being used
+        double Mj[2][12];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
+        for (int k = 0; k < 12; ++k) Mj[0][k] = Mlds[0][k];
+#pragma unroll
+        for (int j = 0; j < kNumParams; ++j) {
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("" ::: "memory");  // read here, not hoisted into 144 registers
+          if (j + 1 < kNumParams) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) Mj[(j + 1) & 1][k] = Mlds[j + 1][k];
+          }
           double rp[2];
-          reprojResidual(A.M[1 + j], P, u, v, rp);
+          reprojResidual(Mj[j & 1], el.P, el.u, el.v, rp);
           J[0][j] = (rp[0] - r[0]) * A.inv_h[j];
           J[1][j] = (rp[1] - r[1]) * A.inv_h[j];
         }
-        const double w = lossWeight<double>(A.loss_kind, A.loss_param, rr);
-        // padded elements are all-zero points: o[2] = 0 gives inf/NaN, so mask by selection
-        if (valid) accumulateDense<double, 2, 6, COV>(J, r, w, rr, A.cov, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        MOPT_STAMP(3);
+        // padded slots repeat the last element (relayoutReprojKernel): finite, left out by w = 0 —
+        // a branch around the accumulation lets the compiler sink all seven residuals into it, behind
+        // the LDS reads of all six projections (144 registers)
+        double w = 1.0;
+        if constexpr (decltype(robust)::value) w = lossWeight<double>(kLossGemanMcClure, A.loss_param, rr);
+        accumulateDense<double, 2, 6, COV>(J, r, valid ? w : 0.0, valid ? rr : 0.0, A.cov, acc);
       }
+      MOPT_STAMP(4);
+      el = nx;
     }
-  }
+  };
+  if (!COST_ONLY && A.loss_kind == kLossGemanMcClure)
+    sweep(std::true_type());
+  else
+    sweep(std::false_type());
+  MOPT_STAMP(5);
   blockReduceStore<NACC>(acc, A.partials + size_t(block) * NACC);
+  MOPT_STAMP(6);
 }
 
 template <int COV, bool COST_ONLY>
 __global__ __launch_bounds__(kBlockThreads) void reprojKernel(const ReprojSweepArgs A) {
-  reprojBody<COV, COST_ONLY>(A, blockIdx.x, gridDim.x);
+  reprojBody<COV, COST_ONLY>(A, blockIdx.x, gridDim.x, A);
 }
 
 template <int COV>
@@ -453,20 +515,21 @@ __global__ __launch_bounds__(kBlockThreads) void reprojResidentKernel(
     const ReprojSweepArgs *__restrict__ d_args, const LmControl *__restrict__ control) {
   if (control->done) return;
   const ReprojSweepArgs A = *d_args;
-  reprojBody<COV, false>(A, blockIdx.x, gridDim.x);
+  reprojBody<COV, false>(A, blockIdx.x, gridDim.x, *d_args);
 }
 
-// The sweeps of several reprojection costs of one problem in one launch: workgroups
-// [first_block[k], first_block[k + 1]) sweep cost k.  Each cost alone fills part of the chip
-// (100 k elements: 196 tiles), behind one another they would also pay a launch boundary each.
+// The sweeps of several reprojection costs of one problem in one launch (device-resident LM):
+// workgroups [first_block[k], first_block[k + 1]) sweep cost k.  Each cost alone fills part of the
+// chip, behind one another they would also pay a launch boundary each.
 template <int COV>
 __global__ __launch_bounds__(kBlockThreads) void reprojResidentSetKernel(
     const ResidentSweepSet set, const LmControl *__restrict__ control) {
   if (control->done) return;
   const int k = costOfBlock(set);
-  const ReprojSweepArgs A = *static_cast<const ReprojSweepArgs *>(set.args[k]);
+  const ReprojSweepArgs *d_args = static_cast<const ReprojSweepArgs *>(set.args[k]);
+  const ReprojSweepArgs A = *d_args;
   reprojBody<COV, false>(A, int(blockIdx.x) - set.first_block[k],
-                         set.first_block[k + 1] - set.first_block[k]);
+                         set.first_block[k + 1] - set.first_block[k], *d_args);
 }
 
 // ---- small parametric models over per-element scalar data ------------------------------------
@@ -779,11 +842,14 @@ __global__ void relayoutReprojKernel(const double *__restrict__ pts, const int *
   unsigned char *tb = tiles + tile * kReprojTileBytes;
   double *planes = reinterpret_cast<double *>(tb);
   int *pixels = reinterpret_cast<int *>(tb + size_t(4) * kReprojTilePoints * 8);
-  const bool valid = i < count;
+  // the tail of the last tile repeats the last element: whatever the sweep computes for a padded slot
+  // is then as finite as for a real one, and a weight of zero is enough to leave it out (an all-zero
+  // point projects to 0 / 0)
+  const long long from = i < count ? i : count - 1;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) planes[k * kReprojTilePoints + within] = valid ? pts[4 * i + k] : 0.0;
-  pixels[2 * within + 0] = valid ? pix[2 * i + 0] : 0;
-  pixels[2 * within + 1] = valid ? pix[2 * i + 1] : 0;
+  for (int k = 0; k < 4; ++k) planes[k * kReprojTilePoints + within] = pts[4 * from + k];
+  pixels[2 * within + 0] = pix[2 * from + 0];
+  pixels[2 * within + 1] = pix[2 * from + 1];
 }
 
 // ---- finalisation: workgroup partials -> H | b | sum_sq -----------------------------------------
@@ -902,9 +968,13 @@ __device__ __forceinline__ double columnBatch(const double *partials, int t, int
 #pragma unroll
   for (int k = 0; k < K; ++k) v[k] = partials[at[k]];
   __builtin_amdgcn_sched_barrier(0);
+  // (the comparisons again from a laundered copy of t: left to itself the compiler keeps the K lane
+  // masks of the first round alive across the loads — 2 K scalar registers, spilled from K = 32 on)
+  int t_again = t;
+  asm volatile("" : "+v"(t_again));
   double s[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int k = 0; k < K; ++k) s[k & 3] += (t + k * stride) < total_elems ? v[k] : 0.0;
+  for (int k = 0; k < K; ++k) s[k & 3] += (t_again + k * stride) < total_elems ? v[k] : 0.0;
   return (s[0] + s[1]) + (s[2] + s[3]);
 }
 
@@ -1181,10 +1251,8 @@ __global__ __launch_bounds__(kStepThreads) void finalizeMomentsResidentKernel(
   }
 }
 
-__global__ __launch_bounds__(kFinalThreads) void finalizeCostKernel(const double *partials,
-                                                                     int grid, double *result,
-                                                                     const HostPublish pub,
-                                                                     const PeerCombine pc) {
+__device__ __forceinline__ void finalizeCostBody(const double *partials, int grid, double *result,
+                                                 const HostPublish &pub, const PeerCombine &pc) {
   __shared__ double lds[kFinalThreads / 64];
   double s = 0.0;
   for (int row = threadIdx.x; row < grid; row += kFinalThreads) s += partials[row];
@@ -1202,6 +1270,13 @@ __global__ __launch_bounds__(kFinalThreads) void finalizeCostKernel(const double
   const double v = peerCombine(pc, 1, lds[0], &status);
   if (threadIdx.x == 0) result[0] = v;
   publishToHost(pub, 1, v, status);
+}
+
+__global__ __launch_bounds__(kFinalThreads) void finalizeCostKernel(const double *partials,
+                                                                     int grid, double *result,
+                                                                     const HostPublish pub,
+                                                                     const PeerCombine pc) {
+  finalizeCostBody(partials, grid, result, pub, pc);
 }
 
 __global__ void publishKernel(const double *values, int count, const HostPublish pub) {
@@ -1241,7 +1316,11 @@ hipError_t launchRelayoutReproj(const double *points_xyzw, const int32_t *pixels
 namespace {
 template <typename Kernel, typename Args>
 hipError_t launchSweep(Kernel kernel, int grid, const LaunchSite &site, const Args &args) {
-  hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlockThreads), 0, site.stream, args);
+  if (site.time_start && site.time_stop)
+    hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(kBlockThreads), 0, site.stream, site.time_start,
+                          site.time_stop, 0, args);
+  else
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlockThreads), 0, site.stream, args);
   return hipGetLastError();
 }
 
