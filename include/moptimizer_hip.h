@@ -166,13 +166,6 @@ MOPT_API int mopt_icp_create(mopt_cost **out, int device, int scalar_bytes, cons
                              int64_t num_src, const void *tgt_xyz, int64_t num_tgt,
                              double max_distance);
 MOPT_API int mopt_icp_update(mopt_cost *cost, const void *x, int64_t *num_matched /* may be NULL */);
-/* How the last mopt_icp_update that counted its matches (num_matched != NULL) ran: workgroups (256
- * sources each) that copied the box of grid cells around their sources into LDS by coalesced loads and
- * searched it there — the streaming form, taken while the pose keeps a workgroup's sources within a
- * box of at most 64 rows / 1408 targets —, and workgroups in all; the others gathered cell by cell from
- * HBM.  The results are the same bit for bit. */
-MOPT_API int mopt_icp_search_stats(const mopt_cost *cost, int64_t *staged_workgroups,
-                                   int64_t *workgroups);
 /* current target of every source as packed xyz (NaN triple where unmatched); host buffer of
  * num_src * 3 scalars.  Works for any point2point cost. */
 MOPT_API int mopt_icp_get_matches(mopt_cost *cost, void *tgt_out_xyz);

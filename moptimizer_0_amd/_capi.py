@@ -73,8 +73,6 @@ def load():
         "mopt_icp_create": [c_void_pp, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64,
                             ctypes.c_void_p, ctypes.c_int64, ctypes.c_double],
         "mopt_icp_update": [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)],
-        "mopt_icp_search_stats": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64),
-                                  ctypes.POINTER(ctypes.c_int64)],
         "mopt_icp_get_matches": [ctypes.c_void_p, ctypes.c_void_p],
         "mopt_reprojection_create": [c_void_pp, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
@@ -461,12 +459,6 @@ class IcpCost(Point2PointCost):
         n = ctypes.c_int64(-1)
         check(load().mopt_icp_update(self._h, _ptr(x), ctypes.byref(n) if count_matches else None))
         return n.value
-
-    def search_stats(self):
-        """(workgroups that searched from LDS, workgroups in all) of the last counted update."""
-        staged, total = ctypes.c_int64(0), ctypes.c_int64(0)
-        check(load().mopt_icp_search_stats(self._h, ctypes.byref(staged), ctypes.byref(total)))
-        return staged.value, total.value
 
     def matches(self):
         out = np.zeros((self.count, 3), dtype=_dtype_of(self.scalar_bytes))

@@ -64,13 +64,9 @@ struct IcpMatcher {
   int dims[3] = {1, 1, 1};
   double max_dist = 0.0;
   long long num_targets = 0;
-  // Sources are stored in the order of the grid cells of their un-warped position, brick by brick
-  // (4 x 4 x 4 cells), so that the points of a search workgroup fill a compact box of the grid;
-  // slot k of the tiles holds the caller's source order[k].
+  // Sources are stored in grid-cell order (of their un-warped position) so that neighbouring
+  // lanes visit neighbouring cells; slot k of the tiles holds the caller's source order[k].
   std::vector<long long> order;
-  // of the last mopt_icp_update that counted its matches: workgroups that searched their box from
-  // LDS (the streaming form), and workgroups in all
-  long long last_staged_groups = 0, last_groups = 0;
 };
 
 // How the sums of a sharded cost are added over the ranks (MOPT_COMBINE_* of the header).

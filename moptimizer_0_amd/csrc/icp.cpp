@@ -55,17 +55,16 @@ int buildIcpGrid(const S *src, long long n, const S *tgt, long long m, double ma
   MOPT_HIP_TRY(hipMemsetAsync(g.d_matched, 0, 64, s));  // every search leaves it at zero again
   MOPT_HIP_TRY(d_perm_t.alloc(size_t(m) * sizeof(int)));
   MOPT_HIP_TRY(mopt::icpSortByCell<S>(d_tgt.as<S>(), m, g.origin, g.cell, g.dims, d_perm_t.as<int>(),
-                                      g.d_cell_start, false, s));
+                                      g.d_cell_start, s));
   if (m > 0) {
     MOPT_HIP_TRY(deviceAlloc(&g.d_sorted, size_t(m) * 4 * sizeof(S)));
     MOPT_HIP_TRY(mopt::icpGatherPoints<S>(d_tgt.as<S>(), d_perm_t.as<int>(), m,
                                           static_cast<S *>(g.d_sorted), true, s));
   }
-  // the sources in the order of the cells of their un-warped position, brick by brick (4 x 4 x 4
-  // cells): the 256 points of a search workgroup then fill a compact box of the grid
+  // the sources in the cell order of their un-warped position
   MOPT_HIP_TRY(d_perm_s.alloc(size_t(n) * sizeof(int)));
   MOPT_HIP_TRY(mopt::icpSortByCell<S>(d_src.as<S>(), n, g.origin, g.cell, g.dims, d_perm_s.as<int>(),
-                                      nullptr, true, s));
+                                      nullptr, s));
   MOPT_HIP_TRY(d_src_sorted.alloc(size_t(n) * 3 * sizeof(S)));
   MOPT_HIP_TRY(mopt::icpGatherPoints<S>(d_src.as<S>(), d_perm_s.as<int>(), n, d_src_sorted.as<S>(),
                                         false, s));
@@ -99,8 +98,6 @@ void fillIcpArgs(const mopt_cost *c, mopt::IcpMatchArgs<S> &a) {
   a.max_dist2 = S(mt.max_dist * mt.max_dist);
   for (int k = 0; k < 12; ++k) a.T[k] = S(k % 5 == 0 ? 1 : 0);
   a.matched = nullptr;
-  static const int debug_stage = envInt("MOPT_ICP_DEBUG_STAGE", 0);
-  a.debug_stage = debug_stage;
 }
 template void fillIcpArgs<float>(const mopt_cost *, mopt::IcpMatchArgs<float> &);
 template void fillIcpArgs<double>(const mopt_cost *, mopt::IcpMatchArgs<double> &);
@@ -109,7 +106,7 @@ template void fillIcpArgs<double>(const mopt_cost *, mopt::IcpMatchArgs<double> 
 namespace {
 template <typename S>
 int icpUpdate(mopt_cost *c, const S *x, int64_t *num_matched) {
-  IcpMatcher &mt = *c->matcher;
+  const IcpMatcher &mt = *c->matcher;
   mopt::IcpMatchArgs<S> a;
   fillIcpArgs<S>(c, a);
   const auto T = moptimizer::so3::rigidFrom6DOF<S>(x);
@@ -121,14 +118,12 @@ int icpUpdate(mopt_cost *c, const S *x, int64_t *num_matched) {
   if (num_matched) {
     // the count comes back like a sweep result: a one-wave kernel stores it into mapped host
     // memory and releases a sequence word — no memset, no copy, no stream synchronisation
-    const int slot = mopt_detail::kResultSlots - 2;  // beyond any n*n + n + 1 <= 273
+    const int slot = mopt_detail::kResultSlots - 1;  // beyond any n*n + n + 1 <= 73
     const mopt::HostPublish pub = nextHostPublish(c, slot);
     MOPT_HIP_TRY(mopt::launchPublishCounter(mt.d_matched, pub, c->stream));
     const int rc = waitHostPublished(c, pub.sequence);
     if (rc != MOPT_OK) return rc;
     *num_matched = int64_t(c->h_result[slot]);
-    c->matcher->last_staged_groups = (long long)c->h_result[slot + 1];
-    c->matcher->last_groups = ((long long)c->num_tiles * mopt::TileShape<S>::kPoints) / mopt::kBlockThreads;
   }
   return MOPT_OK;
 }
@@ -195,14 +190,6 @@ int mopt_icp_update(mopt_cost *c, const void *x, int64_t *num_matched) {
   MOPT_HIP_TRY(hipSetDevice(c->device));
   return c->scalar_bytes == 8 ? icpUpdate<double>(c, static_cast<const double *>(x), num_matched)
                               : icpUpdate<float>(c, static_cast<const float *>(x), num_matched);
-}
-
-int mopt_icp_search_stats(const mopt_cost *c, int64_t *staged_workgroups, int64_t *workgroups) {
-  if (!c) return fail(MOPT_ERR_INVALID_ARGUMENT, "cost is NULL");
-  if (!c->matcher) return fail(MOPT_ERR_INVALID_ARGUMENT, "not a cost made by mopt_icp_create");
-  if (staged_workgroups) *staged_workgroups = c->matcher->last_staged_groups;
-  if (workgroups) *workgroups = c->matcher->last_groups;
-  return MOPT_OK;
 }
 
 int mopt_icp_get_matches(mopt_cost *c, void *tgt_out_xyz) {

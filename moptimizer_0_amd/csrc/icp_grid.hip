@@ -69,31 +69,22 @@ struct GridShape {
   int dims[3];
 };
 
-// cell id of every point (clamped into the grid).  BRICKS: the key orders the cells brick by brick
-// (4 x 4 x 4 cells, bricks and the cells inside them both x fastest) instead of row by row, so that
-// consecutive points fill compact boxes — the order of the sources, whose workgroups stage the box of
-// cells around their 256 points in LDS (icpMatchBody); the targets stay row-major: a row of a box is
-// then one contiguous range.
-template <typename S, bool BRICKS>
+// cell id of every point (clamped into the grid)
+template <typename S>
 __global__ __launch_bounds__(kBlockThreads) void cellKeyKernel(const S *xyz, long long m,
                                                                const GridShape g,
                                                                unsigned int *keys) {
   const long long i = (long long)blockIdx.x * kBlockThreads + threadIdx.x;
   if (i >= m) return;
-  int c[3];
+  long long id = 0, stride = 1;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    double v = floor((double(xyz[3 * i + a]) - g.origin[a]) / g.cell);
-    v = v < 0.0 ? 0.0 : (v >= double(g.dims[a]) ? double(g.dims[a] - 1) : v);
-    c[a] = int(v);
+    double c = floor((double(xyz[3 * i + a]) - g.origin[a]) / g.cell);
+    c = c < 0.0 ? 0.0 : (c >= double(g.dims[a]) ? double(g.dims[a] - 1) : c);
+    id += (long long)c * stride;
+    stride *= g.dims[a];
   }
-  if (BRICKS) {
-    const long long bx = (g.dims[0] + 3) >> 2, by = (g.dims[1] + 3) >> 2;
-    const long long brick = ((long long)(c[2] >> 2) * by + (c[1] >> 2)) * bx + (c[0] >> 2);
-    keys[i] = (unsigned int)(brick * 64 + ((c[2] & 3) * 4 + (c[1] & 3)) * 4 + (c[0] & 3));
-  } else {
-    keys[i] = (unsigned int)(((long long)c[2] * g.dims[1] + c[1]) * g.dims[0] + c[0]);
-  }
+  keys[i] = (unsigned int)id;
 }
 
 // ---- stable LSD radix sort of (cell id, point index) pairs, 8 bits per pass --------------------
@@ -291,8 +282,7 @@ hipError_t icpBoundingBox(const S *d_xyz, long long m, double lo[3], double hi[3
 
 template <typename S>
 hipError_t icpSortByCell(const S *d_xyz, long long m, const double origin[3], double cell,
-                         const int dims[3], int *d_perm, int *d_cell_start, bool brick_order,
-                         hipStream_t stream) {
+                         const int dims[3], int *d_perm, int *d_cell_start, hipStream_t stream) {
   long long ncells = 1;
   GridShape g;
   for (int a = 0; a < 3; ++a) {
@@ -308,12 +298,8 @@ hipError_t icpSortByCell(const S *d_xyz, long long m, const double origin[3], do
   }
   // scratch: two key buffers, one value buffer (the other one is d_perm) and the histogram table
   const int num_groups = int((m + kSortTile - 1) / kSortTile);
-  // keys: cell ids, or brick-major ids over the grid padded to whole bricks (<= 2^22 cells: 32 bits do)
-  long long num_keys = ncells;
-  if (brick_order)
-    num_keys = (long long)((dims[0] + 3) >> 2) * ((dims[1] + 3) >> 2) * ((dims[2] + 3) >> 2) * 64;
   int bits = 1;
-  while ((1ll << bits) < num_keys) ++bits;
+  while ((1ll << bits) < ncells) ++bits;
   const int passes = (bits + 7) / 8;
   const long long table = (long long)kDigits * num_groups;  // (digit, workgroup) counters
   const int scan_tiles = int((table + kScanTile - 1) / kScanTile);
@@ -338,12 +324,8 @@ hipError_t icpSortByCell(const S *d_xyz, long long m, const double origin[3], do
     release();
     return e;
   }
-  if (brick_order)
-    hipLaunchKernelGGL((cellKeyKernel<S, true>), dim3(blocksFor(m)), dim3(kBlockThreads), 0, stream,
-                       d_xyz, m, g, keys);
-  else
-    hipLaunchKernelGGL((cellKeyKernel<S, false>), dim3(blocksFor(m)), dim3(kBlockThreads), 0, stream,
-                       d_xyz, m, g, keys);
+  hipLaunchKernelGGL(cellKeyKernel<S>, dim3(blocksFor(m)), dim3(kBlockThreads), 0, stream, d_xyz, m,
+                     g, keys);
   const unsigned int *keys_in = keys;
   unsigned int *keys_out = keys_alt;
   const int *values_in = nullptr;  // pass 1: value i = index i
@@ -367,7 +349,7 @@ hipError_t icpSortByCell(const S *d_xyz, long long m, const double origin[3], do
   }
   const unsigned int *keys_sorted = keys_in;
   e = hipGetLastError();
-  if (e == hipSuccess && d_cell_start && !brick_order) {
+  if (e == hipSuccess && d_cell_start) {
     hipLaunchKernelGGL(cellStartKernel, dim3(blocksFor(ncells + 1)), dim3(kBlockThreads), 0, stream,
                        keys_sorted, m, int(ncells), d_cell_start);
     e = hipGetLastError();
@@ -393,7 +375,7 @@ hipError_t icpGatherPoints(const S *d_xyz, const int *d_perm, long long m, S *d_
 #define MOPT_INSTANTIATE_GRID(S)                                                                  \
   template hipError_t icpBoundingBox<S>(const S *, long long, double[3], double[3], hipStream_t); \
   template hipError_t icpSortByCell<S>(const S *, long long, const double[3], double,             \
-                                       const int[3], int *, int *, bool, hipStream_t);            \
+                                       const int[3], int *, int *, hipStream_t);                  \
   template hipError_t icpGatherPoints<S>(const S *, const int *, long long, S *, bool, hipStream_t);
 MOPT_INSTANTIATE_GRID(double)
 MOPT_INSTANTIATE_GRID(float)

@@ -109,8 +109,7 @@ struct IcpMatchArgs {
   int dims[3];
   S max_dist2;
   S T[12];                // row-major [R | t] applied to the source before the search
-  unsigned int *matched;  // optional counters: [0] matched sources, [1] workgroups searched from LDS
-  int debug_stage;        // 0; timing ablations stop a workgroup early (results are then garbage)
+  unsigned int *matched;  // optional counter of matched sources
 };
 
 // Where a sweep kernel is launched.
@@ -350,17 +349,15 @@ hipError_t launchGatherTargets(const S *tiles, long long count, S *out_xyz, hipS
 // Grid construction for the search (icp_grid.hip).  All pointers are device memory.
 //   icpBoundingBox   min / max of m packed points (synchronises the stream)
 //   icpSortByCell    d_perm[k] = original index of the k-th point in (cell id, original index)
-//                    order; d_cell_start (optional) [cells + 1] offsets into that order;
-//                    brick_order: cells ordered in bricks of 4 x 4 x 4 instead of rows (the
-//                    sources' order; no offsets)  (synchronises the stream)
+//                    order; d_cell_start (optional) [cells + 1] offsets into that order
+//                    (synchronises the stream)
 //   icpGatherPoints  out[k] = xyz[d_perm[k]], packed (3) or padded to 4 scalars
 template <typename S>
 hipError_t icpBoundingBox(const S *d_xyz, long long m, double lo[3], double hi[3],
                           hipStream_t stream);
 template <typename S>
 hipError_t icpSortByCell(const S *d_xyz, long long m, const double origin[3], double cell,
-                         const int dims[3], int *d_perm, int *d_cell_start, bool brick_order,
-                         hipStream_t stream);
+                         const int dims[3], int *d_perm, int *d_cell_start, hipStream_t stream);
 template <typename S>
 hipError_t icpGatherPoints(const S *d_xyz, const int *d_perm, long long m, S *d_out, bool padded,
                            hipStream_t stream);

@@ -670,323 +670,116 @@ __global__ __launch_bounds__(kBlockThreads) void scalarModelResidentSetKernel(
 // model's update(x) (model.h:24-26; "setup can be i.e nearest neighboor search", docs/Cost.puml:14-17)
 // and ships no implementation, so semantics are defined here: exact nearest neighbour in the
 // Euclidean metric, ties resolved to the first candidate in (cell z, y, x; original index) order.
-//
-// Where the candidates come from is a policy of the search below:
-//   IcpGlobalCells  cell bounds and candidates gathered from HBM per lane (a chain of dependent
-//                   gathers: range -> candidates -> next row's bound; rounds 1-3)
-//   IcpStagedCells  the workgroup's box of grid cells copied into LDS first, by coalesced loads (the
-//                   streaming form, round 4): the sources are stored in bricks of 4 x 4 x 4 cells, so the
-//                   256 points of a workgroup fall into a compact box under any pose near the one they
-//                   were sorted at; every row of the box is one contiguous range of the cell-major
-//                   target array.  Boxes that do not fit the LDS image (a pose that rotates the
-//                   bricks far off the grid axes, the end of a brick row) take the gathered form.
-// Both give the same result bit for bit: same candidates, same comparisons, and positions inside the
-// box are in the order of the positions in the target array (rows by (z, y), cells by x).
-template <typename S>
-struct IcpGlobalCells {
-  const S *sorted;
-  const int *cell_start;
-  int dim_x, dim_y;
-  __device__ __forceinline__ void range(int y, int z, int xa, int xb, int &lo, int &hi) const {
-    const int row = (z * dim_y + y) * dim_x;  // the grid has at most 2^22 cells (icp.cpp)
-    lo = cell_start[row + xa];
-    hi = cell_start[row + xb + 1];
-  }
-  __device__ __forceinline__ void fetch(int k, S (&q)[3]) const {
-    const Pack<S> *cand = reinterpret_cast<const Pack<S> *>(sorted + size_t(k) * 4);
-    if (sizeof(S) == 8) {
-      const Pack<S> lo = cand[0], hi = cand[1];
-      q[0] = lo.v[0]; q[1] = lo.v[1]; q[2] = hi.v[0];
-    } else {
-      const Pack<S> all = cand[0];
-      q[0] = all.v[0]; q[1] = all.v[1]; q[2] = all.v[2];
-    }
-  }
-};
-
-// A workgroup's 256 sources come from about four bricks in a row: 16-20 x 4 x 4 cells, one more each
-// way once the pose has moved some of them across a cell face, and the margin: about 23 x 7 x 7.
-constexpr int kIcpMaxCandidates = 1408;  // per workgroup box: 33 KB of fp64 coordinates
-constexpr int kIcpMaxOffsets = 1536;     // cells of the box + one per row
-constexpr int kIcpMaxRows = 64;
-
-template <typename S>
-struct IcpStagedCells {
-  const S *cx, *cy, *cz;  // LDS: candidate coordinates, box order
-  const int *offsets;     // LDS: [row][x - box_lo_x], nx + 1 entries per row
-  int lo_x, lo_y, lo_z, ny, nx1;
-  __device__ __forceinline__ void range(int y, int z, int xa, int xb, int &lo, int &hi) const {
-    const int row = ((z - lo_z) * ny + (y - lo_y)) * nx1;
-    lo = offsets[row + (xa - lo_x)];
-    hi = offsets[row + (xb - lo_x) + 1];
-  }
-  __device__ __forceinline__ void fetch(int k, S (&q)[3]) const {
-    q[0] = cx[k];
-    q[1] = cy[k];
-    q[2] = cz[k];
-  }
-};
-
-// nearest candidate of the warped point w (grid cell c) within the maximum distance: position in
-// the store's order, or found == false
-template <typename S, typename Cells>
-__device__ __forceinline__ void icpSearchPoint(const IcpMatchArgs<S> &A, const Cells &cells,
-                                               const S (&w)[3], const int (&c)[3], bool &found,
-                                               int &best_k) {
-  S best_d = A.max_dist2;
-  // Ties go to the candidate stored first — (cell z, y, x; original index) order — whatever
-  // order the rows are visited in: the position k is part of the comparison.
-  best_k = 0x7fffffff;
-  // (only the distance and the position are tracked; the winner's coordinates are read once,
-  // at the end: six conditional moves less per candidate)
-  auto consider = [&](const S (&q)[3], int k) {
-    const S d0 = w[0] - q[0], d1 = w[1] - q[1], d2 = w[2] - q[2];
-    const S dist = d0 * d0 + d1 * d1 + d2 * d2;
-    if (dist <= A.max_dist2 && (!found || dist < best_d || (dist == best_d && k < best_k))) {
-      found = true;
-      best_d = dist;
-      best_k = k;
-    }
-  };
-  // cells [xa, xb] of row (y, z) are consecutive in storage: one candidate range, two bounds
-  auto visit = [&](int y, int z, int xa, int xb) {
-    xa = xa < 0 ? 0 : xa;
-    xb = xb >= A.dims[0] ? A.dims[0] - 1 : xb;
-    if (z < 0 || z >= A.dims[2] || y < 0 || y >= A.dims[1] || xa > xb) return;
-    int lo, hi;
-    cells.range(y, z, xa, xb, lo, hi);
-    // two candidates per step, both loads issued before either is used
-    for (int k = lo; k < hi; k += 2) {
-      S qa[3], qb[3];
-      const bool pair = k + 1 < hi;
-      cells.fetch(k, qa);
-      cells.fetch(pair ? k + 1 : k, qb);
-      consider(qa, k);
-      if (pair) consider(qb, k + 1);
-    }
-  };
-  // The source's own cell first; every other cell of the 3 x 3 x 3 block is visited only if
-  // its box can hold something at least as close as what has been found (or within the
-  // maximum distance while nothing has) — the bound is the distance to the own cell's faces,
-  // relaxed by a few ulps of the coordinates (targets were binned with floor()).  Range bounds are
-  // fetched only for what is visited.  At about one target per cell and a source close to its
-  // target this leaves 1-3 cells of 27 and takes most of the divergent tail off the wave.
-  // The offsets f are recomputed from the cell index and can disagree with the binning's
-  // floor((w - origin) / cell) by a few ulps OF THE COORDINATE (not of the offset): every gap to
-  // a face is shortened by that much before it is squared, in the scalar type's own epsilon.
-  constexpr S kUlps = S(16) * std::numeric_limits<S>::epsilon();
-  const S fx = w[0] - (A.origin[0] + S(c[0]) * A.cell);  // offsets inside the own cell, [0, cell)
-  const S fy = w[1] - (A.origin[1] + S(c[1]) * A.cell);
-  const S fz = w[2] - (A.origin[2] + S(c[2]) * A.cell);
-  const S ex = kUlps * (fabs(w[0]) + fabs(A.origin[0]) + A.cell);
-  const S ey = kUlps * (fabs(w[1]) + fabs(A.origin[1]) + A.cell);
-  const S ez = kUlps * (fabs(w[2]) + fabs(A.origin[2]) + A.cell);
-  const S gx[2] = {fx - ex, (A.cell - fx) - ex};
-  const S gap_y[3] = {fy - ey, S(0), (A.cell - fy) - ey};
-  const S gap_z[3] = {fz - ez, S(0), (A.cell - fz) - ez};
-  auto within = [&](S bound) {
-    return bound * (S(1) - kUlps) <= (found ? best_d : A.max_dist2);
-  };
-  auto sq = [](S v) { return v > S(0) ? v * v : S(0); };
-  visit(c[1], c[2], c[0], c[0]);
-#pragma unroll
-  for (int r = 0; r < 9; ++r) {
-    const int y = c[1] + r % 3 - 1, z = c[2] + r / 3 - 1;
-    const S yz = sq(gap_y[r % 3]) + sq(gap_z[r / 3]);
-    if (!within(yz)) continue;
-    const bool left = within(yz + sq(gx[0])), right = within(yz + sq(gx[1]));
-    if (r == 4) {  // the own row: its centre cell is done
-      if (left) visit(y, z, c[0] - 1, c[0] - 1);
-      if (right) visit(y, z, c[0] + 1, c[0] + 1);
-    } else {
-      visit(y, z, left ? c[0] - 1 : c[0], right ? c[0] + 1 : c[0]);
-    }
-  }
-}
-
 template <typename S>
 __device__ __forceinline__ void icpMatchBody(const IcpMatchArgs<S> &A, const S (&T)[12]) {
   constexpr int TP = TileShape<S>::kPoints;
   const long long i = (long long)blockIdx.x * kBlockThreads + threadIdx.x;
-  if (i >= (long long)A.num_tiles * TP) return;  // (the grid covers whole tiles: all or none)
+  if (i >= (long long)A.num_tiles * TP) return;
   S *slot = A.tiles + (i / TP) * TileShape<S>::kP2PScalars + (i % TP);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-  // the point, warped, and its grid cell
-  S w[3] = {S(0), S(0), S(0)};
-  int c[3] = {0, 0, 0};
-  bool inside = i < A.count;
-  if (inside) {
+  bool found = false;
+  S best[3] = {S(0), S(0), S(0)};
+  if (i < A.count) {
     const S p[3] = {slot[0 * TP], slot[1 * TP], slot[2 * TP]};
+    S w[3], g[3];
+    bool inside = true;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       w[a] = ((T[a * 4 + 0] * p[0] + T[a * 4 + 1] * p[1]) + T[a * 4 + 2] * p[2]) + T[a * 4 + 3];
-      const S g = floor((w[a] - A.origin[a]) * A.inv_cell);
-      inside = inside && g >= S(-1) && g <= S(A.dims[a]);
-      c[a] = inside ? int(g) : 0;
+      g[a] = floor((w[a] - A.origin[a]) * A.inv_cell);
+      inside = inside && g[a] >= S(-1) && g[a] <= S(A.dims[a]);
     }
-  }
-
-  // ---- the workgroup's box of cells: min / max of the cells of its points, one cell of margin ----
-  __shared__ int box_part[kBlockThreads / 64][6];
-  __shared__ int row_first[kIcpMaxRows];   // position in the target array of the row's first candidate
-  __shared__ int row_offset[kIcpMaxRows];  // ... and in the LDS image
-  __shared__ int staged_total;
-  __shared__ int offsets[kIcpMaxOffsets];
-  __shared__ S cand_x[kIcpMaxCandidates], cand_y[kIcpMaxCandidates], cand_z[kIcpMaxCandidates];
-  {
-    int m[6];  // min x, y, z | -max x, y, z (so that all six reduce with min)
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      m[a] = inside ? c[a] : 0x3fffffff;
-      m[3 + a] = inside ? -c[a] : 0x3fffffff;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-      for (int a = 0; a < 6; ++a) {
-        const int o = __shfl_xor(m[a], off, 64);
-        m[a] = o < m[a] ? o : m[a];
-      }
-    if (lane == 0) {
-#pragma unroll
-      for (int a = 0; a < 6; ++a) box_part[wave][a] = m[a];
-    }
-  }
-  __syncthreads();
-  int lo[3], hi[3];
-  bool any_inside = false;
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    int mn = box_part[0][a], mx = box_part[0][3 + a];
-#pragma unroll
-    for (int wv = 1; wv < kBlockThreads / 64; ++wv) {
-      mn = box_part[wv][a] < mn ? box_part[wv][a] : mn;
-      mx = box_part[wv][3 + a] < mx ? box_part[wv][3 + a] : mx;
-    }
-    any_inside = mn != 0x3fffffff;
-    lo[a] = mn - 1 < 0 ? 0 : mn - 1;
-    hi[a] = -mx + 1 >= A.dims[a] ? A.dims[a] - 1 : -mx + 1;
-  }
-  const int nx1 = hi[0] - lo[0] + 2;  // entries per row: cells + 1
-  const int ny = hi[1] - lo[1] + 1, nz = hi[2] - lo[2] + 1;
-  const int rows = ny * nz;
-  bool staged = any_inside && lo[0] <= hi[0] && lo[1] <= hi[1] && lo[2] <= hi[2] &&
-                rows <= kIcpMaxRows && rows * nx1 <= kIcpMaxOffsets;
-  if (staged) {
-    // every row of the box is one contiguous range of the target array: its two ends, then the
-    // rows' places in the LDS image by a scan over the (at most 64) rows in the first wavefront
-    if (wave == 0) {
-      int first = 0, length = 0;
-      if (lane < rows) {
-        const int y = lo[1] + lane % ny, z = lo[2] + lane / ny;
-        const int row = (z * A.dims[1] + y) * A.dims[0];
-        first = A.cell_start[row + lo[0]];
-        length = A.cell_start[row + hi[0] + 1] - first;
-      }
-      int run = length;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(run, off, 64);
-        if (lane >= off) run += o;
-      }
-      if (lane < rows) {
-        row_first[lane] = first;
-        row_offset[lane] = run - length;
-      }
-      if (lane == 63) staged_total = run;
-    }
-    __syncthreads();
-    // (uniform: every thread reads the same word; an empty box — no target array at all, even —
-    // is left to the gathered form, which then fetches nothing)
-    staged = staged_total > 0 && staged_total <= kIcpMaxCandidates;
-  }
-  bool found = false;
-  S best[3] = {S(0), S(0), S(0)};
-  if (A.debug_stage == 1) return;  // timing ablation (MOPT_ICP_DEBUG_STAGE): box and row bounds only
-  if (staged) {
-    // the copy: thread t takes positions t, t + 256, ... of the image (candidates) and of the offset
-    // table.  All addresses first (the row of a position by bisection over the rows' offsets in LDS),
-    // then every load of the thread back to back, then the LDS stores: one memory round trip for the
-    // whole box — a loop that loads and stores row by row is a chain of as many round trips as rows.
-    constexpr int kCandPerThread = (kIcpMaxCandidates + kBlockThreads - 1) / kBlockThreads;
-    constexpr int kOffPerThread = (kIcpMaxOffsets + kBlockThreads - 1) / kBlockThreads;
-    const int total = staged_total, num_offsets = rows * nx1;
-    int cand_from[kCandPerThread], off_from[kOffPerThread], off_add[kOffPerThread];
-#pragma unroll
-    for (int q = 0; q < kCandPerThread; ++q) {
-      const int j = tid + q * kBlockThreads;
-      int a = 0, b = rows - 1;
-#pragma unroll
-      for (int step = 0; step < 6; ++step) {  // rows <= 64
-        const int mid = (a + b + 1) >> 1;
-        const bool right = a < b && row_offset[mid] <= j;
-        a = right ? mid : a;
-        b = right ? b : (a < b ? mid - 1 : b);
-      }
-      cand_from[q] = j < total ? row_first[a] + (j - row_offset[a]) : 0;  // (slot 0 exists: total > 0)
-    }
-#pragma unroll
-    for (int q = 0; q < kOffPerThread; ++q) {
-      const int idx = tid + q * kBlockThreads;
-      const int r = idx < num_offsets ? idx / nx1 : 0;
-      const int x = idx < num_offsets ? idx - r * nx1 : 0;
-      const int y = lo[1] + r % ny, z = lo[2] + r / ny;
-      off_from[q] = (z * A.dims[1] + y) * A.dims[0] + lo[0] + x;
-      off_add[q] = row_offset[r] - row_first[r];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    typename std::conditional<sizeof(S) == 8, Pack<S>[2], Pack<S>[1]>::type cand_raw[kCandPerThread];
-    int off_raw[kOffPerThread];
-#pragma unroll
-    for (int q = 0; q < kCandPerThread; ++q) {
-      const Pack<S> *from = reinterpret_cast<const Pack<S> *>(A.sorted + size_t(cand_from[q]) * 4);
-      cand_raw[q][0] = from[0];
-      if (sizeof(S) == 8) cand_raw[q][sizeof(S) == 8 ? 1 : 0] = from[1];
-    }
-#pragma unroll
-    for (int q = 0; q < kOffPerThread; ++q) off_raw[q] = A.cell_start[off_from[q]];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < kCandPerThread; ++q) {
-      const int j = tid + q * kBlockThreads;
-      if (j < total) {
-        cand_x[j] = cand_raw[q][0].v[0];
-        cand_y[j] = cand_raw[q][0].v[1];
-        cand_z[j] = sizeof(S) == 8 ? cand_raw[q][sizeof(S) == 8 ? 1 : 0].v[0] : cand_raw[q][0].v[2 % (16 / sizeof(S))];
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < kOffPerThread; ++q) {
-      const int idx = tid + q * kBlockThreads;
-      if (idx < num_offsets) offsets[idx] = off_raw[q] + off_add[q];
-    }
-    __syncthreads();
-    if (A.debug_stage == 2) return;  // ... and the copy into LDS
     if (inside) {
-      const IcpStagedCells<S> cells{cand_x, cand_y, cand_z, offsets, lo[0], lo[1], lo[2], ny, nx1};
-      int best_k;
-      icpSearchPoint<S>(A, cells, w, c, found, best_k);
-      if (found) cells.fetch(best_k, best);
+      const int c[3] = {int(g[0]), int(g[1]), int(g[2])};
+      S best_d = A.max_dist2;
+      // Ties go to the candidate stored first — (cell z, y, x; original index) order — whatever
+      // order the rows are visited in: the position k is part of the comparison.
+      int best_k = 0x7fffffff;
+      // (only the distance and the position are tracked; the winner's coordinates are read once,
+      // at the end: six conditional moves less per candidate)
+      auto consider = [&](const S (&q)[3], int k) {
+        const S d0 = w[0] - q[0], d1 = w[1] - q[1], d2 = w[2] - q[2];
+        const S dist = d0 * d0 + d1 * d1 + d2 * d2;
+        if (dist <= A.max_dist2 && (!found || dist < best_d || (dist == best_d && k < best_k))) {
+          found = true;
+          best_d = dist;
+          best_k = k;
+        }
+      };
+      auto fetch = [&](int k, S (&q)[3]) {
+        const Pack<S> *cand = reinterpret_cast<const Pack<S> *>(A.sorted + size_t(k) * 4);
+        if (sizeof(S) == 8) {
+          const Pack<S> lo = cand[0], hi = cand[1];
+          q[0] = lo.v[0]; q[1] = lo.v[1]; q[2] = hi.v[0];
+        } else {
+          const Pack<S> all = cand[0];
+          q[0] = all.v[0]; q[1] = all.v[1]; q[2] = all.v[2];
+        }
+      };
+      // cells [xa, xb] of row (y, z) are consecutive in storage: one candidate range, two bounds
+      auto visit = [&](int y, int z, int xa, int xb) {
+        xa = xa < 0 ? 0 : xa;
+        xb = xb >= A.dims[0] ? A.dims[0] - 1 : xb;
+        if (z < 0 || z >= A.dims[2] || y < 0 || y >= A.dims[1] || xa > xb) return;
+        const int row = (z * A.dims[1] + y) * A.dims[0];  // the grid has at most 2^22 cells (icp.cpp)
+        const int lo = A.cell_start[row + xa], hi = A.cell_start[row + xb + 1];
+        // two candidates per step, both loads issued before either is used
+        for (int k = lo; k < hi; k += 2) {
+          S qa[3], qb[3];
+          const bool pair = k + 1 < hi;
+          fetch(k, qa);
+          fetch(pair ? k + 1 : k, qb);
+          consider(qa, k);
+          if (pair) consider(qb, k + 1);
+        }
+      };
+      // The source's own cell first; every other cell of the 3 x 3 x 3 block is visited only if
+      // its box can hold something at least as close as what has been found (or within the
+      // maximum distance while nothing has) — the bound is the distance to the own cell's faces,
+      // relaxed by a few ulps of the coordinates (targets were binned with floor()).  Range bounds are
+      // fetched only for what is visited.  At about one target per cell and a source close to its
+      // target this leaves 1-3 cells of 27 and takes most of the divergent tail off the wave.
+      // The offsets f are recomputed from the cell index and can disagree with the binning's
+      // floor((w - origin) / cell) by a few ulps OF THE COORDINATE (not of the offset): every gap to
+      // a face is shortened by that much before it is squared, in the scalar type's own epsilon.
+      constexpr S kUlps = S(16) * std::numeric_limits<S>::epsilon();
+      const S fx = w[0] - (A.origin[0] + S(c[0]) * A.cell);  // offsets inside the own cell, [0, cell)
+      const S fy = w[1] - (A.origin[1] + S(c[1]) * A.cell);
+      const S fz = w[2] - (A.origin[2] + S(c[2]) * A.cell);
+      const S ex = kUlps * (fabs(w[0]) + fabs(A.origin[0]) + A.cell);
+      const S ey = kUlps * (fabs(w[1]) + fabs(A.origin[1]) + A.cell);
+      const S ez = kUlps * (fabs(w[2]) + fabs(A.origin[2]) + A.cell);
+      const S gx[2] = {fx - ex, (A.cell - fx) - ex};
+      const S gap_y[3] = {fy - ey, S(0), (A.cell - fy) - ey};
+      const S gap_z[3] = {fz - ez, S(0), (A.cell - fz) - ez};
+      auto within = [&](S bound) {
+        return bound * (S(1) - kUlps) <= (found ? best_d : A.max_dist2);
+      };
+      auto sq = [](S v) { return v > S(0) ? v * v : S(0); };
+      visit(c[1], c[2], c[0], c[0]);
+#pragma unroll
+      for (int r = 0; r < 9; ++r) {
+        const int y = c[1] + r % 3 - 1, z = c[2] + r / 3 - 1;
+        const S yz = sq(gap_y[r % 3]) + sq(gap_z[r / 3]);
+        if (!within(yz)) continue;
+        const bool left = within(yz + sq(gx[0])), right = within(yz + sq(gx[1]));
+        if (r == 4) {  // the own row: its centre cell is done
+          if (left) visit(y, z, c[0] - 1, c[0] - 1);
+          if (right) visit(y, z, c[0] + 1, c[0] + 1);
+        } else {
+          visit(y, z, left ? c[0] - 1 : c[0], right ? c[0] + 1 : c[0]);
+        }
+      }
+      if (found) fetch(best_k, best);
     }
-  } else if (inside) {
-    const IcpGlobalCells<S> cells{A.sorted, A.cell_start, A.dims[0], A.dims[1]};
-    int best_k;
-    icpSearchPoint<S>(A, cells, w, c, found, best_k);
-    if (found) cells.fetch(best_k, best);
   }
   const S nan = S(__builtin_nan(""));
   slot[3 * TP] = found ? best[0] : nan;
   slot[4 * TP] = found ? best[1] : nan;
   slot[5 * TP] = found ? best[2] : nan;
-  // one counter update per workgroup (the grid covers whole tiles, so no thread has left early):
-  // matched sources, and workgroups that took the staged form
+  // one counter update per workgroup (the grid covers whole tiles, so no thread has left early)
   if (A.matched) {
     const int in_block = __syncthreads_count(found ? 1 : 0);
-    if (threadIdx.x == 0) {
-      if (in_block > 0) atomicAdd(A.matched, (unsigned int)in_block);
-      if (staged) atomicAdd(A.matched + 1, 1u);
-    }
+    if (threadIdx.x == 0 && in_block > 0) atomicAdd(A.matched, (unsigned int)in_block);
   }
 }
 
@@ -1726,13 +1519,12 @@ template hipError_t launchGatherTargets<double>(const double *, long long, doubl
 // matched-source counter of the correspondence search -> mapped host memory (as a double), and
 // back to zero for the next search: no memset launch, no copy, no stream synchronisation
 __global__ void publishCounterKernel(unsigned int *counter, const HostPublish pub) {
-  // [0] matched sources, [1] workgroups that searched their box from LDS
   double v = 0.0;
-  if (threadIdx.x < 2) {
-    v = double(counter[threadIdx.x]);
-    counter[threadIdx.x] = 0u;
+  if (threadIdx.x == 0) {
+    v = double(*counter);
+    *counter = 0u;
   }
-  publishToHost(pub, 2, v);
+  publishToHost(pub, 1, v);
 }
 
 hipError_t launchPublishCounter(unsigned int *d_counter, const HostPublish &pub, hipStream_t stream) {

@@ -839,7 +839,7 @@ def test_set_data_replaces_correspondences(hip_lib, oracle):
             assert abs(cost.compute_cost(x) - want) <= REL * want
 
 
-def _se3(x):
+def _brute_force_matches(src, tgt, x, max_dist):
     T = np.eye(4)
     th = np.linalg.norm(x[3:])
     if th > 0:
@@ -847,11 +847,6 @@ def _se3(x):
         K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
         T[:3, :3] = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
     T[:3, 3] = x[:3]
-    return T
-
-
-def _brute_force_matches(src, tgt, x, max_dist):
-    T = _se3(x)
     w = src @ T[:3, :3].T + T[:3, 3]
     d2 = ((w[:, None, :] - tgt[None, :, :]) ** 2).sum(-1)
     j = d2.argmin(1)
@@ -890,53 +885,6 @@ def test_icp_matcher_equals_brute_force(hip_lib, dtype):
     assert not empty.linearize(np.zeros(6, dtype=dtype), 0)[0].any()
     far = hip_lib.IcpCost(src, np.full((1, 3), 1e3, dtype=dtype), 0.5, dtype=dtype)
     assert far.update(np.zeros(6, dtype=dtype)) == 0 and np.isnan(far.matches()).all()
-
-
-@pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_icp_streaming_form_equals_the_definition(hip_lib, dtype):
-    """The search at about one target per grid cell, where a workgroup's 256 sources (stored brick by
-    brick) fall into a box of cells that fits LDS: near the pose the sources were sorted at most
-    workgroups take the streaming form (box copied by coalesced loads, searched in LDS), under a large
-    rotation the boxes outgrow the image and the gathered form runs — same matches either way, equal to
-    the definition (nearest target of the warped source within max_distance)."""
-    from scipy.spatial import cKDTree
-    rng = np.random.default_rng(21)
-    n = 40_000
-    tgt = rng.random((n, 3)) * np.array([10.0, 10.0, 4.0])
-    src = tgt[rng.permutation(n)] + rng.normal(0, 0.02, (n, 3))
-    src[:500] += 30.0                                     # far outside the grid
-    max_dist = 0.2                                        # 50 x 50 x 20 cells: 0.8 targets per cell
-    tgt_t, src_t = tgt.astype(dtype), src.astype(dtype)
-    cost = hip_lib.IcpCost(src_t, tgt_t, max_dist, dtype=dtype)
-    tree = cKDTree(tgt_t.astype(np.float64))
-    fractions = []
-    for x in (np.zeros(6), np.array([0.05, -0.03, 0.02, 0.004, -0.003, 0.005]),
-              np.array([0.3, -0.2, 0.1, 0.05, -0.02, 0.7])):
-        matched = cost.update(x.astype(dtype))
-        staged, groups = cost.search_stats()
-        fractions.append(staged / groups)
-        got = cost.matches()
-        T = _se3(x)
-        warped = src_t.astype(np.float64) @ T[:3, :3].T + T[:3, 3]
-        dist, idx = tree.query(warped, k=1, distance_upper_bound=max_dist * (1 + 1e-12))
-        miss_w = ~np.isfinite(dist)
-        miss_g = np.isnan(got[:, 0])
-        assert matched == int((~miss_g).sum())
-        if dtype == np.float64:
-            edge = np.abs(dist - max_dist) < 1e-9         # on the radius: either answer
-            assert np.array_equal(miss_g[~edge], miss_w[~edge])
-            both = ~miss_g & ~miss_w
-            same = (got[both] == tgt[idx[both]]).all(1)
-            # a different target only where two are equally near to the last bit
-            d_got = np.linalg.norm(warped[both][~same] - got[both][~same], axis=1)
-            assert np.allclose(d_got, dist[both][~same], rtol=1e-12, atol=0) and (~same).mean() < 1e-4
-        else:
-            assert (miss_g != miss_w).mean() < 2e-3
-            both = ~miss_g & ~miss_w
-            assert (np.abs(got[both] - tgt_t[idx[both]]).max(1) > 0).mean() < 2e-3
-    # near the sorting pose the streaming form carries the search; rotated by 0.7 rad it cannot
-    assert fractions[0] > 0.5 and fractions[1] > 0.5, fractions
-    assert fractions[2] < fractions[0], fractions
 
 
 def test_icp_solve_with_gpu_correspondence_search(hip_lib, oracle):
