@@ -33,7 +33,11 @@ Order for N > 1: attach every transport (host slots, peer slots, RCCL) | headlin
 time pass | CPU baseline — from there the line can stand — | RCCL pass | the comparison passes
 (other transports, no combine, the 10 M strong-scaling split).  A watchdog covers it all: firing
 before the line can stand it ends the rank with exit code 3 and no line; after, it prints the line
-as it is ("extras_incomplete", "note" naming the stage it was in) and ends the rank.
+as it is and ends the rank.  Two top-level booleans, always present for N > 1, say at a glance whether
+the line is whole: "rccl_incomplete" (the RCCL timed pass was started and did not finish) and
+"extras_incomplete" (the comparison passes did not all finish; "note" names the stage).  A transport
+asked for with --collective that cannot be attached (RCCL between ranks that share a GPU) falls back to
+the automatic order; config.collective_requested / collective_fell_back record it.
 """
 import argparse
 import json
@@ -356,25 +360,46 @@ def main():
     progress = {"stage": "attaching the combine transports", "complete": False}
     emitted = threading.Lock()
 
+    def serialized(extra):
+        """The line as JSON, taken while the main thread may still be adding to it (the watchdog's
+        case): a dict that changes size under json.dumps raises, so copy and retry."""
+        import copy
+        for _ in range(200):
+            try:
+                snap = copy.deepcopy(line)
+                snap.update(extra)
+                return json.dumps(snap)
+            except RuntimeError:
+                time.sleep(0.001)
+        return json.dumps(dict(extra, error="bench.py: the line kept changing under the watchdog"))
+
     def emit(final):
         if not emitted.acquire(blocking=False):
             return
         if rank == 0:
+            extra = {}
             if not final:
-                line["extras_incomplete"] = True
-                line["note"] = ("watchdog: still in %r at the deadline; reported without it"
-                                % progress["stage"])
-            print(json.dumps(line), flush=True)
+                # (rccl_incomplete is in the line already: True from the start of the RCCL pass to its end)
+                extra = {"extras_incomplete": True,
+                         "note": "watchdog: still in %r at the deadline; reported without it"
+                                 % progress["stage"]}
+            print(serialized(extra), flush=True)
 
     def watchdog():
-        if progress["complete"]:
-            log("rank %d: watchdog fired in %r: reporting the measurement without it"
-                % (rank, progress["stage"]))
-            emit(False)
-            os._exit(0)
-        print(json.dumps({"error": "bench.py watchdog: no complete measurement by the deadline",
-                          "rank": rank, "stage": progress["stage"]}), file=sys.stderr, flush=True)
-        os._exit(3)
+        # whatever happens in here, this rank ends: a watchdog that dies of an exception would leave
+        # the rank with neither a line nor an exit
+        code = 3
+        try:
+            if progress["complete"]:
+                log("rank %d: watchdog fired in %r: reporting the measurement without it"
+                    % (rank, progress["stage"]))
+                emit(False)
+                code = 0
+            else:
+                print(json.dumps({"error": "bench.py watchdog: no complete measurement by the deadline",
+                                  "rank": rank, "stage": progress["stage"]}), file=sys.stderr, flush=True)
+        finally:
+            os._exit(code)
 
     dog = None
     if world > 1:
@@ -392,7 +417,11 @@ def main():
         if "rccl" not in usable:
             rccl_note = ("ranks share GPUs (rehearsal backend %r): RCCL refuses duplicate devices"
                          % backend) if backend != "nccl" else "ncclCommInitRank failed on some rank"
-        prefer = ("host", "peer", "rccl") if args.collective == "auto" else (args.collective,)
+        # a transport asked for by name comes first; one that could not be attached (RCCL between ranks
+        # that share a GPU, for one) falls back to the automatic order, and the line says so
+        auto = ("host", "peer", "rccl")
+        prefer = auto if args.collective == "auto" else (args.collective,) + tuple(
+            c for c in auto if c != args.collective)
         collective = next((c for c in prefer if c in usable), "torch")
     modes = {"none": mo.COMBINE_NONE, "rccl": mo.COMBINE_RCCL, "host": mo.COMBINE_HOST,
              "peer": mo.COMBINE_PEER}
@@ -578,6 +607,8 @@ def main():
             "collective": collective if not (rehearsal and collective == "torch")
             else "torch/" + backend + " (rehearsal)",
             "collective_is": how,
+            "collective_requested": args.collective,
+            "collective_fell_back": world > 1 and args.collective not in ("auto", collective),
             "collectives_attached": list(usable),
             "rank_backend": backend if world > 1 else None,
             "rehearsal": ("%d ranks on %d GPU(s), torch.distributed over %s" % (world, ndev, backend))
@@ -603,6 +634,14 @@ def main():
         "pct_hbm_peak": 100.0 * achieved / HBM_PEAK_GBS,
         "check": {"sum_sq": float(s), "H00": float(H[0, 0])},
     })
+    if world > 1:
+        # Always present for N > 1, and impossible to miss: the headline above is complete on its own;
+        # these two say whether what follows it in the line is.  rccl_incomplete: the RCCL timed pass
+        # was started and did not finish (it is the one path that has never run with more than one rank
+        # before the driver's own run); extras_incomplete: the comparison passes / the 10 M strong-scaling
+        # split did not all finish (set by the watchdog when it has to report the line as it stands).
+        line["rccl_incomplete"] = False
+        line["extras_incomplete"] = False
     per = {}
     if world > 1:
         per[collective] = as_step_sees_it(ms_per_step)
@@ -643,7 +682,9 @@ def main():
                 info.update(per["rccl"])
                 info["timed_pass"] = "the headline pass"
             else:
+                line["rccl_incomplete"] = True
                 r = guarded_pass(cost, "rccl", args.steps, args.warmup, min(settle, 200))
+                line["rccl_incomplete"] = False
                 info["timed_pass"] = "done" if r is not None else "failed"
                 if r is not None:
                     per["rccl"] = as_step_sees_it(r[0] / args.steps * 1e3)

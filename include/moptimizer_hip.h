@@ -111,7 +111,13 @@ enum mopt_kernel_variant {
                               for forward differences with some 0 < |x_j| < 0.08, where that
                               evaluation leaves the 1e-6 bar (it lacks the reference's own
                               per-point cancellation noise eps |R p + t| / h_j) and the literal
-                              evaluation is used                                                */
+                              evaluation is used.  That rule is the blocking and asynchronous
+                              calls'; the device-resident loop (mopt_lm_minimize) decides per
+                              minimisation, not per point, and under this variant evaluates
+                              forward differences through moments at every iterate — its
+                              Jacobians can then differ from mopt_cost_linearize's at a point
+                              with a small |x_j| by the amount given under _ALWAYS; ask for
+                              MOPT_KERNEL_LITERAL where that matters                            */
   MOPT_KERNEL_MOMENTS_ALWAYS = 3 /* moments whatever the step size: for measurements; forward
                               differences then differ from the reference's by up to
                               2e-8 / min |x_j| relative (0.97 at |x_j| ~ 1e-8)                  */
@@ -185,7 +191,10 @@ MOPT_API int mopt_reprojection_create(mopt_cost **out, int device, const double 
  *   MOPT_MODEL_POWELL     Powell's function        n = 4, m = 4   tst/powell.cpp:21-60 (count = 1)
  * t / y: arrays of `count` scalars read with a stride of `stride_scalars` (the curve-fitting data are
  * interleaved pairs: t = data, y = data + 1, stride 2); ignored for MOPT_MODEL_POWELL.  All the cost
- * calls above apply; x, hessian, b have n, n*n, n entries; async results n*n + n + 1 doubles. */
+ * calls above apply; x, hessian, b have n, n*n, n entries; async results n*n + n + 1 doubles.
+ * An observation whose y is NaN is not a residual: the model's f / f_df return false for it
+ * (model.h:32,43) and every sweep skips the index (linearization.h:102,144) — the marker a
+ * point2point slot without a correspondence carries. */
 enum mopt_scalar_model { MOPT_MODEL_EXP_CURVE = 1, MOPT_MODEL_RATIONAL = 2, MOPT_MODEL_POWELL = 3 };
 MOPT_API int mopt_scalar_model_create(mopt_cost **out, int device, int scalar_bytes, int model_kind,
                                       const void *t, const void *y, int64_t stride_scalars,
@@ -209,6 +218,13 @@ MOPT_API int mopt_scalar_model_create(mopt_cost **out, int device, int scalar_by
  *                  J = m x n row-major (J[i*n + j] = d r_i / d x_j), as IBaseModel::f_df fills it;
  *                  NULL or "" -> only MOPT_JAC_NUMERIC is available (BaseModel without f_df,
  *                  model.h:29-33: the reference throws on f_df, so does mopt_cost_linearize)
+ *
+ * f and f_df return bool — false: "this index is not a residual", and the loops skip it
+ * (model.h:32,43; linearization.h:102,144).  A body says so by clearing the reserved local
+ * `bool valid` (true on entry), e.g. "valid = d[2] > 0;": the element then enters no sum, whatever
+ * the body leaves in r or J (NaN included).  With a supplied Jacobian the element is skipped when
+ * either body clears it (f_df's one verdict); with forward differences only the residual at x
+ * decides — the perturbed evaluations' verdicts are ignored, as linearization.h:104 ignores them.
  *
  * S is `double` or `float` per scalar_bytes; 1 <= n <= 16, 1 <= m <= 16, 0 <= n_planes <= 16,
  * 0 <= n_aux <= 64.  Models with n <= 8 and m <= 4 get the per-lane sweep and everything the

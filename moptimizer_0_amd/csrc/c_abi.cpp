@@ -407,7 +407,18 @@ void fillScalarArgs(const mopt_cost *c, const S *x, mopt::ScalarSweepArgs<S> &a)
   for (int k = 0; k < 16; ++k) a.cov[k] = S(c->cov_m[k]);
 }
 
-bool scalarModelHasJacobian(int kind) { return kind != mopt::kScalarExpCurve; }
+bool scalarModelHasJacobian(int kind) {
+  return kind != mopt::kScalarExpCurve && kind != mopt::kScalarExpCurveMarked;
+}
+
+// workgroups (= partial rows) of a built-in scalar model's sweep: a workgroup per 256 packs of 16
+// bytes, at most four per CU
+int scalarGrid(const mopt_cost *c) {
+  const long long per_block = (long long)mopt::kBlockThreads * (16 / c->scalar_bytes);
+  long long blocks = (c->count + per_block - 1) / per_block;
+  if (blocks > c->num_cus * 4) blocks = c->num_cus * 4;
+  return blocks < 1 ? 1 : int(blocks);
+}
 
 template <typename S>
 int scalarSweepAsync(mopt_cost *c, bool cost_only, int jac_mode, const S *x, double *d_out,
@@ -423,10 +434,7 @@ int scalarSweepAsync(mopt_cost *c, bool cost_only, int jac_mode, const S *x, dou
   }
   mopt::ScalarSweepArgs<S> args;
   fillScalarArgs<S>(c, x, args);
-  long long blocks = (c->count + mopt::kBlockThreads - 1) / mopt::kBlockThreads;
-  if (blocks > c->num_cus * 2) blocks = c->num_cus * 2;
-  if (blocks < 1) blocks = 1;
-  const int grid = int(blocks);
+  const int grid = scalarGrid(c);
   const int n = c->n_params;
   SweepTimer timer(c, s);
   MOPT_HIP_TRY(mopt::launchScalarModel<S>(args, c->scalar_model, cost_only, jac_mode, c->cov_mode,
@@ -755,11 +763,8 @@ int residentGrid(const mopt_cost *c) {
       return gridFor(c, blocksPerCu(usesMoments(c) ? 1 : 2));
     case kModelReprojection:
       return gridFor(c, blocksPerCu(2));
-    case kModelScalar: {
-      long long blocks = (c->count + mopt::kBlockThreads - 1) / mopt::kBlockThreads;
-      if (blocks > c->num_cus * 2) blocks = c->num_cus * 2;
-      return blocks < 1 ? 1 : int(blocks);
-    }
+    case kModelScalar:
+      return scalarGrid(c);
     case kModelJit:
       return jitGrid(c);
     default:
@@ -1527,18 +1532,40 @@ int mopt_scalar_model_create(mopt_cost **out, int device, int scalar_bytes, int 
   c->n_out = m;
   c->count = count;
   c->num_tiles = 1;
-  c->data_stride = count;
+  // plane stride padded to whole 16-byte packs (the sweep loads 16 bytes per lane and plane); the
+  // tail of the last pack is zero-filled and enters no sum
+  const int vec = 16 / scalar_bytes;
+  const int64_t padded = (count + vec - 1) / vec * vec;
+  c->data_stride = padded;
   int rc = commonCreate(c.get(), device);
   if (rc != MOPT_OK) return rc;
   if (planes > 0) {
     // gather the (possibly interleaved) host arrays into contiguous planes t | y
-    std::vector<unsigned char> staged(size_t(planes) * size_t(count) * scalar_bytes);
+    std::vector<unsigned char> staged(size_t(planes) * size_t(padded) * scalar_bytes, 0);
     const unsigned char *src[2] = {static_cast<const unsigned char *>(t),
                                    static_cast<const unsigned char *>(y)};
     for (int p = 0; p < planes; ++p)
       for (int64_t i = 0; i < count; ++i)
-        std::memcpy(&staged[(size_t(p) * count + size_t(i)) * scalar_bytes],
+        std::memcpy(&staged[(size_t(p) * padded + size_t(i)) * scalar_bytes],
                     src[p] + size_t(i) * size_t(stride_scalars) * scalar_bytes, scalar_bytes);
+    // an observation whose y is NaN is "not a residual" (f / f_df returning false: model.h:32,43):
+    // data that carry the marker run the sweeps that look for it (sweep.hpp, ScalarModelKind)
+    bool marked = false;
+    for (int64_t i = 0; i < count && !marked; ++i) {
+      const unsigned char *yi = &staged[(size_t(1) * padded + size_t(i)) * scalar_bytes];
+      if (scalar_bytes == 8) {
+        double v;
+        std::memcpy(&v, yi, 8);
+        marked = v != v;
+      } else {
+        float v;
+        std::memcpy(&v, yi, 4);
+        marked = v != v;
+      }
+    }
+    if (marked)
+      c->scalar_model = model_kind == MOPT_MODEL_EXP_CURVE ? int(mopt::kScalarExpCurveMarked)
+                                                            : int(mopt::kScalarRationalMarked);
     MOPT_HIP_TRY(deviceAlloc(&c->d_tiles, staged.size()));
     MOPT_HIP_TRY(hipMemcpy(c->d_tiles, staged.data(), staged.size(), hipMemcpyHostToDevice));
   }

@@ -184,10 +184,18 @@ __device__ inline void sweep_elements(const JitArgs &A, const S *aux, double (&a
     // registers across the loop
     asm volatile("" ::: "memory");
     S r[M];
-    user_residual(A.x, aux, d, r);
+    // an index the model rejects (f / f_df returning false: model.h:32, linearization.h:102,144) is
+    // skipped like a slot past the end: weight zero, and its values — which may be anything, NaN
+    // included — replaced by zeros so that 0 * value stays 0
+    // (`ok` is a constant for a body that never touches `valid`: the selects on it then fold away;
+    // a slot past the end needs none — it is evaluated on the pack's first element, which is finite)
+    bool ok = user_residual(A.x, aux, d, r);
     S rr = 0;
 #pragma unroll
-    for (int a = 0; a < M; ++a) rr += r[a] * r[a];
+    for (int a = 0; a < M; ++a) {
+      r[a] = ok ? r[a] : S(0);
+      rr += r[a] * r[a];
+    }
     rr = valid ? rr : S(0);
 #if MODE == 0
     acc[0] += (double)rr;
@@ -202,14 +210,19 @@ __device__ inline void sweep_elements(const JitArgs &A, const S *aux, double (&a
       xp[j] += A.h[j];                                   // linearization.h:89
       asm volatile("" ::: "memory");                     // fetch this vector's per-x values now
       S rp[M];
-      user_residual(xp, aux + (1 + j) * AUX, d, rp);
+      (void)user_residual(xp, aux + (1 + j) * AUX, d, rp);   // its result is ignored, :104
 #pragma unroll
-      for (int a = 0; a < M; ++a) J[a * N + j] = (rp[a] - r[a]) * inv_h[j];   // :105
+      for (int a = 0; a < M; ++a) J[a * N + j] = ok ? (rp[a] - r[a]) * inv_h[j] : S(0);   // :105
     }
 #else
-    user_jacobian(A.x, aux, d, J);
+    ok = user_jacobian(A.x, aux, d, J) && ok;
+#pragma unroll
+    for (int q = 0; q < M * N; ++q) J[q] = ok ? J[q] : S(0);
+    rr = ok ? rr : S(0);   // (selects, not a branch: a branch splits the element's basic block)
+#pragma unroll
+    for (int a = 0; a < M; ++a) r[a] = ok ? r[a] : S(0);
 #endif
-    accumulate(r, rr, J, valid);
+    accumulate(r, rr, J, valid && ok);
 #endif
   };
 #if PAIRED
@@ -224,16 +237,20 @@ __device__ inline void sweep_elements(const JitArgs &A, const S *aux, double (&a
                           bool valid1) {
     asm volatile("" ::: "memory");
     S r0[M], r1[M];
-    user_residual(A.x, aux, d0, r0);
-    user_residual(A.x, aux, d1, r1);
+    const bool ok0 = user_residual(A.x, aux, d0, r0);   // (rejected indices: as in element())
+    const bool ok1 = user_residual(A.x, aux, d1, r1);
     S rr0 = 0, rr1 = 0;
 #pragma unroll
     for (int a = 0; a < M; ++a) {
+      r0[a] = ok0 ? r0[a] : S(0);
+      r1[a] = ok1 ? r1[a] : S(0);
       rr0 += r0[a] * r0[a];
       rr1 += r1[a] * r1[a];
     }
     rr0 = valid0 ? rr0 : S(0);
     rr1 = valid1 ? rr1 : S(0);
+    valid0 = valid0 && ok0;
+    valid1 = valid1 && ok1;
     S J0[M * N], J1[M * N];
 #pragma unroll
     for (int j = 0; j < N; ++j) {
@@ -243,12 +260,12 @@ __device__ inline void sweep_elements(const JitArgs &A, const S *aux, double (&a
       xp[j] += A.h[j];                                   // linearization.h:89
       asm volatile("" ::: "memory");                     // fetch this vector's per-x values now
       S rp0[M], rp1[M];
-      user_residual(xp, aux + (1 + j) * AUX, d0, rp0);
-      user_residual(xp, aux + (1 + j) * AUX, d1, rp1);
+      (void)user_residual(xp, aux + (1 + j) * AUX, d0, rp0);   // results ignored, :104
+      (void)user_residual(xp, aux + (1 + j) * AUX, d1, rp1);
 #pragma unroll
       for (int a = 0; a < M; ++a) {
-        J0[a * N + j] = (rp0[a] - r0[a]) * inv_h[j];   // :105
-        J1[a * N + j] = (rp1[a] - r1[a]) * inv_h[j];
+        J0[a * N + j] = ok0 ? (rp0[a] - r0[a]) * inv_h[j] : S(0);   // :105
+        J1[a * N + j] = ok1 ? (rp1[a] - r1[a]) * inv_h[j] : S(0);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -460,10 +477,24 @@ __device__ inline void wide_body(const JitArgs &A) {
 #pragma unroll
     for (int p = 0; p < D; ++p) d[p] = A.data[p * A.stride + at];
     S r[M];
-    user_residual(A.x, aux, d, r);
+    // an index the model rejects (f / f_df returning false: model.h:32, linearization.h:102,144) is
+    // skipped like a padding slot: weight zero, its values replaced by zeros (0 * NaN is NaN)
+    // (`ok` is the model's verdict alone — a constant for a body that never touches `valid`, and the
+    // selects on it fold away; padding slots repeat the last element, which is finite)
+    bool ok = user_residual(A.x, aux, d, r);
+#if MODE == 1
+    // f_df's own verdict: lane 0 of the element evaluates it, the element's lanes share it
+    {
+      const bool jac_ok = j == 0 ? user_jacobian(A.x, aux, d, Je) : true;   // row-major M x N
+      ok = ok && __shfl(jac_ok ? 1 : 0, (int)(threadIdx.x & 63) - j, 64) != 0;
+    }
+#endif
     S rr = 0;
 #pragma unroll
-    for (int a = 0; a < M; ++a) rr += r[a] * r[a];
+    for (int a = 0; a < M; ++a) {
+      r[a] = ok ? r[a] : S(0);
+      rr += r[a] * r[a];
+    }
     rr = valid ? rr : S(0);
 #if MODE == 0
     if (j == 0) acc_s += (double)rr;
@@ -472,9 +503,9 @@ __device__ inline void wide_body(const JitArgs &A) {
 #if MODE == 2
     {
       S rp[M];
-      user_residual(xj, aux + (1 + jc) * AUX, d, rp);
+      (void)user_residual(xj, aux + (1 + jc) * AUX, d, rp);   // its result is ignored, :104
 #pragma unroll
-      for (int a = 0; a < M; ++a) Jc[a] = (rp[a] - r[a]) * inv_h;   // :105
+      for (int a = 0; a < M; ++a) Jc[a] = ok ? (rp[a] - r[a]) * inv_h : S(0);   // :105
       if (owner) {
 #pragma unroll
         for (int a = 0; a < M; ++a) Je[a * N + j] = Jc[a];
@@ -482,17 +513,16 @@ __device__ inline void wide_body(const JitArgs &A) {
     }
     __syncthreads();
 #else
-    if (j == 0) user_jacobian(A.x, aux, d, Je);   // row-major M x N, as IBaseModel::f_df fills it
     __syncthreads();
 #pragma unroll
-    for (int a = 0; a < M; ++a) Jc[a] = Je[a * N + jc];
+    for (int a = 0; a < M; ++a) Jc[a] = ok ? Je[a * N + jc] : S(0);
 #endif
     S w = 1;
     if (A.loss_kind == 1) {
       const S den = rr + A.loss_param;
       w = (A.loss_param * A.loss_param) / (den * den);
     }
-    w = valid ? w : S(0);
+    w = (ok && valid) ? w : S(0);
     S SJc[M], Sr[M];
 #pragma unroll
     for (int a = 0; a < M; ++a) {
@@ -510,7 +540,7 @@ __device__ inline void wide_body(const JitArgs &A) {
       for (int i2 = 0; i2 < N; ++i2) {
         S v = 0;
 #pragma unroll
-        for (int a = 0; a < M; ++a) v += (w * Je[a * N + i2]) * SJc[a];
+        for (int a = 0; a < M; ++a) v += (w * (ok ? Je[a * N + i2] : S(0))) * SJc[a];
         acc[i2] += (double)v;   // H(i2, j)
       }
       S v = 0;
@@ -659,11 +689,16 @@ bool jitCreate(int scalar_bytes, int n_params, int n_outputs, int n_planes, int 
   out.source = out.wide ? kJitWidePrologue : kJitPrologue;
   out.source += "__device__ inline void user_setup(const S *x, S *a) {\n";
   out.source += (n_aux > 0 && setup_body) ? setup_body : "";
-  out.source += "\n}\n__device__ inline void user_residual(const S *x, const S *a, const S *d, S *r) {\n";
+  // IBaseModel::f / f_df return bool (model.h:32,43): "this index is not a residual" — the loops skip
+  // it (linearization.h:102,144).  A body says so by clearing the reserved local `valid`.
+  out.source += "\n}\n__device__ inline bool user_residual(const S *x, const S *a, const S *d, S *r) {\n"
+                "  bool valid = true;\n";
   out.source += residual_body;
-  out.source += "\n}\n__device__ inline void user_jacobian(const S *x, const S *a, const S *d, S *J) {\n";
+  out.source += "\n  return valid;\n}\n"
+                "__device__ inline bool user_jacobian(const S *x, const S *a, const S *d, S *J) {\n"
+                "  bool valid = true;\n";
   out.source += jacobian_body ? jacobian_body : "";
-  out.source += "\n}\n";
+  out.source += "\n  return valid;\n}\n";
   out.source += out.wide ? kJitWideSweep : kJitSweep;
   // Errors in the user's text must surface at construction: build the sweeps that touch each
   // body now (cost only: setup + residual; supplied Jacobian); the others on first use.

@@ -351,7 +351,10 @@ __device__ bool solveDampedPositive(const S *H, const S *b, S lambda, S *delta) 
       dk = fusedMulAdd(-L[k][j], u[j], dk);
     }
     // a pivot that has lost ten digits against its diagonal entry is where pivoting starts to matter
-    positive = positive && (dk > S(1e-10) * akk);
+    // — in fp32, with seven digits in all, one that is within 64 roundings of having cancelled away
+    // (1e-10 sits a thousand times below the fp32 epsilon: nothing would ever fall back)
+    constexpr S kPivotFloor = sizeof(S) == 8 ? S(1e-10) : S(64) * std::numeric_limits<S>::epsilon();
+    positive = positive && (dk > kPivotFloor * akk);
     d[k] = dk;
     inv_d[k] = fastReciprocal(dk);
 #pragma unroll

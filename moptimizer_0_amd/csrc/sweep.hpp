@@ -78,7 +78,16 @@ struct AffineBasis {
 };
 
 // Small parametric models over per-element scalar data (planes data[p * stride + i]).
-enum ScalarModelKind : int { kScalarExpCurve = 1, kScalarRational = 2, kScalarPowell = 3 };
+// (the *Marked kinds: the same models over observations some of which carry the NaN marker "not a
+// residual" — chosen by the library when it finds one in the data, so that data without markers, the
+// reference's own, run the kernels that do not look for them)
+enum ScalarModelKind : int {
+  kScalarExpCurve = 1,
+  kScalarRational = 2,
+  kScalarPowell = 3,
+  kScalarExpCurveMarked = 4,
+  kScalarRationalMarked = 5
+};
 
 template <typename S>
 struct ScalarSweepArgs {

@@ -539,21 +539,41 @@ __global__ __launch_bounds__(kBlockThreads) void reprojResidentSetKernel(
 //   Powell     Powell's singular function    tst/powell.cpp:21-60 (4 outputs, one element)
 // Same skeleton: per-element residual, analytic or forward-difference Jacobian
 // (linearization.h:101-117 / :143-154), loss weight, dense accumulation, workgroup partial row.
+// accept() is what IBaseModel::f / f_df return (model.h:32,43): false = "this index is not a residual",
+// and the sweep skips it (linearization.h:102,144).  The *Marked forms of the models over observations
+// (t, y) say so for an observation whose y is NaN — the marker the point2point sweeps use for a source
+// without a correspondence — and replace that y by a harmless one, so that everything computed for the
+// skipped index stays finite and a weight of zero is enough to leave it out (one select on the way
+// in, not one per residual and Jacobian entry).  The check costs 5 % of a sweep that is bound by its
+// arithmetic (10 M elements: 40.3 against 38.4 us), so data without markers run the forms without it.
+template <typename S>
+__device__ __forceinline__ bool acceptUnlessMarked(S (&d)[2]) {
+  const bool ok = d[1] == d[1];
+  d[1] = ok ? d[1] : S(0);
+  return ok;
+}
+
 template <typename S>
 struct ExpCurve {
   static constexpr int N = 2, M = 1, D = 2;
   static constexpr bool kHasJacobian = false;
+  __device__ static bool accept(S (&)[D]) { return true; }
   __device__ static void residual(const S *x, const S *d, S (&r)[M]) {
 #pragma clang fp contract(off)  // as written: the checker's arithmetic (forward differences amplify an ulp)
     r[0] = d[1] - exp(x[0] * d[0] + x[1]);
   }
   __device__ static void jacobian(const S *, const S *, S (&)[M][N]) {}
 };
+template <typename S>
+struct ExpCurveMarked : ExpCurve<S> {
+  __device__ static bool accept(S (&d)[2]) { return acceptUnlessMarked<S>(d); }
+};
 
 template <typename S>
 struct Rational {
   static constexpr int N = 2, M = 1, D = 2;
   static constexpr bool kHasJacobian = true;
+  __device__ static bool accept(S (&)[D]) { return true; }
   __device__ static void residual(const S *x, const S *d, S (&r)[M]) {
 #pragma clang fp contract(off)  // as written: the checker's arithmetic (forward differences amplify an ulp)
     r[0] = d[1] - (x[0] * d[0]) / (x[1] + d[0]);
@@ -564,11 +584,16 @@ struct Rational {
     J[0][1] = (x[0] * d[0]) / (denominator * denominator);
   }
 };
+template <typename S>
+struct RationalMarked : Rational<S> {
+  __device__ static bool accept(S (&d)[2]) { return acceptUnlessMarked<S>(d); }
+};
 
 template <typename S>
 struct Powell {
   static constexpr int N = 4, M = 4, D = 0;
   static constexpr bool kHasJacobian = true;
+  __device__ static bool accept(S (&)[1]) { return true; }
   __device__ static void residual(const S *x, const S *, S (&r)[M]) {
 #pragma clang fp contract(off)  // as written: the checker's arithmetic (forward differences amplify an ulp)
     r[0] = x[0] + 10 * x[1];
@@ -587,11 +612,19 @@ struct Powell {
   }
 };
 
+// The skeleton of the tiled sweeps (and of the run-time compiled twin, jit_model.cpp): a lane takes
+// the V = 16 / sizeof(S) consecutive elements of one 16-byte pack per data plane and step, the next
+// step's packs are requested before this one's arithmetic starts, the loss kind is taken out of the
+// element, products go into the sums as fused multiply-adds (accumulateDense).  Rounds 1-3 loaded
+// 8 bytes per lane and plane in a plain grid-stride loop: 52 us for the forward-difference sweep of
+// the exp curve over 10 M elements against 37 us for the same model compiled at run time.
 template <typename S, template <typename> class ModelT, int JAC, int COV, bool COST_ONLY>
 __device__ __forceinline__ void scalarModelBody(const ScalarSweepArgs<S> &A, int block,
                                                 int num_blocks) {
   using Model = ModelT<S>;
   constexpr int N = Model::N, M = Model::M, D = Model::D;
+  constexpr int V = TileShape<S>::kVec;
+  constexpr bool kNumeric = JAC == kJacNumeric || !Model::kHasJacobian;
   constexpr int NACC =
       COST_ONLY ? 1 : ((COV == kCovGeneral) ? N * N + N + 1 : N * (N + 1) / 2 + N + 1);
   double acc[NACC];
@@ -602,39 +635,79 @@ __device__ __forceinline__ void scalarModelBody(const ScalarSweepArgs<S> &A, int
   S inv_h[N];
 #pragma unroll
   for (int j = 0; j < N; ++j) inv_h[j] = S(1) / A.h[j];
-  for (long long i = (long long)block * kBlockThreads + threadIdx.x; i < A.count;
-       i += (long long)num_blocks * kBlockThreads) {
-    S d[D > 0 ? D : 1];
+  // `robust`: the loss kind is a property of the sweep (a branch inside the element splits its basic
+  // block and lets the compiler sink one element's accumulation below the next one's residuals)
+  auto sweep = [&](auto robust) {
+    auto element = [&](S (&d)[D > 0 ? D : 1], bool valid) {
+      // an index the model rejects is skipped like a slot past the end: weight zero (its data made
+      // harmless by accept())
+      valid = Model::accept(d) && valid;
+      S r[M];
+      Model::residual(A.x, d, r);
+      S rr = 0;
 #pragma unroll
-    for (int p = 0; p < D; ++p) d[p] = A.data[p * A.stride + i];
-    S r[M];
-    Model::residual(A.x, d, r);
-    S rr = 0;
-#pragma unroll
-    for (int a = 0; a < M; ++a) rr += r[a] * r[a];
-    if constexpr (COST_ONLY) {
-      acc[0] += double(rr);
-    } else {
-      S J[M][N];
-      if (JAC == kJacNumeric || !Model::kHasJacobian) {
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-          S xp[N];
-#pragma unroll
-          for (int k = 0; k < N; ++k) xp[k] = A.x[k];
-          xp[j] += A.h[j];  // linearization.h:89
-          S rp[M];
-          Model::residual(xp, d, rp);
-#pragma unroll
-          for (int a = 0; a < M; ++a) J[a][j] = (rp[a] - r[a]) * inv_h[j];  // :105
-        }
+      for (int a = 0; a < M; ++a) rr += r[a] * r[a];
+      rr = valid ? rr : S(0);
+      if constexpr (COST_ONLY) {
+        acc[0] += double(rr);
       } else {
-        Model::jacobian(A.x, d, J);
+        S J[M][N];
+        if constexpr (kNumeric) {
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            S xp[N];
+#pragma unroll
+            for (int k = 0; k < N; ++k) xp[k] = A.x[k];
+            xp[j] += A.h[j];  // linearization.h:89
+            S rp[M];
+            Model::residual(xp, d, rp);
+#pragma unroll
+            for (int a = 0; a < M; ++a) J[a][j] = (rp[a] - r[a]) * inv_h[j];  // :105
+          }
+        } else {
+          Model::jacobian(A.x, d, J);
+        }
+        S w = S(1);
+        if constexpr (decltype(robust)::value) w = lossWeight<S>(kLossGemanMcClure, A.loss_param, rr);
+        accumulateDense<S, M, N, COV>(J, r, valid ? w : S(0), rr, A.cov, acc);
       }
-      const S w = lossWeight<S>(A.loss_kind, A.loss_param, rr);
-      accumulateDense<S, M, N, COV>(J, r, w, rr, A.cov, acc);
+    };
+    const long long step = (long long)num_blocks * kBlockThreads * V;
+    long long i = ((long long)block * kBlockThreads + threadIdx.x) * V;
+    Pack<S> cur[D > 0 ? D : 1], nxt[D > 0 ? D : 1];
+    // (a run-time choice between these and non-temporal loads — one uniform branch per pack — cost
+    // 6 us of the 38 at 10 M elements, whichever way it went: profiles/r4_jit_timing.txt)
+    auto load = [&](const S *from) { return loadPack<S>(from); };
+    if (i < A.count) {
+#pragma unroll
+      for (int p = 0; p < D; ++p) nxt[p] = load(A.data + p * A.stride + i);
     }
-  }
+    for (; i < A.count; i += step) {
+#pragma unroll
+      for (int p = 0; p < D; ++p) cur[p] = nxt[p];
+      // the next step's packs are requested before this one's arithmetic starts (past the end: this
+      // step's again — an unconditional load, see sweepTiles)
+      const long long ahead = i + step < A.count ? i + step : i;
+#pragma unroll
+      for (int p = 0; p < D; ++p) nxt[p] = load(A.data + p * A.stride + ahead);
+      // a slot past the end (the zero-padded tail of the last pack) is evaluated on the pack's first
+      // element, which is in range, and enters every sum with weight zero
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        if constexpr (kNumeric && !COST_ONLY) __builtin_amdgcn_sched_barrier(0);  // one element after the other
+        const bool valid = i + e < A.count;
+        S d[D > 0 ? D : 1];
+#pragma unroll
+        for (int p = 0; p < D; ++p) d[p] = valid ? cur[p].v[e] : cur[p].v[0];
+        element(d, valid);
+      }
+      if constexpr (kNumeric && !COST_ONLY) __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if (!COST_ONLY && A.loss_kind == kLossGemanMcClure)
+    sweep(std::true_type());
+  else
+    sweep(std::false_type());
   blockReduceStore<NACC>(acc, A.partials + size_t(block) * NACC);
 }
 
@@ -1468,6 +1541,10 @@ hipError_t launchScalarModel(const ScalarSweepArgs<S> &args, int model, bool cos
       return launchScalarFor<S, Rational>(args, cost_only, jac_mode, cov_mode, grid, stream);
     case kScalarPowell:
       return launchScalarFor<S, Powell>(args, cost_only, jac_mode, cov_mode, grid, stream);
+    case kScalarExpCurveMarked:
+      return launchScalarFor<S, ExpCurveMarked>(args, cost_only, jac_mode, cov_mode, grid, stream);
+    case kScalarRationalMarked:
+      return launchScalarFor<S, RationalMarked>(args, cost_only, jac_mode, cov_mode, grid, stream);
     default:
       return hipErrorInvalidValue;
   }
@@ -1750,6 +1827,10 @@ hipError_t launchScalarModelResidentSet(const ResidentSweepSet &set, const LmCon
       return launchScalarResidentSetFor<S, Rational>(set, control, jac_mode, cov_mode, stream);
     case kScalarPowell:
       return launchScalarResidentSetFor<S, Powell>(set, control, jac_mode, cov_mode, stream);
+    case kScalarExpCurveMarked:
+      return launchScalarResidentSetFor<S, ExpCurveMarked>(set, control, jac_mode, cov_mode, stream);
+    case kScalarRationalMarked:
+      return launchScalarResidentSetFor<S, RationalMarked>(set, control, jac_mode, cov_mode, stream);
     default:
       return hipErrorInvalidValue;
   }
@@ -1770,6 +1851,10 @@ hipError_t launchScalarModelResident(const ScalarSweepArgs<S> *d_args, const LmC
       return launchScalarResidentFor<S, Rational>(d_args, control, jac_mode, cov_mode, grid, stream);
     case kScalarPowell:
       return launchScalarResidentFor<S, Powell>(d_args, control, jac_mode, cov_mode, grid, stream);
+    case kScalarExpCurveMarked:
+      return launchScalarResidentFor<S, ExpCurveMarked>(d_args, control, jac_mode, cov_mode, grid, stream);
+    case kScalarRationalMarked:
+      return launchScalarResidentFor<S, RationalMarked>(d_args, control, jac_mode, cov_mode, grid, stream);
     default:
       return hipErrorInvalidValue;
   }

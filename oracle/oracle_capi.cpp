@@ -279,7 +279,8 @@ int oracle_camera_minimize(const double *points_xyzw, const int32_t *pixels_uv,
   }
 }
 
-// The reference tests' small parametric models (model_kind: 1 exp curve, 2 rational, 3 Powell),
+// The reference tests' small parametric models (model_kind: 1 exp curve, 2 rational, 3 Powell; 4 / 5:
+// the rational / exp curve model whose f / f_df return false for an observation with a NaN y),
 // scalar_bytes 4 or 8 (exp curve / Powell: 8 only), numeric = 0 analytic cost class, 1 numeric.
 // t, y: `count` scalars each.  H: n*n column-major, b: n.
 int oracle_scalar_linearize(int scalar_bytes, int model_kind, int numeric, const void *t,
@@ -293,19 +294,32 @@ int oracle_scalar_linearize(int scalar_bytes, int model_kind, int numeric, const
       *(float *)cost = c->linearize((const float *)x, (float *)H, (float *)b);
       return 0;
     }
+    if (model_kind == 4 && scalar_bytes == 4) {
+      auto model = std::make_shared<oracle::SkippingRationalModel<float>>((const float *)t, (const float *)y);
+      auto c = makeCost<float>(cc, model, 2, 1, count, (const float *)cov, loss_kind, loss_param);
+      *(float *)cost = c->linearize((const float *)x, (float *)H, (float *)b);
+      return 0;
+    }
     if (scalar_bytes != 8) return -1;
     std::unique_ptr<moptimizer::CostFunctionBase<double>> c;
     std::vector<double> interleaved;
-    if (model_kind == 1) {
+    if (model_kind == 1 || model_kind == 5) {
       interleaved.resize(2 * size_t(count));
       for (int i = 0; i < count; ++i) {
         interleaved[2 * i] = ((const double *)t)[i];
         interleaved[2 * i + 1] = ((const double *)y)[i];
       }
-      c = makeCost<double>(cc, std::make_shared<oracle::CurveFittingModel>(interleaved.data()), 2, 1,
-                           count, (const double *)cov, loss_kind, loss_param);
+      if (model_kind == 1)
+        c = makeCost<double>(cc, std::make_shared<oracle::CurveFittingModel>(interleaved.data()), 2, 1,
+                             count, (const double *)cov, loss_kind, loss_param);
+      else
+        c = makeCost<double>(cc, std::make_shared<oracle::SkippingCurveFittingModel>(interleaved.data()),
+                             2, 1, count, (const double *)cov, loss_kind, loss_param);
     } else if (model_kind == 2) {
       c = makeCost<double>(cc, std::make_shared<oracle::RationalModel<double>>((const double *)t, (const double *)y),
+                           2, 1, count, (const double *)cov, loss_kind, loss_param);
+    } else if (model_kind == 4) {
+      c = makeCost<double>(cc, std::make_shared<oracle::SkippingRationalModel<double>>((const double *)t, (const double *)y),
                            2, 1, count, (const double *)cov, loss_kind, loss_param);
     } else if (model_kind == 3) {
       c = makeCost<double>(cc, std::make_shared<oracle::PowellModel>(), 4, 4, count,

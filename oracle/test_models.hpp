@@ -14,6 +14,7 @@
 #pragma once
 
 #include <cmath>
+#include <limits>
 #include <cstdint>
 #include <stdexcept>
 
@@ -273,6 +274,52 @@ class RationalModel : public moptimizer::BaseModelJacobian<Scalar, RationalModel
  private:
   const Scalar *data_x_;
   const Scalar *data_y_;
+};
+
+// The interface's other branch: f / f_df returning false for an index (model.h:32,43), which the
+// loops skip (linearization.h:102,144).  The reference's own test models always return true, so these
+// two are not restatements of a reference model but of that contract, over the rational and the exp
+// curve models above: an observation whose y is NaN is not a residual.  (The device models use the
+// same marker.)  What they leave in f_x / jacobian for a rejected index is deliberately poison.
+template <typename Scalar>
+class SkippingRationalModel : public moptimizer::BaseModelJacobian<Scalar, SkippingRationalModel<Scalar>> {
+ public:
+  SkippingRationalModel(const Scalar *xs, const Scalar *ys) : data_x_(xs), data_y_(ys) {}
+  ORACLE_SO3_EXACT bool f(const Scalar *x, Scalar *residual, unsigned int index) const override {
+    ORACLE_SO3_EXACT_BODY
+    residual[0] = data_y_[index] - (x[0] * data_x_[index]) / (x[1] + data_x_[index]);
+    return !std::isnan(data_y_[index]);
+  }
+  bool f_df(const Scalar *x, Scalar *f_x, Scalar *jacobian, unsigned int index) const override {
+    const Scalar denominator = x[1] + data_x_[index];
+    f_x[0] = data_y_[index] - (x[0] * data_x_[index]) / (x[1] + data_x_[index]);
+    jacobian[0] = -data_x_[index] / denominator;
+    jacobian[1] = (x[0] * data_x_[index]) / (denominator * denominator);
+    if (std::isnan(data_y_[index])) {
+      jacobian[0] = jacobian[1] = std::numeric_limits<Scalar>::quiet_NaN();
+      return false;
+    }
+    return true;
+  }
+
+ private:
+  const Scalar *data_x_;
+  const Scalar *data_y_;
+};
+
+class SkippingCurveFittingModel : public moptimizer::BaseModel<double, SkippingCurveFittingModel> {
+ public:
+  explicit SkippingCurveFittingModel(const double *dataset) : dataset_(dataset) {}
+  ORACLE_SO3_EXACT bool f(const double *x, double *f_x, unsigned int index) const override {
+    ORACLE_SO3_EXACT_BODY
+    const double x_ = dataset_[2 * index];
+    const double y_ = dataset_[2 * index + 1];
+    f_x[0] = y_ - std::exp(x[0] * x_ + x[1]);
+    return !std::isnan(y_);
+  }
+
+ private:
+  const double *dataset_;
 };
 
 // src - tgt, no parameters.

@@ -53,6 +53,19 @@ def main():
             print("n=%9d %-30s kernel %8.2f us  %7.1f GB/s  call %8.2f us" %
                   (n, name, k, n * 16 / (k * 1e-6) / 1e9, wall), flush=True)
         print("n=%9d jit create (compile + upload) %.1f ms" % (n, create_ms), flush=True)
+        # the built-in model with a Jacobian of its own (tst/test_models.h:7-20) and its run-time compiled twin
+        yr = 0.36 * t / (0.56 + t) + rng.normal(0, 0.02, n)
+        rational = mo.ScalarModelCost(mo.capi.MODEL_RATIONAL, t, yr)
+        jit_rational = mo.JitModelCost(2, 1, "r[0] = d[1] - (x[0] * d[0]) / (x[1] + d[0]);",
+                                       "const S q = x[1] + d[0]; J[0] = -d[0] / q; J[1] = (x[0] * d[0]) / (q * q);",
+                                       planes=np.stack([t, yr]))
+        for name, cost, mode in (("built-in rational, analytic", rational, 0),
+                                 ("built-in rational, numeric", rational, 2),
+                                 ("jit rational, analytic", jit_rational, 0),
+                                 ("jit rational, numeric", jit_rational, 2)):
+            k, wall = timed(cost, np.array([0.3, 0.5]), mode, args.iters)
+            print("n=%9d %-30s kernel %8.2f us  %7.1f GB/s  call %8.2f us" %
+                  (n, name, k, n * 16 / (k * 1e-6) / 1e9, wall), flush=True)
         planes = rng.normal(0, 1.0, (3, n))
         planes[0] = np.linspace(0.0, 6.0, n)
         osc = mo.JitModelCost(

@@ -149,7 +149,9 @@ class Oracle:
 
     def scalar_linearize(self, kind, t, y, x, numeric=True, cov=None, loss_kind=0, loss_param=0.0,
                          dtype=np.float64):
-        n, m = {1: (2, 1), 2: (2, 1), 3: (4, 4)}[kind]
+        # kind: 1 exp curve, 2 rational, 3 Powell; 4 / 5: rational / exp curve whose f / f_df return
+        # false for an observation with a NaN y
+        n, m = {1: (2, 1), 2: (2, 1), 3: (4, 4), 4: (2, 1), 5: (2, 1)}[kind]
         count = 1 if kind == 3 else len(t)
         t = None if t is None else np.ascontiguousarray(t, dtype=dtype)
         y = None if y is None else np.ascontiguousarray(y, dtype=dtype)

@@ -195,6 +195,32 @@ def test_float32_cost(hip_lib):
     cost.close()
 
 
+def test_float32_nearly_rank_deficient_normal_equations(hip_lib):
+    """fp32 with a Hessian close to singular (the rational model observed over a narrow range of t:
+    its two Jacobian columns are nearly parallel, the second pivot of the damped system cancels to a
+    few 1e-7 of its diagonal entry): the device's unpivoted solve must hand such a system to the
+    pivoted one — its test for that scales with the type's epsilon (64 eps; the fp64 constant 1e-10
+    would never fire in fp32) — and the loop must still descend as the host loop over the same cost
+    does (whose solve is numpy's, in fp64, on the same fp32 sums)."""
+    mo = hip_lib
+    rng = np.random.default_rng(8)
+    n = 20_000
+    t = (2.0 + 1e-3 * rng.random(n)).astype(np.float32)
+    y = (0.36 * t / (0.56 + t) + rng.normal(0, 1e-3, n)).astype(np.float32)
+    cost = mo.ScalarModelCost(mo.capi.MODEL_RATIONAL, t, y, dtype=np.float32)
+    x0 = np.array([0.5, 0.9], dtype=np.float32)
+    H, b, y0 = cost.linearize(x0, mo.JAC_ANALYTIC)
+    lam = 1e-9 * np.abs(np.diag(H)).max()
+    A = np.array(H, dtype=np.float64) + lam * np.diag(np.diag(H))
+    pivot2 = A[1, 1] - A[1, 0] * A[0, 1] / A[0, 0]
+    assert 0 < pivot2 / A[1, 1] < 64 * np.finfo(np.float32).eps, pivot2 / A[1, 1]   # the regime meant
+    xd, rep = mo.capi.lm_minimize([cost], [mo.JAC_ANALYTIC], x0)
+    xh, status, iters = host_lm(cost, mo.JAC_ANALYTIC, x0)
+    cd, ch = cost.compute_cost(xd.astype(np.float32)), cost.compute_cost(xh.astype(np.float32))
+    assert np.isfinite(xd).all() and rep["status"] in (CONVERGED, MAX_ITERATIONS, SMALL_DELTA)
+    assert cd < 0.05 * y0 and cd <= ch * 1.05 + 1e-6, (cd, ch, y0, rep)
+
+
 def test_blocking_calls_still_work_after_a_device_resident_solve(hip_lib, oracle):
     mo = hip_lib
     src, tgt = ds.synthetic_pair(30_000, seed=6, noise=0.01)

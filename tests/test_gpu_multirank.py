@@ -169,7 +169,11 @@ def _check_multirank_line(line, world, rehearsal):
         assert "rccl" in line["by_collective"]
     cpu = line["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["value"] > 1e6
-    assert "extras_incomplete" not in line, line.get("note")
+    # the two flags a reader of a one-shot multi-GPU run looks at first: always there, both clear
+    assert line["extras_incomplete"] is False and line["rccl_incomplete"] is False, line.get("note")
+    assert cfg["collective_requested"] in ("auto", "host", "peer", "rccl", "torch")
+    if rccl.get("timed_pass") in ("done", "the headline pass"):
+        assert 0 < rccl["step_frac"] < 1.2 and rccl["ms_per_step"] > 0
     c4 = line["config4_strong"]
     assert c4["total_correspondences"] == 10_000_000 and c4["ms_per_step"] > 0
     assert c4["kernel_ms"] > 0 and set(c4["by_collective"]) >= {"none", "host", "peer"}
@@ -198,9 +202,9 @@ def test_bench_launches_its_own_ranks(hip_lib):
 
 
 def test_driver_command_rehearsed_with_four_ranks(hip_lib):
-    """The driver's multi-GPU command as it stands — default workload (10 M correspondences per
-    rank), default settling, every extra pass, the 10 M strong-scaling split, the CPU baseline —
-    with 4 ranks (this pool lets 6 processes share one GPU, and the test runner is one of them;
+    """The driver's multi-GPU command — default workload (10 M correspondences per rank), default
+    settling, every extra pass, the 10 M strong-scaling split, the CPU baseline; plus `--collective
+    rccl`, so that the transport north_star names is the one asked for — with 4 ranks (this pool lets 6 processes share one GPU, and the test runner is one of them;
     scripts/rehearse_driver_command.sh runs the same with 6 outside pytest), started by
     torch.distributed.run like the driver does.  It must report every field and finish well inside
     the driver's 600 s."""
@@ -220,7 +224,8 @@ def test_driver_command_rehearsed_with_four_ranks(hip_lib):
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                           "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
                           "--master-port", str(port), os.path.join(ds.ROOT, "bench.py"),
-                          "--gpus", str(world), "--steps", "20", "--warmup", "5"],
+                          "--gpus", str(world), "--steps", "20", "--warmup", "5",
+                          "--collective", "rccl"],
                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=500)
     elapsed = time.time() - t0
     assert out.returncode == 0, out.stderr.decode()[-3000:]
@@ -230,9 +235,19 @@ def test_driver_command_rehearsed_with_four_ranks(hip_lib):
     assert line["check"]["H00"] == 10_000_000.0 * world
     assert line["config"]["correspondences_per_gpu"] == 10_000_000
     _check_multirank_line(line, world, rehearsal)
+    # RCCL asked for by name: the headline where it can run; where the ranks share a GPU it refuses, the
+    # bench falls back to the fused combines and says so (the branch a driver run would take if
+    # ncclCommInitRank failed on its node)
+    assert line["config"]["collective_requested"] == "rccl"
+    if rehearsal:
+        assert line["config"]["collective_fell_back"] is True and line["config"]["collective"] in ("host", "peer")
+        assert line["rccl"]["attached"] is False
+    else:
+        assert line["config"]["collective"] == "rccl" and line["config"]["collective_fell_back"] is False
+        assert line["rccl"]["timed_pass"] == "the headline pass"
     assert elapsed < 300, elapsed
     keep = os.path.join(ds.ROOT, "gpurun_out")
     if os.path.isdir(keep):
         line["_rehearsal_wall_s"] = elapsed
-        with open(os.path.join(keep, "r3_4rank_driver_command_rehearsal.json"), "w") as f:
+        with open(os.path.join(keep, "r4_4rank_driver_command_rehearsal.json"), "w") as f:
             json.dump(line, f, indent=1)

@@ -1433,6 +1433,112 @@ def test_wide_model_with_supplied_jacobian_against_numpy(hip_lib, dtype, n, m):
         cost.close()
 
 
+def test_models_that_reject_indices(hip_lib, oracle):
+    """f / f_df returning false for an index (model.h:32,43): the loops skip it (linearization.h:102,144;
+    the perturbed models' verdicts are ignored, :104).  The reference's own test models always return true;
+    the oracle's SkippingRationalModel / SkippingCurveFittingModel restate the contract (an observation whose
+    y is NaN is not a residual, what they leave behind for it is NaN).  Device side: the built-in
+    observation models use the same marker; a run-time compiled body clears the reserved local `valid`.
+    Analytic, forward-difference and cost-only sweeps, loss and covariance, fp64 and fp32, the wide form,
+    and the device-resident loop."""
+    mo = hip_lib
+    rng = np.random.default_rng(31)
+    tr = np.abs(rng.normal(1.0, 1.0, 3001)) + 0.05
+    yr = 0.36 * tr / (0.56 + tr) + rng.normal(0, 0.01, tr.shape)
+    rejected = rng.random(tr.shape) < 0.15
+    rejected[[0, 1, 2, 1499, 3000]] = True                 # whole packs, pack tails, the last element
+    ym = np.where(rejected, np.nan, yr)
+    skip_residual = "if (!(d[1] == d[1])) valid = false;  r[0] = d[1] - (x[0] * d[0]) / (x[1] + d[0]);"
+    skip_jacobian = ("const S q = x[1] + d[0]; J[0] = -d[0] / q; J[1] = (x[0] * d[0]) / (q * q);"
+                     "if (!(d[1] == d[1])) { valid = false; J[0] = J[1] = d[1]; }")
+    for dtype, tol in ((np.float64, None), (np.float32, 5e-3)):
+        x = np.array([0.9, 0.2], dtype=dtype)
+        builtin = mo.ScalarModelCost(mo.capi.MODEL_RATIONAL, tr, ym, dtype=dtype)
+        jit = mo.JitModelCost(2, 1, skip_residual, skip_jacobian, planes=np.stack([tr, ym]), dtype=dtype)
+        for cost in (builtin, jit):
+            for cov, lk, lp in ((None, 0, 0.0), (np.array([[0.5]]), 1, 0.05)):
+                cost.set_covariance(None if cov is None else cov.astype(dtype))
+                cost.set_loss(lk, lp)
+                for numeric in (True, False):
+                    want = oracle.scalar_linearize(4, tr, ym, x, numeric=numeric, cov=cov, loss_kind=lk,
+                                                   loss_param=lp, dtype=dtype)
+                    want = tuple(np.asarray(v, dtype=np.float64) for v in want)
+                    assert np.isfinite(want[0]).all() and want[2] > 0
+                    check(cost.linearize(x, 2 if numeric else 0), want,
+                          tol=tol if tol else (fd_tolerance_libm(x) if numeric else REL))
+                assert abs(cost.compute_cost(x) - want[2]) <= (tol or REL) * want[2]
+            cost.close()
+    # the exp curve (no Jacobian of its own): built-in and as source
+    t = np.linspace(0.0, 4.95, 5000)
+    y = np.exp(0.3 * t + 0.1) + rng.normal(0, 0.2, t.shape)
+    y[rng.random(t.shape) < 0.2] = np.nan
+    x = np.array([0.29, 0.13])
+    want = oracle.scalar_linearize(5, t, y, x, numeric=True, loss_kind=1, loss_param=100.0)
+    for cost in (mo.ScalarModelCost(mo.capi.MODEL_EXP_CURVE, t, y),
+                 mo.JitModelCost(2, 1, "valid = d[1] == d[1]; r[0] = d[1] - exp(x[0] * d[0] + x[1]);",
+                                 planes=np.stack([t, y]))):
+        cost.set_loss(1, 100.0)
+        check(cost.linearize(x, 2), want, tol=fd_tolerance_libm(x))
+        assert abs(cost.compute_cost(x) - want[2]) <= REL * want[2]
+    # a predicate on a data plane of its own, against the same model over the kept observations only
+    mask = (rng.random(tr.shape) < 0.7).astype(np.float64)
+    keep = mask > 0.5
+    gated = mo.JitModelCost(2, 1, "valid = d[2] > S(0.5); r[0] = d[1] - (x[0] * d[0]) / (x[1] + d[0]);",
+                            "const S q = x[1] + d[0]; J[0] = -d[0] / q; J[1] = (x[0] * d[0]) / (q * q);",
+                            planes=np.stack([tr, yr, mask]))
+    x = np.array([0.9, 0.2])
+    for numeric in (True, False):
+        want = oracle.scalar_linearize(2, tr[keep], yr[keep], x, numeric=numeric)
+        check(gated.linearize(x, 2 if numeric else 0), want, tol=fd_tolerance_libm(x) if numeric else REL)
+    # ... and under the device-resident loop: the same minimum as over the kept observations
+    plain = mo.JitModelCost(2, 1, "r[0] = d[1] - (x[0] * d[0]) / (x[1] + d[0]);",
+                            "const S q = x[1] + d[0]; J[0] = -d[0] / q; J[1] = (x[0] * d[0]) / (q * q);",
+                            planes=np.stack([tr[keep], yr[keep]]))
+    for jac in (mo.JAC_ANALYTIC, mo.JAC_NUMERIC):
+        xg, rep_g = mo.capi.lm_minimize([gated], [jac], np.array([0.9, 0.2]))
+        xp, rep_p = mo.capi.lm_minimize([plain], [jac], np.array([0.9, 0.2]))
+        # (the two sum in different orders, and the loop ends on a noise-level step: the same minimum,
+        # not the same number of iterations)
+        assert rep_g["status"] == rep_p["status"], (rep_g, rep_p)
+        assert np.abs(xg - xp).max() < 1e-6 and abs(xg[0] - 0.36) < 0.02 and abs(xg[1] - 0.56) < 0.05
+    # the wide form (n = 9): elements rejected by the residual body, or by the Jacobian body alone
+    n, m, count = 9, 2, 533
+    tw = rng.uniform(0.0, 3.0, count)
+    a_idx, k_idx = np.arange(1, m + 1)[:, None], np.arange(1, n + 1)[None, :]
+    Jw = np.cos((a_idx * k_idx)[None, :, :] * tw[:, None, None])
+    x_true = rng.uniform(-1, 1, n)
+    yw = Jw @ x_true + 0.05 * rng.standard_normal((count, m))
+    flag = rng.integers(0, 3, count).astype(np.float64)      # 0 keep, 1 residual says no, 2 Jacobian says no
+    residual = """
+  for (int a = 0; a < %d; ++a) {
+    S v = 0;
+    for (int k = 0; k < %d; ++k) v += cos(S((a + 1) * (k + 1)) * d[0]) * x[k];
+    r[a] = v - d[1 + a];
+  }
+  if (d[%d] == S(1)) { valid = false; r[0] = sqrt(S(-1)); }""" % (m, n, m + 1)
+    jacobian = """
+  for (int a = 0; a < %d; ++a)
+    for (int k = 0; k < %d; ++k) J[a * %d + k] = cos(S((a + 1) * (k + 1)) * d[0]);
+  if (d[%d] == S(2)) { valid = false; J[3] = sqrt(S(-1)); }""" % (m, n, n, m + 1)
+    planes = np.vstack([tw[None, :], yw.T, flag[None, :]])
+    wide = mo.JitModelCost(n, m, residual, jacobian_body=jacobian, planes=planes)
+    xw = x_true + 0.1 * rng.standard_normal(n)
+    r = Jw @ xw - yw
+    for jac, kept in ((mo.JAC_ANALYTIC, flag == 0), (mo.JAC_NUMERIC, flag != 1)):
+        for loss in (0.0, 5.0):
+            wide.set_loss(mo.LOSS_GEMAN_MCCLURE if loss else mo.LOSS_NONE, loss)
+            rr = (r * r).sum(axis=1)
+            w = ((loss * loss) / (rr + loss) ** 2 if loss else np.ones(count)) * kept
+            Hw = np.einsum("i,iam,ibn->mn", w, Jw, Jw)   # identity covariance: sum over a = b
+            Hw = np.einsum("i,iam,ian->mn", w, Jw, Jw)
+            bw = np.einsum("i,iam,ia->m", w, Jw, r)
+            H, b, s_sum = wide.linearize(xw, jac)
+            assert np.isfinite(H).all() and np.abs(H - Hw).max() <= REL * np.abs(Hw).max(), (jac, loss)
+            assert np.abs(b - bw).max() <= REL * max(np.abs(bw).max(), np.abs(Hw).max() * 1e-3)
+            assert abs(s_sum - rr[kept].sum()) <= REL * rr[kept].sum()
+    assert abs(wide.compute_cost(xw) - rr[flag != 1].sum()) <= REL * rr[flag != 1].sum()
+
+
 def test_linked_costs_sweep_together_and_return_the_same_numbers(hip_lib, oracle):
     """mopt_costs_link: the optimizer's loop asks the costs of a problem one after the other at the same
     x (levenberg_marquadt_dyn.cpp:52-59, :86); linked, the first call queues the others' sweeps too.  The
