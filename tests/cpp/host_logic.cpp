@@ -11,6 +11,7 @@
 #include <sstream>
 #include <stdexcept>
 
+#include "moptimizer_amd/cost_function_hip.hpp"
 #include "moptimizer_caller/levenberg_marquadt.hpp"
 #include "moptimizer_amd/so3.hpp"
 
@@ -305,10 +306,50 @@ static void denseAndSo3() {
   }
 }
 
+// The binding's recovery of a Geman-McClure threshold from a loss object that keeps it private, as
+// the reference's class does (loss_function/geman_mcclure.h:6-19: no accessor): one probe of
+// weight(1) = t^2 / (1 + t)^2 gives t = sqrt(w) / (1 - sqrt(w)) (cost_function_hip.hpp,
+// gemanMcClureThreshold).  Against a class of the reference's shape here, since its headers are not in
+// this image; the class of host_api.hpp has an accessor and must come back exactly.
+template <typename T>
+class ReferenceShapedGemanMcClure : public moptimizer::loss::ILossFunction<T> {
+ public:
+  explicit ReferenceShapedGemanMcClure(T threshold) : threshold_(threshold) {}
+  T weight(T errorSquaredNorm) override {
+    const T den = errorSquaredNorm + threshold_;
+    return (threshold_ * threshold_) / (den * den);
+  }
+
+ private:
+  T threshold_;
+};
+
+template <typename T>
+static void lossThresholdRecoveryFor(const char *type_name, double tolerance_at_1, double tolerance_at_1e4) {
+  const double thresholds[] = {0.05, 0.8, 1.0, 100.0, 1e4};
+  for (double t : thresholds) {
+    ReferenceShapedGemanMcClure<T> hidden{T(t)};
+    const double got = moptimizer::hip::gemanMcClureThreshold(&hidden, 0);
+    // 1 - sqrt(w) cancels as t grows: the error is ~ t * eps relative
+    const double tolerance = t <= 1.0 ? tolerance_at_1 : tolerance_at_1 + (tolerance_at_1e4 - tolerance_at_1) * t / 1e4;
+    expectTrue((std::string("threshold recovered from weight(1), ") + type_name + ", t = " + std::to_string(t)).c_str(),
+               std::fabs(got - double(T(t))) <= tolerance * t);
+    moptimizer::loss::GemmanMCClure<T> open{T(t)};
+    expectTrue((std::string("threshold through the accessor, ") + type_name).c_str(),
+               moptimizer::hip::gemanMcClureThreshold(&open, 0) == double(T(t)));
+  }
+}
+
+static void lossThresholdRecovery() {
+  lossThresholdRecoveryFor<double>("double", 1e-14, 1e-11);
+  lossThresholdRecoveryFor<float>("float", 1e-6, 2e-3);
+}
+
 int main() {
   optimizerStatuses();
   ldlt();
   denseAndSo3();
+  lossThresholdRecovery();
   std::printf("SUMMARY %d checks, failures=%d\n", g_checks, g_fail);
   return g_fail == 0 ? 0 : 1;
 }
