@@ -158,7 +158,7 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
   // for another cost (its own stream, or the caller's) write the same partial rows: wait for them.
   // (Running each cost's sweeps on its own stream instead, joined by events, was measured and
   // dropped: a cross-queue dependency costs 7-13 us on this runtime, more than the sweeps that
-  // would overlap — DESIGN.md section 3.)
+  // would overlap — profiles/NOTES.md, "Device-resident Levenberg-Marquardt".)
   // So does a sweep queued ahead for a linked cost (mopt_costs_link) that nobody has consumed yet.
   for (int k = 0; k < num_costs; ++k) {
     mopt_cost *ck = costs[k];

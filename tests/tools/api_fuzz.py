@@ -236,7 +236,7 @@ def run(args):
             note("set_data")
         else:
             # |x_j| >= 0.05: a forward step h = sqrt(eps) |x_j| amplifies the last-bit difference between
-            # the device's exp and glibc's by eps / h — not what is being tested here
+            # the device's exp and glibc's by eps / h (profiles/NOTES.md, "Parity") — not what is being tested here
             xc = rng.uniform(0.05, 0.5, 2) * rng.choice([-1.0, 1.0], 2)
             H, b, c = curve.cost.linearize(xc, mo.JAC_NUMERIC)
             Hw, bw, cw = oracle.scalar_linearize(1, t, y, xc, numeric=True)
