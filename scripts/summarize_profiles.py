@@ -61,7 +61,12 @@ def main():
         print(json.dumps(res, indent=1))
         if len(sys.argv) >= 6:
             sweeps = {k: d for k, d in res.items() if d.get("launches_FETCH_SIZE", 0) > 2}
-            name = max(sweeps, key=lambda k: sweeps[k]["hbm_bytes_per_launch"])
+            # the sweep kernel of the run: among the kernels that move (nearly) the most bytes per launch,
+            # the one launched most often (the bench also times the literal form of the same sweep a few
+            # times: same bytes, a handful of launches)
+            top = max(d["hbm_bytes_per_launch"] for d in sweeps.values())
+            name = max((k for k, d in sweeps.items() if d["hbm_bytes_per_launch"] > 0.9 * top),
+                       key=lambda k: sweeps[k]["launches_FETCH_SIZE"])
             tpath = os.path.join(out_dir, "hbm_traffic.json")
             table = json.load(open(tpath)) if os.path.exists(tpath) else {}
             table[sys.argv[5]] = res[name]["hbm_bytes_per_launch"]

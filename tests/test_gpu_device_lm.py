@@ -518,3 +518,38 @@ def test_several_costs_in_every_combination_of_sweep_kinds(hip_lib):
         assert np.abs(x - np.array([0.3, 0.1])).max() < 1e-2
     for c in parts + [one]:
         c.close()
+
+
+def test_four_wide_costs_each_with_full_rows(hip_lib):
+    """Four wide run-time compiled costs (n = 14: rows of n^2 + n + 1 = 211 values) large enough for two
+    workgroups per CU each (>= 32 x CUs elements): 8 x CUs rows of 211 doubles do not fit the last cost's
+    partial-row buffer (16 x CUs rows of 96), so their rows must NOT be merged behind one another into
+    it — the gate of round 3 counted rows only and would have sent the later costs' rows past its end
+    (ADVICE r3).  The device-resident loop over all four must reach the host loop's minimum."""
+    mo = hip_lib
+    n, per_cost = 14, 8448          # 33 x 256 elements: a 256-CU part gets its 512 workgroups per cost
+    rng = np.random.default_rng(17)
+    x_true = rng.uniform(-1, 1, n)
+    residual = """
+  S v = 0;
+  for (int k = 0; k < %d; ++k) v += cos(S(k + 1) * d[0]) * x[k];
+  r[0] = v - d[1];""" % n
+    jacobian = "for (int k = 0; k < %d; ++k) J[k] = cos(S(k + 1) * d[0]);" % n
+    costs = []
+    for _ in range(4):
+        t = rng.uniform(0.0, 3.0, per_cost)
+        basis = np.cos(np.arange(1, n + 1)[None, :] * t[:, None])
+        y = basis @ x_true + 0.01 * rng.standard_normal(per_cost)
+        costs.append(mo.JitModelCost(n, 1, residual, jacobian_body=jacobian, planes=np.stack([t, y])))
+    x0 = x_true + 0.2 * rng.standard_normal(n)
+    for jac in (mo.JAC_ANALYTIC, mo.JAC_NUMERIC):
+        xd, rep = mo.capi.lm_minimize(costs, [jac] * 4, x0, max_iterations=30)
+        xh, sh, ih = host_lm_sum(costs, [jac] * 4, x0, max_iter=30)
+        assert np.isfinite(xd).all() and rep["status"] == sh, (jac, rep, sh, ih)
+        assert np.abs(xd - xh).max() < 1e-6 and np.abs(xd - x_true).max() < 5e-3, (jac, xd, xh)
+    # and every cost still answers on its own afterwards (nobody's rows or constants were overwritten)
+    for c in costs:
+        Hc, bc, sc = c.linearize(xd, mo.JAC_ANALYTIC)
+        assert np.isfinite(Hc).all() and sc > 0
+        c.close()
+
