@@ -415,32 +415,40 @@ __device__ void projectionFor(const LmCostDesc &d, const double (&T)[12], double
 // transform at x (j = 0) or at x + h_j e_j.
 template <typename S>
 __device__ __forceinline__ void writeSweepConstants(const LmProblem &P, const S *x) {
-  __shared__ S Tj[1 + kNumParams][12];
-  __shared__ S inv_h[kNumParams];
+  // The transforms at x and at x + h_j e_j are the same for every SE(3) cost of the problem: formed
+  // once (seven lanes, one sincos each), before the loop over the costs — a cost that does not
+  // differentiate numerically takes the transform at x in all seven places and steps of zero, as when
+  // each cost formed its own.
+  __shared__ S Tstep[1 + kNumParams][12];
+  __shared__ S inv_step[kNumParams];
   const int tid = threadIdx.x;
+  bool any_pose = false;
+  for (int ci = 0; ci < P.num_costs; ++ci)
+    any_pose = any_pose || P.cost[ci].model == kLmPoint2Point || P.cost[ci].model == kLmReprojection;
+  if (any_pose) {
+    if (tid <= kNumParams) {
+      S xp[kNumParams];
+      for (int k = 0; k < kNumParams; ++k) xp[k] = x[k];
+      if (tid > 0) {
+        const S h = forwardStep<S>(x[tid - 1]);
+        xp[tid - 1] = x[tid - 1] + h;
+        inv_step[tid - 1] = S(1) / h;
+      }
+      rigidFrom6DOF<S>(xp, Tstep[tid]);
+    }
+    __syncthreads();
+  }
   for (int ci = 0; ci < P.num_costs; ++ci) {
     const LmCostDesc &d = P.cost[ci];
     const bool numeric = d.jac_mode == kJacNumeric;
     if (d.model == kLmPoint2Point || d.model == kLmReprojection) {
-      if (tid <= kNumParams) {
-        S xp[kNumParams];
-        for (int k = 0; k < kNumParams; ++k) xp[k] = x[k];
-        if (tid > 0) {
-          if (numeric) {
-            const S h = forwardStep<S>(x[tid - 1]);
-            xp[tid - 1] = x[tid - 1] + h;
-            inv_h[tid - 1] = S(1) / h;
-          } else {
-            inv_h[tid - 1] = S(0);
-          }
-        }
-        rigidFrom6DOF<S>(xp, Tj[tid]);
-      }
-      __syncthreads();
+      // this cost's view: Tj[j] = the transform at x + h_j e_j (numeric) or at x; inv_h likewise
+      auto Tj = [&](int j) -> const S(&)[12] { return Tstep[numeric ? j : 0]; };
+      auto inv_h_of = [&](int j) { return numeric ? inv_step[j] : S(0); };
       if (d.model == kLmPoint2Point) {
         P2PSweepArgs<S> *a = static_cast<P2PSweepArgs<S> *>(d.args);
-        if (tid < (1 + kNumParams) * 12) a->T[tid / 12][tid % 12] = Tj[tid / 12][tid % 12];
-        if (tid < kNumParams) a->inv_h[tid] = inv_h[tid];
+        if (tid < (1 + kNumParams) * 12) a->T[tid / 12][tid % 12] = Tj(tid / 12)[tid % 12];
+        if (tid < kNumParams) a->inv_h[tid] = inv_h_of(tid);
         if (d.moments && d.jac_mode == kJacAnalyticLeft && tid < 18) {
           // J(p) = [I | -skew(R p + t)] = J0 + sum_k p_k J_k (c_abi.cpp fillBasis)
           const int r = tid / 6, j = tid % 6;
@@ -453,12 +461,12 @@ __device__ __forceinline__ void writeSweepConstants(const LmProblem &P, const S 
             const bool positive = (r == 0 && c == 1) || (r == 1 && c == 2) || (r == 2 && c == 0);
             return positive ? w[other] : -w[other];
           };
-          const S w0[3] = {Tj[0][3], Tj[0][7], Tj[0][11]};
+          const S w0[3] = {Tj(0)[3], Tj(0)[7], Tj(0)[11]};
           const S base = pattern(w0);
           d.basis->J[0][r * 6 + j] = double(base);
           for (int k = 0; k < 3; ++k) {
-            const S wk[3] = {w0[0] + Tj[0][0 * 4 + k], w0[1] + Tj[0][1 * 4 + k],
-                             w0[2] + Tj[0][2 * 4 + k]};
+            const S wk[3] = {w0[0] + Tj(0)[0 * 4 + k], w0[1] + Tj(0)[1 * 4 + k],
+                             w0[2] + Tj(0)[2 * 4 + k]};
             d.basis->J[1 + k][r * 6 + j] = double(pattern(wk)) - double(base);
           }
         }
@@ -476,7 +484,7 @@ __device__ __forceinline__ void writeSweepConstants(const LmProblem &P, const S 
                 const bool even = (m == 0 && c == 1 && k == 2) || (m == 1 && c == 2 && k == 0) ||
                                   (m == 2 && c == 0 && k == 1);
                 const double skew_mc = even ? -1.0 : 1.0;
-                v = -double(Tj[0][r * 4 + m]) * skew_mc;
+                v = -double(Tj(0)[r * 4 + m]) * skew_mc;
               }
             }
             d.basis->J[1 + k][r * 6 + j] = v;
@@ -485,19 +493,19 @@ __device__ __forceinline__ void writeSweepConstants(const LmProblem &P, const S 
         if (d.moments && numeric && tid < 18) {
           // column j of J is ((R_j - R) p + (t_j - t)) / h_j  (c_abi.cpp fillBasis)
           const int r = tid / 6, j = tid % 6;
-          d.basis->J[0][r * 6 + j] = double((Tj[1 + j][r * 4 + 3] - Tj[0][r * 4 + 3]) * inv_h[j]);
+          d.basis->J[0][r * 6 + j] = double((Tj(1 + j)[r * 4 + 3] - Tj(0)[r * 4 + 3]) * inv_h_of(j));
           for (int k = 0; k < 3; ++k)
             d.basis->J[1 + k][r * 6 + j] =
-                double((Tj[1 + j][r * 4 + k] - Tj[0][r * 4 + k]) * inv_h[j]);
+                double((Tj(1 + j)[r * 4 + k] - Tj(0)[r * 4 + k]) * inv_h_of(j));
         }
       } else {
         if constexpr (sizeof(S) == 8) {
           ReprojSweepArgs *a = static_cast<ReprojSweepArgs *>(d.args);
           if (tid <= kNumParams) {
             double M[12];
-            projectionFor(d, Tj[tid], M);
+            projectionFor(d, Tj(tid), M);
             for (int k = 0; k < 12; ++k) a->M[tid][k] = M[k];
-            if (tid > 0) a->inv_h[tid - 1] = inv_h[tid - 1];
+            if (tid > 0) a->inv_h[tid - 1] = inv_h_of(tid - 1);
           }
         }
       }
