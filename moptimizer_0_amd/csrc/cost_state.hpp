@@ -58,7 +58,8 @@ inline int envInt(const char *name, int fallback) {
 struct IcpMatcher {
   void *d_sorted = nullptr;      // [num_targets][4] scalars grouped by cell
   int *d_cell_start = nullptr;   // [cells + 1]
-  unsigned int *d_matched = nullptr;
+  unsigned int *d_matched = nullptr;  // matched sources per wave of the last counting search
+  long long num_waves = 0;
   double origin[3] = {0, 0, 0};
   double cell = 1.0;
   int dims[3] = {1, 1, 1};

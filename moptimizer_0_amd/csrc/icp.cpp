@@ -51,8 +51,11 @@ int buildIcpGrid(const S *src, long long n, const S *tgt, long long m, double ma
   out_matcher = std::move(mt);  // from here on the caller frees the matcher's device arrays
   IcpMatcher &g = *out_matcher;
   MOPT_HIP_TRY(deviceAlloc(reinterpret_cast<void **>(&g.d_cell_start), size_t(ncells + 1) * sizeof(int)));
-  MOPT_HIP_TRY(deviceAlloc(reinterpret_cast<void **>(&g.d_matched), 64));
-  MOPT_HIP_TRY(hipMemsetAsync(g.d_matched, 0, 64, s));  // every search leaves it at zero again
+  // one matched count per wave of the search (whole tiles of sources, 64 to a wave)
+  constexpr long long kTile = mopt::TileShape<S>::kPoints;
+  g.num_waves = (n + kTile - 1) / kTile * kTile / 64;
+  MOPT_HIP_TRY(deviceAlloc(reinterpret_cast<void **>(&g.d_matched),
+                           size_t(g.num_waves > 0 ? g.num_waves : 1) * sizeof(unsigned int)));
   MOPT_HIP_TRY(d_perm_t.alloc(size_t(m) * sizeof(int)));
   MOPT_HIP_TRY(mopt::icpSortByCell<S>(d_tgt.as<S>(), m, g.origin, g.cell, g.dims, d_perm_t.as<int>(),
                                       g.d_cell_start, s));
@@ -111,7 +114,7 @@ int icpUpdate(mopt_cost *c, const S *x, int64_t *num_matched) {
   fillIcpArgs<S>(c, a);
   const auto T = moptimizer::so3::rigidFrom6DOF<S>(x);
   std::memcpy(a.T, T.m, sizeof T.m);
-  a.matched = num_matched ? mt.d_matched : nullptr;  // zero between searches (publishCounterKernel)
+  a.matched = num_matched ? mt.d_matched : nullptr;
   MOPT_HIP_TRY(mopt::launchIcpMatch<S>(a, c->stream));
   c->cache.valid = false;
   c->state_version += 1;
@@ -120,7 +123,7 @@ int icpUpdate(mopt_cost *c, const S *x, int64_t *num_matched) {
     // memory and releases a sequence word — no memset, no copy, no stream synchronisation
     const int slot = mopt_detail::kResultSlots - 1;  // beyond any n*n + n + 1 <= 73
     const mopt::HostPublish pub = nextHostPublish(c, slot);
-    MOPT_HIP_TRY(mopt::launchPublishCounter(mt.d_matched, pub, c->stream));
+    MOPT_HIP_TRY(mopt::launchPublishCounter(mt.d_matched, mt.num_waves, pub, c->stream));
     const int rc = waitHostPublished(c, pub.sequence);
     if (rc != MOPT_OK) return rc;
     *num_matched = int64_t(c->h_result[slot]);

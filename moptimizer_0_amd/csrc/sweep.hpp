@@ -118,7 +118,7 @@ struct IcpMatchArgs {
   int dims[3];
   S max_dist2;
   S T[12];                // row-major [R | t] applied to the source before the search
-  unsigned int *matched;  // optional counter of matched sources
+  unsigned int *matched;  // optional: matched sources per wave, [workgroups x waves per workgroup]
 };
 
 // Where a sweep kernel is launched.
@@ -371,8 +371,9 @@ template <typename S>
 hipError_t icpGatherPoints(const S *d_xyz, const int *d_perm, long long m, S *d_out, bool padded,
                            hipStream_t stream);
 
-// *d_counter -> mapped host memory (as one double) + flag; the counter is left at zero
-hipError_t launchPublishCounter(unsigned int *d_counter, const HostPublish &pub, hipStream_t stream);
+// sum of the search's per-wave matched counts -> mapped host memory (as one double) + flag
+hipError_t launchPublishCounter(const unsigned int *d_wave_counts, long long num_waves,
+                                const HostPublish &pub, hipStream_t stream);
 // device result (count doubles) -> mapped host memory + flag (after a collective)
 hipError_t launchPublish(const double *d_values, int count, const HostPublish &pub,
                          hipStream_t stream);

@@ -743,129 +743,207 @@ __global__ __launch_bounds__(kBlockThreads) void scalarModelResidentSetKernel(
 // model's update(x) (model.h:24-26; "setup can be i.e nearest neighboor search", docs/Cost.puml:14-17)
 // and ships no implementation, so semantics are defined here: exact nearest neighbour in the
 // Euclidean metric, ties resolved to the first candidate in (cell z, y, x; original index) order.
-template <typename S>
+// candidates per lane and trip of the first round (4, 6 and 8 measure the same; 2 is slower)
+constexpr int kIcpTrip = 4;
+
+template <typename S, int TRIP>
 __device__ __forceinline__ void icpMatchBody(const IcpMatchArgs<S> &A, const S (&T)[12]) {
   constexpr int TP = TileShape<S>::kPoints;
   const long long i = (long long)blockIdx.x * kBlockThreads + threadIdx.x;
-  if (i >= (long long)A.num_tiles * TP) return;
+  if (i >= (long long)A.num_tiles * TP) return;  // (whole workgroups: TP is a multiple of their size)
   S *slot = A.tiles + (i / TP) * TileShape<S>::kP2PScalars + (i % TP);
+  // No lane leaves before the end: the first round below runs in lock step over the wave, every
+  // load from an address that exists whatever the lane holds (slots past the count are padding).
+  const S p[3] = {slot[0 * TP], slot[1 * TP], slot[2 * TP]};
+  S w[3], g[3];
+  bool inside = i < A.count;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    w[a] = ((T[a * 4 + 0] * p[0] + T[a * 4 + 1] * p[1]) + T[a * 4 + 2] * p[2]) + T[a * 4 + 3];
+    g[a] = floor((w[a] - A.origin[a]) * A.inv_cell);
+    inside = inside && g[a] >= S(-1) && g[a] <= S(A.dims[a]);
+  }
+  const int c[3] = {inside ? int(g[0]) : 0, inside ? int(g[1]) : 0, inside ? int(g[2]) : 0};
   bool found = false;
+  S best_d = A.max_dist2;
+  // Ties go to the candidate stored first — (cell z, y, x; original index) order — whatever order
+  // the cells are visited in, and however often: the position k is part of the comparison.
+  int best_k = 0x7fffffff;
+  // In the first round the winner's coordinates travel with it (reading them at the end would be
+  // one more dependent round trip for every wave); the second round tracks distance and position
+  // only and reads the coordinates of a winner it found once, at its end: six conditional moves
+  // less per candidate where candidates are many.
   S best[3] = {S(0), S(0), S(0)};
-  if (i < A.count) {
-    const S p[3] = {slot[0 * TP], slot[1 * TP], slot[2 * TP]};
-    S w[3], g[3];
-    bool inside = true;
+  auto consider = [&](const S (&q)[3], int k, bool present, auto keep_coordinates) {
+    const S d0 = w[0] - q[0], d1 = w[1] - q[1], d2 = w[2] - q[2];
+    const S dist = d0 * d0 + d1 * d1 + d2 * d2;
+    const bool better = present && dist <= A.max_dist2 &&
+                        (!found || dist < best_d || (dist == best_d && k < best_k));
+    found = found || better;
+    best_d = better ? dist : best_d;
+    best_k = better ? k : best_k;
+    if constexpr (decltype(keep_coordinates)::value) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      w[a] = ((T[a * 4 + 0] * p[0] + T[a * 4 + 1] * p[1]) + T[a * 4 + 2] * p[2]) + T[a * 4 + 3];
-      g[a] = floor((w[a] - A.origin[a]) * A.inv_cell);
-      inside = inside && g[a] >= S(-1) && g[a] <= S(A.dims[a]);
+      for (int a = 0; a < 3; ++a) best[a] = better ? q[a] : best[a];
     }
-    if (inside) {
-      const int c[3] = {int(g[0]), int(g[1]), int(g[2])};
-      S best_d = A.max_dist2;
-      // Ties go to the candidate stored first — (cell z, y, x; original index) order — whatever
-      // order the rows are visited in: the position k is part of the comparison.
-      int best_k = 0x7fffffff;
-      // (only the distance and the position are tracked; the winner's coordinates are read once,
-      // at the end: six conditional moves less per candidate)
-      auto consider = [&](const S (&q)[3], int k) {
-        const S d0 = w[0] - q[0], d1 = w[1] - q[1], d2 = w[2] - q[2];
-        const S dist = d0 * d0 + d1 * d1 + d2 * d2;
-        if (dist <= A.max_dist2 && (!found || dist < best_d || (dist == best_d && k < best_k))) {
-          found = true;
-          best_d = dist;
-          best_k = k;
-        }
-      };
-      auto fetch = [&](int k, S (&q)[3]) {
-        const Pack<S> *cand = reinterpret_cast<const Pack<S> *>(A.sorted + size_t(k) * 4);
-        if (sizeof(S) == 8) {
-          const Pack<S> lo = cand[0], hi = cand[1];
-          q[0] = lo.v[0]; q[1] = lo.v[1]; q[2] = hi.v[0];
-        } else {
-          const Pack<S> all = cand[0];
-          q[0] = all.v[0]; q[1] = all.v[1]; q[2] = all.v[2];
-        }
-      };
-      // cells [xa, xb] of row (y, z) are consecutive in storage: one candidate range, two bounds
-      auto visit = [&](int y, int z, int xa, int xb) {
-        xa = xa < 0 ? 0 : xa;
-        xb = xb >= A.dims[0] ? A.dims[0] - 1 : xb;
-        if (z < 0 || z >= A.dims[2] || y < 0 || y >= A.dims[1] || xa > xb) return;
-        const int row = (z * A.dims[1] + y) * A.dims[0];  // the grid has at most 2^22 cells (icp.cpp)
-        const int lo = A.cell_start[row + xa], hi = A.cell_start[row + xb + 1];
-        // two candidates per step, both loads issued before either is used
-        for (int k = lo; k < hi; k += 2) {
-          S qa[3], qb[3];
-          const bool pair = k + 1 < hi;
-          fetch(k, qa);
-          fetch(pair ? k + 1 : k, qb);
-          consider(qa, k);
-          if (pair) consider(qb, k + 1);
-        }
-      };
-      // The source's own cell first; every other cell of the 3 x 3 x 3 block is visited only if
-      // its box can hold something at least as close as what has been found (or within the
-      // maximum distance while nothing has) — the bound is the distance to the own cell's faces,
-      // relaxed by a few ulps of the coordinates (targets were binned with floor()).  Range bounds are
-      // fetched only for what is visited.  At about one target per cell and a source close to its
-      // target this leaves 1-3 cells of 27 and takes most of the divergent tail off the wave.
-      // The offsets f are recomputed from the cell index and can disagree with the binning's
-      // floor((w - origin) / cell) by a few ulps OF THE COORDINATE (not of the offset): every gap to
-      // a face is shortened by that much before it is squared, in the scalar type's own epsilon.
-      constexpr S kUlps = S(16) * std::numeric_limits<S>::epsilon();
-      const S fx = w[0] - (A.origin[0] + S(c[0]) * A.cell);  // offsets inside the own cell, [0, cell)
-      const S fy = w[1] - (A.origin[1] + S(c[1]) * A.cell);
-      const S fz = w[2] - (A.origin[2] + S(c[2]) * A.cell);
-      const S ex = kUlps * (fabs(w[0]) + fabs(A.origin[0]) + A.cell);
-      const S ey = kUlps * (fabs(w[1]) + fabs(A.origin[1]) + A.cell);
-      const S ez = kUlps * (fabs(w[2]) + fabs(A.origin[2]) + A.cell);
-      const S gx[2] = {fx - ex, (A.cell - fx) - ex};
-      const S gap_y[3] = {fy - ey, S(0), (A.cell - fy) - ey};
-      const S gap_z[3] = {fz - ez, S(0), (A.cell - fz) - ez};
-      auto within = [&](S bound) {
-        return bound * (S(1) - kUlps) <= (found ? best_d : A.max_dist2);
-      };
-      auto sq = [](S v) { return v > S(0) ? v * v : S(0); };
-      visit(c[1], c[2], c[0], c[0]);
+  };
+  auto fetch = [&](int k, S (&q)[3]) {
+    const Pack<S> *cand = reinterpret_cast<const Pack<S> *>(A.sorted + size_t(k) * 4);
+    if (sizeof(S) == 8) {
+      const Pack<S> lo = cand[0], hi = cand[1];
+      q[0] = lo.v[0]; q[1] = lo.v[1]; q[2] = hi.v[0];
+    } else {
+      const Pack<S> all = cand[0];
+      q[0] = all.v[0]; q[1] = all.v[1]; q[2] = all.v[2];
+    }
+  };
+  // Offsets inside the own cell, [0, cell).  They are recomputed from the cell index and can
+  // disagree with the binning's floor((w - origin) / cell) by a few ulps OF THE COORDINATE (not of
+  // the offset): every gap to a face is shortened by that much before it is squared, in the scalar
+  // type's own epsilon (targets were binned with floor()).
+  constexpr S kUlps = S(16) * std::numeric_limits<S>::epsilon();
+  const S fx = w[0] - (A.origin[0] + S(c[0]) * A.cell);
+  const S fy = w[1] - (A.origin[1] + S(c[1]) * A.cell);
+  const S fz = w[2] - (A.origin[2] + S(c[2]) * A.cell);
+  const S ex = kUlps * (fabs(w[0]) + fabs(A.origin[0]) + A.cell);
+  const S ey = kUlps * (fabs(w[1]) + fabs(A.origin[1]) + A.cell);
+  const S ez = kUlps * (fabs(w[2]) + fabs(A.origin[2]) + A.cell);
+  auto within = [&](S bound) {
+    return bound * (S(1) - kUlps) <= (found ? best_d : A.max_dist2);
+  };
+  auto sq = [](S v) { return v > S(0) ? v * v : S(0); };
+
+  // First round, the wave in lock step: the 2 x 2 x 2 cells nearest to the point (per axis the own
+  // cell and the neighbour across the nearer face) hold every target closer than half a cell.
+  // They are four runs of two consecutive cells: eight range bounds fetched together, then the
+  // lane's candidates out of the four runs as ONE list, four per trip — every trip is eight (fp32:
+  // four) loads in flight and one wait, and the wave makes as many trips as its longest list
+  // needs.  Walking the rows one after the other instead, each lane under its own pruning, the
+  // wave executed the union of its lanes' visits: ~116 vector loads per wave with an eighth of the
+  // lanes active in each, ~20 dependent waits.
+  const S half = S(0.5) * A.cell;
+  const int sx = fx < half ? -1 : 0, sy = fy < half ? -1 : 0, sz = fz < half ? -1 : 0;
+  int first[4], ends[4];
+  {
+    int xa = c[0] + sx, xb = xa + 1;
+    xa = xa < 0 ? 0 : xa;
+    xb = xb >= A.dims[0] ? A.dims[0] - 1 : xb;
+    int at_a[4], at_b[4];
 #pragma unroll
-      for (int r = 0; r < 9; ++r) {
-        const int y = c[1] + r % 3 - 1, z = c[2] + r / 3 - 1;
-        const S yz = sq(gap_y[r % 3]) + sq(gap_z[r / 3]);
-        if (!within(yz)) continue;
-        const bool left = within(yz + sq(gx[0])), right = within(yz + sq(gx[1]));
-        if (r == 4) {  // the own row: its centre cell is done
-          if (left) visit(y, z, c[0] - 1, c[0] - 1);
-          if (right) visit(y, z, c[0] + 1, c[0] + 1);
-        } else {
-          visit(y, z, left ? c[0] - 1 : c[0], right ? c[0] + 1 : c[0]);
-        }
+    for (int r = 0; r < 4; ++r) {
+      const int y = c[1] + sy + (r & 1), z = c[2] + sz + (r >> 1);
+      const bool ok = inside && xa <= xb && y >= 0 && y < A.dims[1] && z >= 0 && z < A.dims[2];
+      const int row = (z * A.dims[1] + y) * A.dims[0];  // the grid has at most 2^22 cells (icp.cpp)
+      at_a[r] = ok ? row + xa : 0;  // (entry 0 twice: an empty run)
+      at_b[r] = ok ? row + xb + 1 : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      first[r] = A.cell_start[at_a[r]];
+      ends[r] = A.cell_start[at_b[r]];
+    }
+  }
+  const int n0 = ends[0] - first[0];
+  const int n1 = n0 + (ends[1] - first[1]);
+  const int n2 = n1 + (ends[2] - first[2]);
+  const bool first_round = TRIP > 0;
+  const int total = first_round ? n2 + (ends[3] - first[3]) : 0;
+  constexpr int kSlots = TRIP > 0 ? TRIP : 1;
+  for (int j = 0; __any(j < total); j += kSlots) {
+    int k[kSlots];
+    bool present[kSlots];
+    S q[kSlots][3];
+#pragma unroll
+    for (int u = 0; u < kSlots; ++u) {
+      const int jj = j + u;
+      present[u] = jj < total;
+      // position jj of the four runs laid end to end (selects, no branches)
+      int at = first[3] + (jj - n2);
+      at = jj < n2 ? first[2] + (jj - n1) : at;
+      at = jj < n1 ? first[1] + (jj - n0) : at;
+      at = jj < n0 ? first[0] + jj : at;
+      k[u] = present[u] ? at : 0;  // (a trip is only made when some lane has a candidate)
+    }
+#pragma unroll
+    for (int u = 0; u < kSlots; ++u) fetch(k[u], q[u]);
+#pragma unroll
+    for (int u = 0; u < kSlots; ++u) consider(q[u], k[u], present[u], std::true_type());
+  }
+
+  // Everything else lies across a far face of that block: only a lane whose best so far (or the
+  // maximum distance, while it has none) reaches the nearest of the three goes on — at about one
+  // target per cell and a source within half a cell of its target, none.  Those that do walk the
+  // 3 x 3 x 3 block row by row under the running bound, the own cell first; cells seen above are
+  // seen again, which changes nothing (same distances, same positions).
+  const S far_x = (sx < 0 ? A.cell - fx : fx) - ex;
+  const S far_y = (sy < 0 ? A.cell - fy : fy) - ey;
+  const S far_z = (sz < 0 ? A.cell - fz : fz) - ez;
+  if (inside && (!first_round || within(sq(fmin(far_x, fmin(far_y, far_z)))))) {
+    const int first_round_k = best_k;
+    // cells [xa, xb] of row (y, z) are consecutive in storage: one candidate range, two bounds
+    auto visit = [&](int y, int z, int xa, int xb) {
+      xa = xa < 0 ? 0 : xa;
+      xb = xb >= A.dims[0] ? A.dims[0] - 1 : xb;
+      if (z < 0 || z >= A.dims[2] || y < 0 || y >= A.dims[1] || xa > xb) return;
+      const int row = (z * A.dims[1] + y) * A.dims[0];
+      const int lo = A.cell_start[row + xa], hi = A.cell_start[row + xb + 1];
+      // two candidates per step, both loads issued before either is used
+      for (int k = lo; k < hi; k += 2) {
+        S qa[3], qb[3];
+        const bool pair = k + 1 < hi;
+        fetch(k, qa);
+        fetch(pair ? k + 1 : k, qb);
+        consider(qa, k, true, std::false_type());
+        consider(qb, k + 1, pair, std::false_type());
       }
-      if (found) fetch(best_k, best);
+    };
+    // Every cell is visited only if its box can hold something at least as close as what has been
+    // found (or within the maximum distance while nothing has) — the bound is the distance to the
+    // own cell's faces.  Range bounds are fetched only for what is visited.
+    const S gx[2] = {fx - ex, (A.cell - fx) - ex};
+    const S gap_y[3] = {fy - ey, S(0), (A.cell - fy) - ey};
+    const S gap_z[3] = {fz - ez, S(0), (A.cell - fz) - ez};
+    visit(c[1], c[2], c[0], c[0]);
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      const int y = c[1] + r % 3 - 1, z = c[2] + r / 3 - 1;
+      const S yz = sq(gap_y[r % 3]) + sq(gap_z[r / 3]);
+      if (!within(yz)) continue;
+      const bool left = within(yz + sq(gx[0])), right = within(yz + sq(gx[1]));
+      if (r == 4) {  // the own row: its centre cell is done
+        if (left) visit(y, z, c[0] - 1, c[0] - 1);
+        if (right) visit(y, z, c[0] + 1, c[0] + 1);
+      } else {
+        visit(y, z, left ? c[0] - 1 : c[0], right ? c[0] + 1 : c[0]);
+      }
     }
+    if (best_k != first_round_k) fetch(best_k, best);
   }
   const S nan = S(__builtin_nan(""));
   slot[3 * TP] = found ? best[0] : nan;
   slot[4 * TP] = found ? best[1] : nan;
   slot[5 * TP] = found ? best[2] : nan;
-  // one counter update per workgroup (the grid covers whole tiles, so no thread has left early)
+  // How many sources found a target: every wave leaves its count in a slot of its own and the
+  // publishing kernel adds the slots — no atomics (15.6 k of them on one address, one per wave,
+  // take 178 us at 1 M; one per workgroup behind a barrier made the search 57.6 us instead of 44.4).
   if (A.matched) {
-    const int in_block = __syncthreads_count(found ? 1 : 0);
-    if (threadIdx.x == 0 && in_block > 0) atomicAdd(A.matched, (unsigned int)in_block);
+    const unsigned long long in_wave = __ballot(found);
+    if ((threadIdx.x & 63) == 0)
+      A.matched[(size_t)blockIdx.x * (kBlockThreads / 64) + threadIdx.x / 64] =
+          (unsigned int)__popcll(in_wave);
   }
 }
 
-template <typename S>
+template <typename S, int TRIP>
 __global__ __launch_bounds__(kBlockThreads) void icpMatchKernel(const IcpMatchArgs<S> A) {
-  icpMatchBody<S>(A, A.T);
+  icpMatchBody<S, TRIP>(A, A.T);
 }
 
 // Resident form for the device-resident LM: the pose comes from the cost's sweep constants in HBM
 // (T at the point the step kernel has just proposed), and the search only runs when the step
 // kernel asked for it — the model's update(x) at the top of an outer iteration
 // (levenberg_marquadt_dyn.cpp:54) — or not at all once the loop has stopped.
-template <typename S>
+template <typename S, int TRIP>
 __global__ __launch_bounds__(kBlockThreads) void icpMatchResidentKernel(
     const IcpMatchArgs<S> A, const P2PSweepArgs<S> *__restrict__ d_args,
     const LmControl *__restrict__ control) {
@@ -873,7 +951,7 @@ __global__ __launch_bounds__(kBlockThreads) void icpMatchResidentKernel(
   S T[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) T[k] = d_args->T[0][k];
-  icpMatchBody<S>(A, T);
+  icpMatchBody<S, TRIP>(A, T);
 }
 
 template <typename S>
@@ -1554,12 +1632,24 @@ template hipError_t launchScalarModel<float>(const ScalarSweepArgs<float> &, int
 template hipError_t launchScalarModel<double>(const ScalarSweepArgs<double> &, int, bool, int, int,
                                               int, hipStream_t);
 
+// MOPT_ICP_FIRST_ROUND=0: the row-by-row search alone (measurements: scripts/icp_offsets_timing.py)
+static bool icpFirstRound() {
+  static const bool on = [] {
+    const char *v = getenv("MOPT_ICP_FIRST_ROUND");
+    return !(v && v[0] == '0');
+  }();
+  return on;
+}
+
 template <typename S>
 hipError_t launchIcpMatch(const IcpMatchArgs<S> &args, hipStream_t stream) {
   const long long padded = (long long)args.num_tiles * TileShape<S>::kPoints;
   if (padded == 0) return hipSuccess;
   const unsigned blocks = unsigned((padded + kBlockThreads - 1) / kBlockThreads);
-  hipLaunchKernelGGL((icpMatchKernel<S>), dim3(blocks), dim3(kBlockThreads), 0, stream, args);
+  if (icpFirstRound())
+    hipLaunchKernelGGL((icpMatchKernel<S, kIcpTrip>), dim3(blocks), dim3(kBlockThreads), 0, stream, args);
+  else
+    hipLaunchKernelGGL((icpMatchKernel<S, 0>), dim3(blocks), dim3(kBlockThreads), 0, stream, args);
   return hipGetLastError();
 }
 template hipError_t launchIcpMatch<float>(const IcpMatchArgs<float> &, hipStream_t);
@@ -1571,7 +1661,7 @@ hipError_t launchIcpMatchResident(const IcpMatchArgs<S> &args, const P2PSweepArg
   const long long padded = (long long)args.num_tiles * TileShape<S>::kPoints;
   if (padded == 0) return hipSuccess;
   const unsigned blocks = unsigned((padded + kBlockThreads - 1) / kBlockThreads);
-  hipLaunchKernelGGL((icpMatchResidentKernel<S>), dim3(blocks), dim3(kBlockThreads), 0, stream, args,
+  hipLaunchKernelGGL((icpMatchResidentKernel<S, kIcpTrip>), dim3(blocks), dim3(kBlockThreads), 0, stream, args,
                      d_args, control);
   return hipGetLastError();
 }
@@ -1593,19 +1683,31 @@ hipError_t launchGatherTargets(const S *tiles, long long count, S *out_xyz, hipS
 template hipError_t launchGatherTargets<float>(const float *, long long, float *, hipStream_t);
 template hipError_t launchGatherTargets<double>(const double *, long long, double *, hipStream_t);
 
-// matched-source counter of the correspondence search -> mapped host memory (as a double), and
-// back to zero for the next search: no memset launch, no copy, no stream synchronisation
-__global__ void publishCounterKernel(unsigned int *counter, const HostPublish pub) {
+// matched sources of the correspondence search: the per-wave counts (icpMatchBody) added up and
+// handed to mapped host memory as one double — no memset launch, no copy, no stream synchronisation
+__global__ __launch_bounds__(1024) void publishCounterKernel(const unsigned int *wave_counts,
+                                                             long long num_waves,
+                                                             const HostPublish pub) {
+  __shared__ unsigned long long per_wave[16];
+  unsigned long long sum = 0;
+  for (long long k = threadIdx.x; k < num_waves; k += blockDim.x) sum += wave_counts[k];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+  if ((threadIdx.x & 63) == 0) per_wave[threadIdx.x / 64] = sum;
+  __syncthreads();
   double v = 0.0;
   if (threadIdx.x == 0) {
-    v = double(*counter);
-    *counter = 0u;
+    unsigned long long total = 0;
+    for (int k = 0; k < int(blockDim.x) / 64; ++k) total += per_wave[k];
+    v = double(total);
   }
   publishToHost(pub, 1, v);
 }
 
-hipError_t launchPublishCounter(unsigned int *d_counter, const HostPublish &pub, hipStream_t stream) {
-  hipLaunchKernelGGL(publishCounterKernel, dim3(1), dim3(64), 0, stream, d_counter, pub);
+hipError_t launchPublishCounter(const unsigned int *d_wave_counts, long long num_waves,
+                                const HostPublish &pub, hipStream_t stream) {
+  hipLaunchKernelGGL(publishCounterKernel, dim3(1), dim3(1024), 0, stream, d_wave_counts, num_waves,
+                     pub);
   return hipGetLastError();
 }
 

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Correspondence search against the distance between the clouds: 1 M sources whose targets lie
+`offset` cells away (0 = aligned, 0.2 = the benchmark of icp_timing.py, 0.7 and 1.5 = most lanes
+have to look beyond the 2 x 2 x 2 cells of the first round).  MOPT_ICP_FIRST_ROUND=0 runs the
+row-by-row search alone.
+Usage: python scripts/icp_offsets_timing.py [--dtype f32] [--per-cell 1]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import moptimizer_0_amd as mo
+
+def arg(name, default):
+    return sys.argv[sys.argv.index(name) + 1] if name in sys.argv else default
+
+dtype = {"f64": np.float64, "f32": np.float32}[arg("--dtype", "f64")]
+per_cell = float(arg("--per-cell", "1"))
+n = int(arg("--n", "1000000"))
+mo.capi.device_count()
+rng = np.random.default_rng(1)
+side = 100.0
+tgt = rng.random((n, 3)) * side
+max_dist = side * (per_cell / n) ** (1.0 / 3.0)
+for offset in (0.0, 0.2, 0.7, 1.5):
+    shift = np.array([1.0, -1.0, 1.0]) / np.sqrt(3.0) * offset * max_dist
+    src = tgt[rng.permutation(n)] + rng.normal(0, 0.01 * max_dist, (n, 3)) + shift
+    cost = mo.IcpCost(src, tgt, max_dist, dtype=dtype)
+    x = np.zeros(6)
+    cost.update(x)
+    ts = []
+    for _ in range(20):
+        t0 = time.perf_counter(); m = cost.update(x); ts.append(time.perf_counter() - t0)
+    dt = float(np.median(ts))
+    print("first_round=%s %s n=%d targets/cell~%.0f offset %.1f cells: update %.3f ms, %d matched"
+          % (os.environ.get("MOPT_ICP_FIRST_ROUND", "1"), arg("--dtype", "f64"), n, per_cell, offset, dt * 1e3, m), flush=True)
+    cost.close()

@@ -887,6 +887,43 @@ def test_icp_matcher_equals_brute_force(hip_lib, dtype):
     assert far.update(np.zeros(6, dtype=dtype)) == 0 and np.isnan(far.matches()).all()
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_icp_ties_go_to_the_target_stored_first(hip_lib, dtype):
+    """Exact ties: targets on a unit lattice, sources at the midpoints of its edges, faces and
+    cubes (2, 4 and 8 targets at exactly the same distance, spread over up to eight grid cells —
+    some in the 2 x 2 x 2 block of the search's first round, some only reached by its second).
+    The documented rule: the tied target stored first, i.e. smallest (cell z, cell y, cell x,
+    original index); and a target at exactly max_distance counts as within it."""
+    g = np.arange(6, dtype=np.float64)
+    tgt = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    rng = np.random.default_rng(3)
+    tgt = tgt[rng.permutation(len(tgt))]
+    base = tgt[(tgt < 5).all(1)]
+    src = np.concatenate([base + np.array(o) for o in
+                          ((0.5, 0, 0), (0, 0.5, 0), (0, 0, 0.5), (0.5, 0.5, 0), (0.5, 0, 0.5),
+                           (0, 0.5, 0.5), (0.5, 0.5, 0.5), (0.25, 0.5, 0.5))])
+    for max_dist in (0.9, 1.0, 0.5, np.sqrt(0.75)):
+        cell = max_dist * 1.001          # icp.cpp: the cell edge is a hair above the radius
+        d2 = ((src[:, None, :] - tgt[None, :, :]) ** 2).sum(-1)
+        cells = np.floor(tgt / cell).astype(np.int64)      # the box of the targets starts at 0
+        key = ((cells[:, 2] * 1000 + cells[:, 1]) * 1000 + cells[:, 0]) * 100000 + np.arange(len(tgt))
+        best = d2.min(1)
+        tied = d2 == best[:, None]
+        winner = np.where(tied, key[None, :], np.iinfo(np.int64).max).argmin(1)
+        want = tgt[winner].copy()
+        want[best > max_dist ** 2] = np.nan
+        cost = hip_lib.IcpCost(src.astype(dtype), tgt.astype(dtype), float(dtype(max_dist)), dtype=dtype)
+        n = cost.update(np.zeros(6, dtype=dtype))
+        got = cost.matches()
+        if dtype == np.float32 and max_dist == np.sqrt(0.75):
+            continue   # the radius itself is rounded: whether 0.75 is within its square is not defined
+        assert np.array_equal(np.isnan(got[:, 0]), np.isnan(want[:, 0])), max_dist
+        ok = ~np.isnan(want[:, 0])
+        assert np.array_equal(got[ok], want[ok].astype(dtype)), max_dist
+        assert n == int(ok.sum())
+        cost.close()
+
+
 def test_icp_solve_with_gpu_correspondence_search(hip_lib, oracle):
     """Real ICP: unknown correspondences, re-matched at the top of every outer LM iteration
     (cost->update(x), levenberg_marquadt_dyn.cpp:54).  Target = moved source + noise, shuffled,
