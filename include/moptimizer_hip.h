@@ -175,6 +175,13 @@ MOPT_API int mopt_icp_update(mopt_cost *cost, const void *x, int64_t *num_matche
 /* current target of every source as packed xyz (NaN triple where unmatched); host buffer of
  * num_src * 3 scalars.  Works for any point2point cost. */
 MOPT_API int mopt_icp_get_matches(mopt_cost *cost, void *tgt_out_xyz);
+/* The uniform grid an ICP cost searches: cell edge, cells to the search radius (`reach`: 1 where the
+ * radius holds about one target, up to 8 where it holds many — the cells are then finer than the
+ * radius and the search covers (2 reach + 1)^3 of them), cells per axis and the grid's origin.
+ * Ties in distance go to the target stored first: smallest (cell z, cell y, cell x, index in the
+ * caller's array) with cell = floor((q - origin) / cell_edge).  Any pointer may be NULL. */
+MOPT_API int mopt_icp_grid(const mopt_cost *cost, double *cell_edge, int *reach, int dims[3],
+                           double origin[3]);
 
 /* Reprojection (camera-calibration) cost, fp64, numeric Jacobian only.  points_xyzw: packed
  * 4-vectors (32 B); pixels_uv: packed int32 pairs (8 B).  camera_3x4 / frame_4x4: row-major

@@ -74,6 +74,9 @@ def load():
                             ctypes.c_void_p, ctypes.c_int64, ctypes.c_double],
         "mopt_icp_update": [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)],
         "mopt_icp_get_matches": [ctypes.c_void_p, ctypes.c_void_p],
+        "mopt_icp_grid": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
+                          ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                          ctypes.POINTER(ctypes.c_double)],
         "mopt_reprojection_create": [c_void_pp, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_uint],
@@ -459,6 +462,13 @@ class IcpCost(Point2PointCost):
         n = ctypes.c_int64(-1)
         check(load().mopt_icp_update(self._h, _ptr(x), ctypes.byref(n) if count_matches else None))
         return n.value
+
+    def grid(self):
+        """(cell edge, reach, dims[3], origin[3]) of the grid the search walks."""
+        edge, reach = ctypes.c_double(), ctypes.c_int()
+        dims, origin = (ctypes.c_int * 3)(), (ctypes.c_double * 3)()
+        check(load().mopt_icp_grid(self._h, ctypes.byref(edge), ctypes.byref(reach), dims, origin))
+        return edge.value, reach.value, np.array(dims[:]), np.array(origin[:])
 
     def matches(self):
         out = np.zeros((self.count, 3), dtype=_dtype_of(self.scalar_bytes))

@@ -62,6 +62,7 @@ struct IcpMatcher {
   long long num_waves = 0;
   double origin[3] = {0, 0, 0};
   double cell = 1.0;
+  int reach = 1;  // cells to the search radius (the search covers (2 reach + 1)^3 cells)
   int dims[3] = {1, 1, 1};
   double max_dist = 0.0;
   long long num_targets = 0;

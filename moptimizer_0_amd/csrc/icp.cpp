@@ -32,15 +32,32 @@ int buildIcpGrid(const S *src, long long n, const S *tgt, long long m, double ma
     MOPT_HIP_TRY(hipMemcpyAsync(d_src.p, src, size_t(n) * 3 * sizeof(S), hipMemcpyHostToDevice, s));
   double lo[3], hi[3];
   MOPT_HIP_TRY(mopt::icpBoundingBox<S>(d_tgt.as<S>(), m, lo, hi, s));
-  // cell edge a hair above the search radius, so the 27 cells around a query hold every target
-  // within it; enlarged when the box would need more than ~4 M cells
-  double cell = max_distance * 1.001;
-  for (;;) {
+  // Cell edge: a hair above the search radius over `reach`, so that the (2 reach + 1)^3 cells around
+  // a query hold every target within the radius.  reach = 1 while that leaves about one target per
+  // cell; where the radius spans many targets the cells are made finer (up to 8 to the radius, and
+  // never more than ~4 M cells): the search's first round looks at 2 x 2 x 2 cells whatever the
+  // radius, and what it costs goes with the targets in them.  Enlarged instead when even cells of
+  // the radius's size would be more than ~4 M.
+  const double kMostCells = double(1 << 22);
+  auto cellsAt = [&](double edge) {
     double cells = 1.0;
-    for (int a = 0; a < 3; ++a) cells *= std::floor((hi[a] - lo[a]) / cell) + 1.0;
-    if (cells <= double(1 << 22)) break;
-    cell *= 1.26;
+    for (int a = 0; a < 3; ++a) cells *= std::floor((hi[a] - lo[a]) / edge) + 1.0;
+    return cells;
+  };
+  double cell = max_distance * 1.001;
+  int reach = 1;
+  static const int forced_reach = envInt("MOPT_ICP_REACH", 0);  // tests and measurements
+  if (forced_reach > 0) {
+    reach = forced_reach > 8 ? 8 : forced_reach;
+    while (reach > 1 && cellsAt(cell / reach) > kMostCells) --reach;
+  } else {
+    while (reach < 8 && double(m) > 1.5 * cellsAt(cell / reach) &&
+           cellsAt(cell / (reach + 1)) <= kMostCells)
+      ++reach;
   }
+  cell /= reach;
+  while (cellsAt(cell) > kMostCells) cell *= 1.26;  // (only ever with reach == 1)
+  mt->reach = reach;
   mt->cell = cell;
   long long ncells = 1;
   for (int a = 0; a < 3; ++a) {
@@ -98,6 +115,7 @@ void fillIcpArgs(const mopt_cost *c, mopt::IcpMatchArgs<S> &a) {
   }
   a.inv_cell = S(1.0 / mt.cell);
   a.cell = S(mt.cell);
+  a.reach = mt.reach;
   a.max_dist2 = S(mt.max_dist * mt.max_dist);
   for (int k = 0; k < 12; ++k) a.T[k] = S(k % 5 == 0 ? 1 : 0);
   a.matched = nullptr;
@@ -193,6 +211,18 @@ int mopt_icp_update(mopt_cost *c, const void *x, int64_t *num_matched) {
   MOPT_HIP_TRY(hipSetDevice(c->device));
   return c->scalar_bytes == 8 ? icpUpdate<double>(c, static_cast<const double *>(x), num_matched)
                               : icpUpdate<float>(c, static_cast<const float *>(x), num_matched);
+}
+
+int mopt_icp_grid(const mopt_cost *c, double *cell_edge, int *reach, int dims[3], double origin[3]) {
+  if (!c || !c->matcher) return fail(MOPT_ERR_INVALID_ARGUMENT, "not an ICP cost");
+  const IcpMatcher &mt = *c->matcher;
+  if (cell_edge) *cell_edge = mt.cell;
+  if (reach) *reach = mt.reach;
+  for (int a = 0; a < 3; ++a) {
+    if (dims) dims[a] = mt.dims[a];
+    if (origin) origin[a] = mt.origin[a];
+  }
+  return MOPT_OK;
 }
 
 int mopt_icp_get_matches(mopt_cost *c, void *tgt_out_xyz) {

@@ -103,8 +103,9 @@ struct ScalarSweepArgs {
 };
 
 // Correspondence search (the model's update(x) step for ICP): targets binned into a uniform grid
-// (cell edge >= the maximum correspondence distance, so the 27 cells around a query hold every
-// candidate), stored cell by cell as padded 4-vectors with a prefix table of cell starts.
+// (`reach` cell edges >= the maximum correspondence distance, so the (2 reach + 1)^3 cells around a
+// query hold every candidate; icp.cpp picks reach by the density of the targets), stored cell by
+// cell as padded 4-vectors with a prefix table of cell starts.
 template <typename S>
 struct IcpMatchArgs {
   S *tiles;               // point2point tile layout: source planes read, target planes written
@@ -114,7 +115,8 @@ struct IcpMatchArgs {
   const int *cell_start;  // [cells + 1]
   S origin[3];
   S inv_cell;
-  S cell;                 // cell edge (>= the maximum correspondence distance)
+  S cell;                 // cell edge: reach cells cover the maximum correspondence distance
+  int reach;              // >= 1
   int dims[3];
   S max_dist2;
   S T[12];                // row-major [R | t] applied to the source before the search

@@ -737,9 +737,10 @@ __global__ __launch_bounds__(kBlockThreads) void scalarModelResidentSetKernel(
 }
 
 // ---- correspondence search (ICP update step) ---------------------------------------------------
-// One thread per source point: warp it with the current pose, visit the 27 grid cells around it,
-// keep the nearest target within the maximum distance, and write that target into the target
-// planes of the point's slot (or the NaN marker).  The reference leaves this step to the user
+// One thread per source point: warp it with the current pose, look through the grid cells around
+// it — the 2 x 2 x 2 nearest first, the wave in lock step, then what of the (2 reach + 1)^3 block
+// the best so far still admits —, keep the nearest target within the maximum distance, and write
+// that target into the target planes of the point's slot (or the NaN marker).  The reference leaves this step to the user
 // model's update(x) (model.h:24-26; "setup can be i.e nearest neighboor search", docs/Cost.puml:14-17)
 // and ships no implementation, so semantics are defined here: exact nearest neighbour in the
 // Euclidean metric, ties resolved to the first candidate in (cell z, y, x; original index) order.
@@ -761,7 +762,7 @@ __device__ __forceinline__ void icpMatchBody(const IcpMatchArgs<S> &A, const S (
   for (int a = 0; a < 3; ++a) {
     w[a] = ((T[a * 4 + 0] * p[0] + T[a * 4 + 1] * p[1]) + T[a * 4 + 2] * p[2]) + T[a * 4 + 3];
     g[a] = floor((w[a] - A.origin[a]) * A.inv_cell);
-    inside = inside && g[a] >= S(-1) && g[a] <= S(A.dims[a]);
+    inside = inside && g[a] >= S(-A.reach) && g[a] <= S(A.dims[a] - 1 + A.reach);
   }
   const int c[3] = {inside ? int(g[0]) : 0, inside ? int(g[1]) : 0, inside ? int(g[2]) : 0};
   bool found = false;
@@ -873,8 +874,8 @@ __device__ __forceinline__ void icpMatchBody(const IcpMatchArgs<S> &A, const S (
   // Everything else lies across a far face of that block: only a lane whose best so far (or the
   // maximum distance, while it has none) reaches the nearest of the three goes on — at about one
   // target per cell and a source within half a cell of its target, none.  Those that do walk the
-  // 3 x 3 x 3 block row by row under the running bound, the own cell first; cells seen above are
-  // seen again, which changes nothing (same distances, same positions).
+  // (2 reach + 1)^3 block row by row under the running bound, the own cell first; cells seen above
+  // are seen again, which changes nothing (same distances, same positions).
   const S far_x = (sx < 0 ? A.cell - fx : fx) - ex;
   const S far_y = (sy < 0 ? A.cell - fy : fy) - ey;
   const S far_z = (sz < 0 ? A.cell - fz : fz) - ez;
@@ -903,18 +904,55 @@ __device__ __forceinline__ void icpMatchBody(const IcpMatchArgs<S> &A, const S (
     const S gx[2] = {fx - ex, (A.cell - fx) - ex};
     const S gap_y[3] = {fy - ey, S(0), (A.cell - fy) - ey};
     const S gap_z[3] = {fz - ez, S(0), (A.cell - fz) - ez};
-    visit(c[1], c[2], c[0], c[0]);
+    if (A.reach == 1) {
+      visit(c[1], c[2], c[0], c[0]);
 #pragma unroll
-    for (int r = 0; r < 9; ++r) {
-      const int y = c[1] + r % 3 - 1, z = c[2] + r / 3 - 1;
-      const S yz = sq(gap_y[r % 3]) + sq(gap_z[r / 3]);
-      if (!within(yz)) continue;
-      const bool left = within(yz + sq(gx[0])), right = within(yz + sq(gx[1]));
-      if (r == 4) {  // the own row: its centre cell is done
-        if (left) visit(y, z, c[0] - 1, c[0] - 1);
-        if (right) visit(y, z, c[0] + 1, c[0] + 1);
-      } else {
-        visit(y, z, left ? c[0] - 1 : c[0], right ? c[0] + 1 : c[0]);
+      for (int r = 0; r < 9; ++r) {
+        const int y = c[1] + r % 3 - 1, z = c[2] + r / 3 - 1;
+        const S yz = sq(gap_y[r % 3]) + sq(gap_z[r / 3]);
+        if (!within(yz)) continue;
+        const bool left = within(yz + sq(gx[0])), right = within(yz + sq(gx[1]));
+        if (r == 4) {  // the own row: its centre cell is done
+          if (left) visit(y, z, c[0] - 1, c[0] - 1);
+          if (right) visit(y, z, c[0] + 1, c[0] + 1);
+        } else {
+          visit(y, z, left ? c[0] - 1 : c[0], right ? c[0] + 1 : c[0]);
+        }
+      }
+    } else {
+      // Cells finer than the radius (icp.cpp picks them so where the targets are dense): the
+      // (2 reach + 1)^3 block, its rows ring by ring around the own one — nearest first, so that the
+      // bound tightens early —, each row over the stretch of cells the bound still admits.  A ring
+      // whose nearest face is out of reach ends the walk.
+      // (every loop counter here is the same for all lanes of the wave: the loops are scalar, only
+      // the decisions inside are per lane — a lane that is done with a ring simply skips the rest)
+      const int R = A.reach;
+      auto gapAlong = [&](S near_gap, S far_gap, int d) {  // to the slab of cells d steps away
+        return d == 0 ? S(0) : (d < 0 ? near_gap : far_gap) + S((d < 0 ? -d : d) - 1) * A.cell;
+      };
+      bool walking = true;
+      for (int ring = 0; ring <= R; ++ring) {
+        if (ring > 0) {
+          const S nearest = fmin(fmin(gapAlong(gap_y[0], gap_y[2], -ring), gapAlong(gap_y[0], gap_y[2], ring)),
+                                 fmin(gapAlong(gap_z[0], gap_z[2], -ring), gapAlong(gap_z[0], gap_z[2], ring)));
+          walking = walking && within(sq(nearest));
+          if (!__any(walking)) break;
+        }
+        const int rows = ring == 0 ? 1 : 8 * ring;
+        for (int u = 0; u < rows; ++u) {
+          // row u of the ring, counter-clockwise from its (-ring, -ring) corner
+          const int side = ring == 0 ? 0 : u / (2 * ring), along = ring == 0 ? 0 : u % (2 * ring);
+          const int dy = side == 0 ? -ring + along : side == 1 ? ring : side == 2 ? ring - along : -ring;
+          const int dz = side == 0 ? -ring : side == 1 ? -ring + along : side == 2 ? ring : ring - along;
+          const S yz = sq(gapAlong(gap_y[0], gap_y[2], dy)) + sq(gapAlong(gap_z[0], gap_z[2], dz));
+          if (!(walking && within(yz))) continue;
+          int left = 0, right = 0;
+          for (int step = 0; step < R; ++step) {
+            left += (left == step && within(yz + sq(gx[0] + S(step) * A.cell))) ? 1 : 0;
+            right += (right == step && within(yz + sq(gx[1] + S(step) * A.cell))) ? 1 : 0;
+          }
+          visit(c[1] + dy, c[2] + dz, c[0] - left, c[0] + right);
+        }
       }
     }
     if (best_k != first_round_k) fetch(best_k, best);

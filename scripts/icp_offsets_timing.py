@@ -3,7 +3,8 @@
 `offset` cells away (0 = aligned, 0.2 = the benchmark of icp_timing.py, 0.7 and 1.5 = most lanes
 have to look beyond the 2 x 2 x 2 cells of the first round).  MOPT_ICP_FIRST_ROUND=0 runs the
 row-by-row search alone.
-Usage: python scripts/icp_offsets_timing.py [--dtype f32] [--per-cell 1]"""
+MOPT_ICP_REACH=k forces k cells to the radius (default: by the density of the targets).
+Usage: python scripts/icp_offsets_timing.py [--dtype f32] [--per-cell 1] [--offsets 0,0.2,0.7]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,7 +22,8 @@ rng = np.random.default_rng(1)
 side = 100.0
 tgt = rng.random((n, 3)) * side
 max_dist = side * (per_cell / n) ** (1.0 / 3.0)
-for offset in (0.0, 0.2, 0.7, 1.5):
+offsets = [float(v) for v in arg("--offsets", "0,0.2,0.7,1.5").split(",")]
+for offset in offsets:
     shift = np.array([1.0, -1.0, 1.0]) / np.sqrt(3.0) * offset * max_dist
     src = tgt[rng.permutation(n)] + rng.normal(0, 0.01 * max_dist, (n, 3)) + shift
     cost = mo.IcpCost(src, tgt, max_dist, dtype=dtype)
@@ -31,6 +33,6 @@ for offset in (0.0, 0.2, 0.7, 1.5):
     for _ in range(20):
         t0 = time.perf_counter(); m = cost.update(x); ts.append(time.perf_counter() - t0)
     dt = float(np.median(ts))
-    print("first_round=%s %s n=%d targets/cell~%.0f offset %.1f cells: update %.3f ms, %d matched"
-          % (os.environ.get("MOPT_ICP_FIRST_ROUND", "1"), arg("--dtype", "f64"), n, per_cell, offset, dt * 1e3, m), flush=True)
+    print("first_round=%s reach=%d %s n=%d targets per radius cube~%.0f offset %.2f radii: update %.3f ms, %d matched"
+          % (os.environ.get("MOPT_ICP_FIRST_ROUND", "1"), cost.grid()[1], arg("--dtype", "f64"), n, per_cell, offset, dt * 1e3, m), flush=True)
     cost.close()

@@ -862,8 +862,10 @@ def test_icp_matcher_equals_brute_force(hip_lib, dtype):
     rng = np.random.default_rng(12)
     tgt = (rng.random((4000, 3)) * np.array([10.0, 6.0, 3.0])).astype(dtype)
     src = (rng.random((3000, 3)) * np.array([12.0, 7.0, 4.0]) - 1.0).astype(dtype)   # some outside
+    reaches = []
     for max_dist in (0.15, 0.5, 2.5):
         cost = hip_lib.IcpCost(src, tgt, max_dist, dtype=dtype)
+        reaches.append(cost.grid()[1])
         for x in (np.zeros(6), np.array([0.3, -0.2, 0.1, 0.05, -0.02, 0.04])):
             n = cost.update(x.astype(dtype))
             got = cost.matches()
@@ -877,6 +879,7 @@ def test_icp_matcher_equals_brute_force(hip_lib, dtype):
                 both = ~miss_g & ~miss_w
                 assert (np.abs(got[both] - want[both]).max(1) > 0).mean() < 2e-3
             assert n == int((~miss_g).sum())
+    assert reaches[0] == 1 and reaches[1] > 1 and reaches[2] > reaches[1]   # 0.07 / 3 / 350 targets per radius cube
     with pytest.raises(hip_lib.MoptError):   # the search owns the correspondences of such a cost
         cost.set_data(src, src)
     # degenerate clouds: no targets at all, and a single target far away -> nothing matched
@@ -902,8 +905,12 @@ def test_icp_ties_go_to_the_target_stored_first(hip_lib, dtype):
     src = np.concatenate([base + np.array(o) for o in
                           ((0.5, 0, 0), (0, 0.5, 0), (0, 0, 0.5), (0.5, 0.5, 0), (0.5, 0, 0.5),
                            (0, 0.5, 0.5), (0.5, 0.5, 0.5), (0.25, 0.5, 0.5))])
-    for max_dist in (0.9, 1.0, 0.5, np.sqrt(0.75)):
-        cell = max_dist * 1.001          # icp.cpp: the cell edge is a hair above the radius
+    reaches = set()
+    for max_dist in (0.9, 1.0, 0.5, np.sqrt(0.75), 2.0):
+        cost = hip_lib.IcpCost(src.astype(dtype), tgt.astype(dtype), float(dtype(max_dist)), dtype=dtype)
+        cell, reach, dims, origin = cost.grid()   # cells finer than the radius where it holds many targets
+        assert reach >= 1 and cell * reach >= max_dist and (origin == 0).all()
+        reaches.add(reach)
         d2 = ((src[:, None, :] - tgt[None, :, :]) ** 2).sum(-1)
         cells = np.floor(tgt / cell).astype(np.int64)      # the box of the targets starts at 0
         key = ((cells[:, 2] * 1000 + cells[:, 1]) * 1000 + cells[:, 0]) * 100000 + np.arange(len(tgt))
@@ -912,7 +919,6 @@ def test_icp_ties_go_to_the_target_stored_first(hip_lib, dtype):
         winner = np.where(tied, key[None, :], np.iinfo(np.int64).max).argmin(1)
         want = tgt[winner].copy()
         want[best > max_dist ** 2] = np.nan
-        cost = hip_lib.IcpCost(src.astype(dtype), tgt.astype(dtype), float(dtype(max_dist)), dtype=dtype)
         n = cost.update(np.zeros(6, dtype=dtype))
         got = cost.matches()
         if dtype == np.float32 and max_dist == np.sqrt(0.75):
@@ -922,6 +928,7 @@ def test_icp_ties_go_to_the_target_stored_first(hip_lib, dtype):
         assert np.array_equal(got[ok], want[ok].astype(dtype)), max_dist
         assert n == int(ok.sum())
         cost.close()
+    assert len(reaches) >= 2   # both the one-cell and the finer-cell walk have been through this
 
 
 def test_icp_solve_with_gpu_correspondence_search(hip_lib, oracle):
