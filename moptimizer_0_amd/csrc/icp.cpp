@@ -35,10 +35,10 @@ int buildIcpGrid(const S *src, long long n, const S *tgt, long long m, double ma
   // Cell edge: a hair above the search radius over `reach`, so that the (2 reach + 1)^3 cells around
   // a query hold every target within the radius.  reach = 1 while that leaves about one target per
   // cell; where the radius spans many targets the cells are made finer (up to 8 to the radius, and
-  // never more than ~4 M cells): the search's first round looks at 2 x 2 x 2 cells whatever the
+  // never more than ~16 M cells: a 64 MB offset table): the search's first round looks at 2 x 2 x 2 cells whatever the
   // radius, and what it costs goes with the targets in them.  Enlarged instead when even cells of
-  // the radius's size would be more than ~4 M.
-  const double kMostCells = double(1 << 22);
+  // the radius's size would be more than that.
+  const double kMostCells = double(1 << 24);
   auto cellsAt = [&](double edge) {
     double cells = 1.0;
     for (int a = 0; a < 3; ++a) cells *= std::floor((hi[a] - lo[a]) / edge) + 1.0;

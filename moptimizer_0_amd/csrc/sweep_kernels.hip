@@ -834,7 +834,7 @@ __device__ __forceinline__ void icpMatchBody(const IcpMatchArgs<S> &A, const S (
     for (int r = 0; r < 4; ++r) {
       const int y = c[1] + sy + (r & 1), z = c[2] + sz + (r >> 1);
       const bool ok = inside && xa <= xb && y >= 0 && y < A.dims[1] && z >= 0 && z < A.dims[2];
-      const int row = (z * A.dims[1] + y) * A.dims[0];  // the grid has at most 2^22 cells (icp.cpp)
+      const int row = (z * A.dims[1] + y) * A.dims[0];  // the grid has at most 2^24 cells (icp.cpp)
       at_a[r] = ok ? row + xa : 0;  // (entry 0 twice: an empty run)
       at_b[r] = ok ? row + xb + 1 : 0;
     }
