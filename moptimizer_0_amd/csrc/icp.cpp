@@ -44,38 +44,57 @@ int buildIcpGrid(const S *src, long long n, const S *tgt, long long m, double ma
     for (int a = 0; a < 3; ++a) cells *= std::floor((hi[a] - lo[a]) / edge) + 1.0;
     return cells;
   };
-  double cell = max_distance * 1.001;
+  const double radius_cell = max_distance * 1.001;
+  auto mostReach = [&](int wanted) {  // the largest reach <= wanted the cell budget allows
+    while (wanted > 1 && cellsAt(radius_cell / wanted) > kMostCells) --wanted;
+    return wanted;
+  };
   int reach = 1;
   static const int forced_reach = envInt("MOPT_ICP_REACH", 0);  // tests and measurements
   if (forced_reach > 0) {
-    reach = forced_reach > 8 ? 8 : forced_reach;
-    while (reach > 1 && cellsAt(cell / reach) > kMostCells) --reach;
+    reach = mostReach(forced_reach > 8 ? 8 : forced_reach);
   } else {
-    while (reach < 8 && double(m) > 1.5 * cellsAt(cell / reach) &&
-           cellsAt(cell / (reach + 1)) <= kMostCells)
+    while (reach < 8 && double(m) > 1.5 * cellsAt(radius_cell / reach) && mostReach(reach + 1) > reach)
       ++reach;
-  }
-  cell /= reach;
-  while (cellsAt(cell) > kMostCells) cell *= 1.26;  // (only ever with reach == 1)
-  mt->reach = reach;
-  mt->cell = cell;
-  long long ncells = 1;
-  for (int a = 0; a < 3; ++a) {
-    mt->origin[a] = lo[a];
-    mt->dims[a] = int(std::floor((hi[a] - lo[a]) / cell)) + 1;
-    ncells *= mt->dims[a];
   }
   out_matcher = std::move(mt);  // from here on the caller frees the matcher's device arrays
   IcpMatcher &g = *out_matcher;
-  MOPT_HIP_TRY(deviceAlloc(reinterpret_cast<void **>(&g.d_cell_start), size_t(ncells + 1) * sizeof(int)));
+  MOPT_HIP_TRY(d_perm_t.alloc(size_t(m) * sizeof(int)));
+  // The box's volume says little about how the targets fill it (a scanned surface occupies a thin
+  // sheet of the cells): after the first binning the cells that hold anything are counted, and while
+  // they hold more than three targets each on average the grid is made finer and the targets are
+  // binned again (at most twice more; a binning is ~0.25 ms per million).
+  for (int attempt = 0;; ++attempt) {
+    double cell = radius_cell / reach;
+    while (cellsAt(cell) > kMostCells) cell *= 1.26;  // (only ever with reach == 1)
+    g.reach = reach;
+    g.cell = cell;
+    long long ncells = 1;
+    for (int a = 0; a < 3; ++a) {
+      g.origin[a] = lo[a];
+      g.dims[a] = int(std::floor((hi[a] - lo[a]) / cell)) + 1;
+      ncells *= g.dims[a];
+    }
+    if (g.d_cell_start) deviceRelease(g.d_cell_start);
+    g.d_cell_start = nullptr;
+    MOPT_HIP_TRY(deviceAlloc(reinterpret_cast<void **>(&g.d_cell_start), size_t(ncells + 1) * sizeof(int)));
+    MOPT_HIP_TRY(mopt::icpSortByCell<S>(d_tgt.as<S>(), m, g.origin, g.cell, g.dims, d_perm_t.as<int>(),
+                                        g.d_cell_start, s));
+    if (forced_reach > 0 || m == 0 || attempt == 2 || reach == 8) break;
+    long long occupied = 0;
+    MOPT_HIP_TRY(mopt::icpCountOccupiedCells(g.d_cell_start, ncells, &occupied, s));
+    const double per_cell = double(m) / double(occupied > 0 ? occupied : 1);
+    if (per_cell <= 3.0) break;
+    const int wanted = int(std::ceil(reach * std::sqrt(per_cell / 1.5)));
+    const int finer = mostReach(std::min(8, std::max(reach + 1, wanted)));
+    if (finer <= reach) break;
+    reach = finer;
+  }
   // one matched count per wave of the search (whole tiles of sources, 64 to a wave)
   constexpr long long kTile = mopt::TileShape<S>::kPoints;
   g.num_waves = (n + kTile - 1) / kTile * kTile / 64;
   MOPT_HIP_TRY(deviceAlloc(reinterpret_cast<void **>(&g.d_matched),
                            size_t(g.num_waves > 0 ? g.num_waves : 1) * sizeof(unsigned int)));
-  MOPT_HIP_TRY(d_perm_t.alloc(size_t(m) * sizeof(int)));
-  MOPT_HIP_TRY(mopt::icpSortByCell<S>(d_tgt.as<S>(), m, g.origin, g.cell, g.dims, d_perm_t.as<int>(),
-                                      g.d_cell_start, s));
   if (m > 0) {
     MOPT_HIP_TRY(deviceAlloc(&g.d_sorted, size_t(m) * 4 * sizeof(S)));
     MOPT_HIP_TRY(mopt::icpGatherPoints<S>(d_tgt.as<S>(), d_perm_t.as<int>(), m,

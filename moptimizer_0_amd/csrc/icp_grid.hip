@@ -372,6 +372,39 @@ hipError_t icpGatherPoints(const S *d_xyz, const int *d_perm, long long m, S *d_
   return hipGetLastError();
 }
 
+// how many cells hold at least one target: one count per workgroup, added up on the host (this is
+// part of building the grid, which ends in a stream synchronisation anyway)
+__global__ __launch_bounds__(kBlockThreads) void occupiedCellsKernel(const int *cell_start,
+                                                                     long long ncells,
+                                                                     unsigned int *per_block) {
+  const long long c = (long long)blockIdx.x * kBlockThreads + threadIdx.x;
+  const bool occupied = c < ncells && cell_start[c + 1] > cell_start[c];
+  const int in_block = __syncthreads_count(occupied ? 1 : 0);
+  if (threadIdx.x == 0) per_block[blockIdx.x] = (unsigned int)in_block;
+}
+
+hipError_t icpCountOccupiedCells(const int *d_cell_start, long long ncells, long long *occupied,
+                                 hipStream_t stream) {
+  *occupied = 0;
+  if (ncells <= 0) return hipSuccess;
+  const unsigned blocks = unsigned((ncells + kBlockThreads - 1) / kBlockThreads);
+  unsigned int *d_counts = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_counts), size_t(blocks) * sizeof(unsigned int));
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(occupiedCellsKernel, dim3(blocks), dim3(kBlockThreads), 0, stream, d_cell_start,
+                     ncells, d_counts);
+  std::vector<unsigned int> counts(blocks);
+  e = hipGetLastError();
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(counts.data(), d_counts, size_t(blocks) * sizeof(unsigned int),
+                       hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  (void)hipFree(d_counts);
+  if (e != hipSuccess) return e;
+  for (unsigned int v : counts) *occupied += v;
+  return hipSuccess;
+}
+
 #define MOPT_INSTANTIATE_GRID(S)                                                                  \
   template hipError_t icpBoundingBox<S>(const S *, long long, double[3], double[3], hipStream_t); \
   template hipError_t icpSortByCell<S>(const S *, long long, const double[3], double,             \

@@ -369,6 +369,9 @@ hipError_t icpBoundingBox(const S *d_xyz, long long m, double lo[3], double hi[3
 template <typename S>
 hipError_t icpSortByCell(const S *d_xyz, long long m, const double origin[3], double cell,
                          const int dims[3], int *d_perm, int *d_cell_start, hipStream_t stream);
+// cells of the grid that hold at least one point (synchronises the stream)
+hipError_t icpCountOccupiedCells(const int *d_cell_start, long long ncells, long long *occupied,
+                                 hipStream_t stream);
 template <typename S>
 hipError_t icpGatherPoints(const S *d_xyz, const int *d_perm, long long m, S *d_out, bool padded,
                            hipStream_t stream);

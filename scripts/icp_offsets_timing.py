@@ -4,7 +4,7 @@
 have to look beyond the 2 x 2 x 2 cells of the first round).  MOPT_ICP_FIRST_ROUND=0 runs the
 row-by-row search alone.
 MOPT_ICP_REACH=k forces k cells to the radius (default: by the density of the targets).
-Usage: python scripts/icp_offsets_timing.py [--dtype f32] [--per-cell 1] [--offsets 0,0.2,0.7]"""
+Usage: python scripts/icp_offsets_timing.py [--dtype f32] [--per-cell 1 | --surface --radius-spacings 3] [--offsets 0,0.2,0.7]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,8 +20,14 @@ n = int(arg("--n", "1000000"))
 mo.capi.device_count()
 rng = np.random.default_rng(1)
 side = 100.0
-tgt = rng.random((n, 3)) * side
-max_dist = side * (per_cell / n) ** (1.0 / 3.0)
+if "--surface" in sys.argv:
+    # a scanned surface: a wavy sheet through the box; the radius is given in point spacings
+    uv = rng.random((n, 2)) * side
+    tgt = np.column_stack([uv, 10.0 * np.sin(uv[:, 0] / 10.0) * np.cos(uv[:, 1] / 15.0) + 50.0])
+    max_dist = float(arg("--radius-spacings", "3")) * side / np.sqrt(n)
+else:
+    tgt = rng.random((n, 3)) * side
+    max_dist = side * (per_cell / n) ** (1.0 / 3.0)
 offsets = [float(v) for v in arg("--offsets", "0,0.2,0.7,1.5").split(",")]
 for offset in offsets:
     shift = np.array([1.0, -1.0, 1.0]) / np.sqrt(3.0) * offset * max_dist
@@ -33,6 +39,8 @@ for offset in offsets:
     for _ in range(20):
         t0 = time.perf_counter(); m = cost.update(x); ts.append(time.perf_counter() - t0)
     dt = float(np.median(ts))
-    print("first_round=%s reach=%d %s n=%d targets per radius cube~%.0f offset %.2f radii: update %.3f ms, %d matched"
-          % (os.environ.get("MOPT_ICP_FIRST_ROUND", "1"), cost.grid()[1], arg("--dtype", "f64"), n, per_cell, offset, dt * 1e3, m), flush=True)
+    what = ("surface, radius %s spacings" % arg("--radius-spacings", "3")) if "--surface" in sys.argv \
+        else "targets per radius cube~%.0f" % per_cell
+    print("first_round=%s reach=%d %s n=%d %s offset %.2f radii: update %.3f ms, %d matched"
+          % (os.environ.get("MOPT_ICP_FIRST_ROUND", "1"), cost.grid()[1], arg("--dtype", "f64"), n, what, offset, dt * 1e3, m), flush=True)
     cost.close()
