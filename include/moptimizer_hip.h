@@ -167,7 +167,10 @@ MOPT_API int mopt_point2point_set_data(mopt_cost *cost, const void *src_xyz, con
  * sources without one are skipped by the sweeps exactly as an index whose f() returns false
  * (linearization.h:102,144).  mopt_icp_create builds a point2point cost over `num_src` sources
  * whose targets are (re)chosen from the `num_tgt`-point target cloud by every mopt_icp_update; all
- * cost calls (linearize / compute / covariance / loss) apply unchanged.  Host arrays, packed xyz. */
+ * cost calls (linearize / compute / covariance / loss) apply unchanged.  Host arrays, packed xyz.
+ * Targets with a NaN or infinite coordinate are ignored (they do not shape the grid and are never
+ * matched); a source with one is never matched either, but its arithmetic is masked by weight, not
+ * skipped, so the sums of such a cloud are NaN — as the reference's over NaN data: filter sources. */
 MOPT_API int mopt_icp_create(mopt_cost **out, int device, int scalar_bytes, const void *src_xyz,
                              int64_t num_src, const void *tgt_xyz, int64_t num_tgt,
                              double max_distance);

@@ -31,8 +31,9 @@ __global__ __launch_bounds__(kBlockThreads) void boundingBoxKernel(const S *xyz,
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const double v = double(xyz[3 * i + a]);
-      lo[a] = v < lo[a] ? v : lo[a];
-      hi[a] = v > hi[a] ? v : hi[a];
+      const bool finite = fabs(v) <= 1e300;  // (NaN and +-Inf coordinates do not shape the grid)
+      lo[a] = finite && v < lo[a] ? v : lo[a];
+      hi[a] = finite && v > hi[a] ? v : hi[a];
     }
   }
   __shared__ double lds[kBlockThreads / 64][6];
@@ -80,7 +81,8 @@ __global__ __launch_bounds__(kBlockThreads) void cellKeyKernel(const S *xyz, lon
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     double c = floor((double(xyz[3 * i + a]) - g.origin[a]) / g.cell);
-    c = c < 0.0 ? 0.0 : (c >= double(g.dims[a]) ? double(g.dims[a] - 1) : c);
+    c = c >= 0.0 ? c : 0.0;  // (also a NaN coordinate: such a point is never anyone's nearest)
+    c = c >= double(g.dims[a]) ? double(g.dims[a] - 1) : c;
     id += (long long)c * stride;
     stride *= g.dims[a];
   }
@@ -277,6 +279,8 @@ hipError_t icpBoundingBox(const S *d_xyz, long long m, double lo[3], double hi[3
       if (part[size_t(b) * 6 + a] < lo[a]) lo[a] = part[size_t(b) * 6 + a];
       if (part[size_t(b) * 6 + 3 + a] > hi[a]) hi[a] = part[size_t(b) * 6 + 3 + a];
     }
+  for (int a = 0; a < 3; ++a)
+    if (!(lo[a] <= hi[a])) lo[a] = hi[a] = 0.0;  // no finite coordinate on this axis
   return hipSuccess;
 }
 

@@ -931,6 +931,40 @@ def test_icp_ties_go_to_the_target_stored_first(hip_lib, dtype):
     assert len(reaches) >= 2   # both the one-cell and the finer-cell walk have been through this
 
 
+def test_icp_clouds_with_non_finite_points(hip_lib):
+    """NaN and infinite coordinates in either cloud: they do not shape the grid, are nobody's
+    nearest target, and such a source stays unmatched; everything else as without them.  (The
+    sums over a cloud whose SOURCES hold a non-finite coordinate are NaN, as the reference's would
+    be: the arithmetic of an unmatched source is masked by weight, not skipped.)"""
+    rng = np.random.default_rng(21)
+    tgt = rng.random((3000, 3)) * np.array([8.0, 5.0, 3.0])
+    src = tgt[rng.permutation(3000)[:2000]] + rng.normal(0, 0.02, (2000, 3))
+    bad_t, bad_s = tgt.copy(), src.copy()
+    bad_t[5, 1] = np.nan
+    bad_t[77] = np.inf
+    bad_t[400, 2] = -np.inf
+    bad_s[3, 0] = np.nan
+    bad_s[10, 2] = np.inf
+    max_dist = 0.4
+    cost = hip_lib.IcpCost(bad_s, bad_t, max_dist)
+    cell, reach, dims, origin = cost.grid()
+    assert np.isfinite(cell) and (dims < 1000).all() and np.isfinite(origin).all()
+    n = cost.update(np.zeros(6))
+    got = cost.matches()
+    clean = np.isfinite(bad_t).all(1)
+    want = _brute_force_matches(src, tgt[clean], np.zeros(6), max_dist)
+    want[[3, 10]] = np.nan
+    assert np.array_equal(np.isnan(got[:, 0]), np.isnan(want[:, 0]))
+    ok = ~np.isnan(want[:, 0])
+    assert np.array_equal(got[ok], want[ok]) and n == int(ok.sum())
+    assert np.isnan(cost.linearize(np.zeros(6), 0)[0]).all()
+    finite_sources = hip_lib.IcpCost(src, bad_t, max_dist)
+    assert finite_sources.update(np.zeros(6)) == n + 2 - int(np.isnan(_brute_force_matches(
+        src[[3, 10]], tgt[clean], np.zeros(6), max_dist)[:, 0]).sum())
+    H, b, c = finite_sources.linearize(np.zeros(6), 0)
+    assert np.isfinite(H).all() and np.isfinite(b).all() and np.isfinite(c) and c > 0
+
+
 def test_icp_solve_with_gpu_correspondence_search(hip_lib, oracle):
     """Real ICP: unknown correspondences, re-matched at the top of every outer LM iteration
     (cost->update(x), levenberg_marquadt_dyn.cpp:54).  Target = moved source + noise, shuffled,
