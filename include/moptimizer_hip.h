@@ -168,15 +168,16 @@ MOPT_API int mopt_point2point_set_data(mopt_cost *cost, const void *src_xyz, con
  * (linearization.h:102,144).  mopt_icp_create builds a point2point cost over `num_src` sources
  * whose targets are (re)chosen from the `num_tgt`-point target cloud by every mopt_icp_update; all
  * cost calls (linearize / compute / covariance / loss) apply unchanged.  Host arrays, packed xyz.
- * Targets with a NaN or infinite coordinate are ignored (they do not shape the grid and are never
- * matched); a source with one is never matched either, but its arithmetic is masked by weight, not
- * skipped, so the sums of such a cloud are NaN — as the reference's over NaN data: filter sources. */
+ * Points with a NaN or infinite coordinate (the invalid pixels of a depth image) are left out: such
+ * a target does not shape the grid and is never matched; such a source is not part of the cost (no
+ * residual, no sum sees it) and mopt_icp_get_matches reports a NaN triple for it. */
 MOPT_API int mopt_icp_create(mopt_cost **out, int device, int scalar_bytes, const void *src_xyz,
                              int64_t num_src, const void *tgt_xyz, int64_t num_tgt,
                              double max_distance);
 MOPT_API int mopt_icp_update(mopt_cost *cost, const void *x, int64_t *num_matched /* may be NULL */);
-/* current target of every source as packed xyz (NaN triple where unmatched); host buffer of
- * num_src * 3 scalars.  Works for any point2point cost. */
+/* current target of every source as packed xyz (NaN triple where unmatched), in the order of the
+ * array handed to mopt_icp_create; host buffer of num_src * 3 scalars.  Works for any point2point
+ * cost. */
 MOPT_API int mopt_icp_get_matches(mopt_cost *cost, void *tgt_out_xyz);
 /* The uniform grid an ICP cost searches: cell edge, cells to the search radius (`reach`: 1 where the
  * radius holds about one target, up to 8 where it holds many — the cells are then finer than the

@@ -60,6 +60,7 @@ struct IcpMatcher {
   int *d_cell_start = nullptr;   // [cells + 1]
   unsigned int *d_matched = nullptr;  // matched sources per wave of the last counting search
   long long num_waves = 0;
+  long long num_sources = 0;  // as handed to mopt_icp_create (the cost holds those with finite coordinates)
   double origin[3] = {0, 0, 0};
   double cell = 1.0;
   int reach = 1;  // cells to the search radius (the search covers (2 reach + 1)^3 cells)

@@ -90,26 +90,31 @@ int buildIcpGrid(const S *src, long long n, const S *tgt, long long m, double ma
     if (finer <= reach) break;
     reach = finer;
   }
-  // one matched count per wave of the search (whole tiles of sources, 64 to a wave)
+  // (one matched count per wave of the search: whole tiles of sources, 64 to a wave)
   constexpr long long kTile = mopt::TileShape<S>::kPoints;
-  g.num_waves = (n + kTile - 1) / kTile * kTile / 64;
-  MOPT_HIP_TRY(deviceAlloc(reinterpret_cast<void **>(&g.d_matched),
-                           size_t(g.num_waves > 0 ? g.num_waves : 1) * sizeof(unsigned int)));
   if (m > 0) {
     MOPT_HIP_TRY(deviceAlloc(&g.d_sorted, size_t(m) * 4 * sizeof(S)));
     MOPT_HIP_TRY(mopt::icpGatherPoints<S>(d_tgt.as<S>(), d_perm_t.as<int>(), m,
                                           static_cast<S *>(g.d_sorted), true, s));
   }
-  // the sources in the cell order of their un-warped position
+  // the sources in the cell order of their un-warped position; those with a NaN or infinite
+  // coordinate sort behind the others and are left out of the cost (they can have no target, and
+  // their arithmetic would turn every sum into NaN): the cost holds the first `kept` of the order
   MOPT_HIP_TRY(d_perm_s.alloc(size_t(n) * sizeof(int)));
+  long long parked = 0;
   MOPT_HIP_TRY(mopt::icpSortByCell<S>(d_src.as<S>(), n, g.origin, g.cell, g.dims, d_perm_s.as<int>(),
-                                      nullptr, s));
-  MOPT_HIP_TRY(d_src_sorted.alloc(size_t(n) * 3 * sizeof(S)));
-  MOPT_HIP_TRY(mopt::icpGatherPoints<S>(d_src.as<S>(), d_perm_s.as<int>(), n, d_src_sorted.as<S>(),
+                                      nullptr, s, &parked));
+  const long long kept = n - parked;
+  g.num_sources = n;
+  g.num_waves = (kept + kTile - 1) / kTile * kTile / 64;
+  MOPT_HIP_TRY(deviceAlloc(reinterpret_cast<void **>(&g.d_matched),
+                           size_t(g.num_waves > 0 ? g.num_waves : 1) * sizeof(unsigned int)));
+  MOPT_HIP_TRY(d_src_sorted.alloc(size_t(kept) * 3 * sizeof(S)));
+  MOPT_HIP_TRY(mopt::icpGatherPoints<S>(d_src.as<S>(), d_perm_s.as<int>(), kept, d_src_sorted.as<S>(),
                                         false, s));
-  std::vector<int> perm(static_cast<size_t>(n));
-  if (n > 0)
-    MOPT_HIP_TRY(hipMemcpyAsync(perm.data(), d_perm_s.p, size_t(n) * sizeof(int),
+  std::vector<int> perm(static_cast<size_t>(kept));
+  if (kept > 0)
+    MOPT_HIP_TRY(hipMemcpyAsync(perm.data(), d_perm_s.p, size_t(kept) * sizeof(int),
                                 hipMemcpyDeviceToHost, s));
   MOPT_HIP_TRY(hipStreamSynchronize(s));
   g.order.assign(perm.begin(), perm.end());
@@ -207,8 +212,8 @@ int mopt_icp_create(mopt_cost **out, int device, int scalar_bytes, const void *s
   // first search
   mopt_cost *raw = nullptr;
   if (rc == MOPT_OK)
-    rc = mopt_point2point_create(&raw, device, scalar_bytes, d_src_sorted.p, d_src_sorted.p, num_src,
-                                 MOPT_INPUT_DEVICE);
+    rc = mopt_point2point_create(&raw, device, scalar_bytes, d_src_sorted.p, d_src_sorted.p,
+                                 int64_t(matcher->order.size()), MOPT_INPUT_DEVICE);
   if (rc != MOPT_OK) {
     freeMatcher();
     return rc;
@@ -248,6 +253,15 @@ int mopt_icp_get_matches(mopt_cost *c, void *tgt_out_xyz) {
   if (!c || !tgt_out_xyz) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
   if (c->model != kModelPoint2Point) return fail(MOPT_ERR_INVALID_ARGUMENT, "not a point2point cost");
   MOPT_HIP_TRY(hipSetDevice(c->device));
+  // sources an ICP cost left out (non-finite coordinates) have no target: NaN triples for them
+  if (c->matcher && c->matcher->num_sources > c->count) {
+    const double nan8 = std::numeric_limits<double>::quiet_NaN();
+    const float nan4 = std::numeric_limits<float>::quiet_NaN();
+    for (size_t k = 0; k < size_t(c->matcher->num_sources) * 3; ++k) {
+      if (c->scalar_bytes == 8) static_cast<double *>(tgt_out_xyz)[k] = nan8;
+      else static_cast<float *>(tgt_out_xyz)[k] = nan4;
+    }
+  }
   if (c->count == 0) return MOPT_OK;
   const size_t bytes = size_t(c->count) * 3 * c->scalar_bytes;
   void *d_tmp = nullptr;

@@ -70,23 +70,40 @@ struct GridShape {
   int dims[3];
 };
 
-// cell id of every point (clamped into the grid)
+// cell id of every point (clamped into the grid); with parked_key >= 0 a point with a NaN or
+// infinite coordinate gets that key instead — one past the last cell, so it sorts behind all others
 template <typename S>
 __global__ __launch_bounds__(kBlockThreads) void cellKeyKernel(const S *xyz, long long m,
                                                                const GridShape g,
+                                                               long long parked_key,
                                                                unsigned int *keys) {
   const long long i = (long long)blockIdx.x * kBlockThreads + threadIdx.x;
   if (i >= m) return;
   long long id = 0, stride = 1;
+  bool finite = true;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    double c = floor((double(xyz[3 * i + a]) - g.origin[a]) / g.cell);
+    const double v = double(xyz[3 * i + a]);
+    finite = finite && fabs(v) <= 1e300;
+    double c = floor((v - g.origin[a]) / g.cell);
     c = c >= 0.0 ? c : 0.0;  // (also a NaN coordinate: such a point is never anyone's nearest)
     c = c >= double(g.dims[a]) ? double(g.dims[a] - 1) : c;
     id += (long long)c * stride;
     stride *= g.dims[a];
   }
-  keys[i] = (unsigned int)id;
+  keys[i] = (unsigned int)((parked_key >= 0 && !finite) ? parked_key : id);
+}
+
+// how many of the sorted keys are the parked key (they are the last ones)
+__global__ void countParkedKernel(const unsigned int *sorted_keys, long long m,
+                                  unsigned int parked_key, long long *out) {
+  long long lo = 0, hi = m;  // first position whose key is >= parked_key
+  while (lo < hi) {
+    const long long mid = (lo + hi) / 2;
+    if (sorted_keys[mid] < parked_key) lo = mid + 1;
+    else hi = mid;
+  }
+  *out = m - lo;
 }
 
 // ---- stable LSD radix sort of (cell id, point index) pairs, 8 bits per pass --------------------
@@ -286,7 +303,9 @@ hipError_t icpBoundingBox(const S *d_xyz, long long m, double lo[3], double hi[3
 
 template <typename S>
 hipError_t icpSortByCell(const S *d_xyz, long long m, const double origin[3], double cell,
-                         const int dims[3], int *d_perm, int *d_cell_start, hipStream_t stream) {
+                         const int dims[3], int *d_perm, int *d_cell_start, hipStream_t stream,
+                         long long *num_parked) {
+  if (num_parked) *num_parked = 0;
   long long ncells = 1;
   GridShape g;
   for (int a = 0; a < 3; ++a) {
@@ -303,7 +322,7 @@ hipError_t icpSortByCell(const S *d_xyz, long long m, const double origin[3], do
   // scratch: two key buffers, one value buffer (the other one is d_perm) and the histogram table
   const int num_groups = int((m + kSortTile - 1) / kSortTile);
   int bits = 1;
-  while ((1ll << bits) < ncells) ++bits;
+  while ((1ll << bits) < ncells + (num_parked ? 1 : 0)) ++bits;
   const int passes = (bits + 7) / 8;
   const long long table = (long long)kDigits * num_groups;  // (digit, workgroup) counters
   const int scan_tiles = int((table + kScanTile - 1) / kScanTile);
@@ -329,7 +348,7 @@ hipError_t icpSortByCell(const S *d_xyz, long long m, const double origin[3], do
     return e;
   }
   hipLaunchKernelGGL(cellKeyKernel<S>, dim3(blocksFor(m)), dim3(kBlockThreads), 0, stream, d_xyz, m,
-                     g, keys);
+                     g, num_parked ? ncells : -1ll, keys);
   const unsigned int *keys_in = keys;
   unsigned int *keys_out = keys_alt;
   const int *values_in = nullptr;  // pass 1: value i = index i
@@ -358,7 +377,17 @@ hipError_t icpSortByCell(const S *d_xyz, long long m, const double origin[3], do
                        keys_sorted, m, int(ncells), d_cell_start);
     e = hipGetLastError();
   }
+  long long *d_parked = nullptr;
+  if (e == hipSuccess && num_parked) {
+    e = hipMalloc(reinterpret_cast<void **>(&d_parked), sizeof(long long));
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(countParkedKernel, dim3(1), dim3(1), 0, stream, keys_sorted, m,
+                         (unsigned int)ncells, d_parked);
+      e = hipMemcpyAsync(num_parked, d_parked, sizeof(long long), hipMemcpyDeviceToHost, stream);
+    }
+  }
   if (e == hipSuccess) e = hipStreamSynchronize(stream);  // the scratch arrays die here
+  if (d_parked) (void)hipFree(d_parked);
   release();
   return e;
 }
@@ -412,7 +441,7 @@ hipError_t icpCountOccupiedCells(const int *d_cell_start, long long ncells, long
 #define MOPT_INSTANTIATE_GRID(S)                                                                  \
   template hipError_t icpBoundingBox<S>(const S *, long long, double[3], double[3], hipStream_t); \
   template hipError_t icpSortByCell<S>(const S *, long long, const double[3], double,             \
-                                       const int[3], int *, int *, hipStream_t);                  \
+                                       const int[3], int *, int *, hipStream_t, long long *);     \
   template hipError_t icpGatherPoints<S>(const S *, const int *, long long, S *, bool, hipStream_t);
 MOPT_INSTANTIATE_GRID(double)
 MOPT_INSTANTIATE_GRID(float)

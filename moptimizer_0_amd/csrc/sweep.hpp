@@ -368,7 +368,9 @@ hipError_t icpBoundingBox(const S *d_xyz, long long m, double lo[3], double hi[3
                           hipStream_t stream);
 template <typename S>
 hipError_t icpSortByCell(const S *d_xyz, long long m, const double origin[3], double cell,
-                         const int dims[3], int *d_perm, int *d_cell_start, hipStream_t stream);
+                         const int dims[3], int *d_perm, int *d_cell_start, hipStream_t stream,
+                         long long *num_parked = nullptr);  // non-NULL: points with a non-finite
+                                                             // coordinate sort last and are counted
 // cells of the grid that hold at least one point (synchronises the stream)
 hipError_t icpCountOccupiedCells(const int *d_cell_start, long long ncells, long long *occupied,
                                  hipStream_t stream);

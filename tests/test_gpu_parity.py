@@ -932,10 +932,9 @@ def test_icp_ties_go_to_the_target_stored_first(hip_lib, dtype):
 
 
 def test_icp_clouds_with_non_finite_points(hip_lib):
-    """NaN and infinite coordinates in either cloud: they do not shape the grid, are nobody's
-    nearest target, and such a source stays unmatched; everything else as without them.  (The
-    sums over a cloud whose SOURCES hold a non-finite coordinate are NaN, as the reference's would
-    be: the arithmetic of an unmatched source is masked by weight, not skipped.)"""
+    """NaN and infinite coordinates in either cloud (the invalid pixels of a depth image): such
+    a target does not shape the grid and is nobody's nearest; such a source is left out of the cost
+    — unmatched in matches(), absent from every sum; everything else as without them."""
     rng = np.random.default_rng(21)
     tgt = rng.random((3000, 3)) * np.array([8.0, 5.0, 3.0])
     src = tgt[rng.permutation(3000)[:2000]] + rng.normal(0, 0.02, (2000, 3))
@@ -957,12 +956,22 @@ def test_icp_clouds_with_non_finite_points(hip_lib):
     assert np.array_equal(np.isnan(got[:, 0]), np.isnan(want[:, 0]))
     ok = ~np.isnan(want[:, 0])
     assert np.array_equal(got[ok], want[ok]) and n == int(ok.sum())
-    assert np.isnan(cost.linearize(np.zeros(6), 0)[0]).all()
-    finite_sources = hip_lib.IcpCost(src, bad_t, max_dist)
-    assert finite_sources.update(np.zeros(6)) == n + 2 - int(np.isnan(_brute_force_matches(
-        src[[3, 10]], tgt[clean], np.zeros(6), max_dist)[:, 0]).sum())
-    H, b, c = finite_sources.linearize(np.zeros(6), 0)
-    assert np.isfinite(H).all() and np.isfinite(b).all() and np.isfinite(c) and c > 0
+    # the sums are those of the cloud without the two sources
+    keep = np.ones(len(src), dtype=bool)
+    keep[[3, 10]] = False
+    without = hip_lib.IcpCost(src[keep], bad_t, max_dist)
+    assert without.update(np.zeros(6)) == n
+    x = np.array([0.01, -0.02, 0.015, 0.002, -0.001, 0.003])
+    cost.update(x), without.update(x)
+    for mode in (0, 2):
+        got_sums, want_sums = cost.linearize(x, mode), without.linearize(x, mode)
+        assert np.isfinite(got_sums[0]).all() and got_sums[2] > 0
+        check(got_sums, want_sums)
+    assert abs(cost.compute_cost(x) - without.compute_cost(x)) <= REL * without.compute_cost(x)
+    # a cloud with no finite source at all: an empty cost
+    none = hip_lib.IcpCost(np.full((5, 3), np.nan), tgt, max_dist)
+    assert none.update(np.zeros(6)) == 0 and np.isnan(none.matches()).all()
+    assert not none.linearize(np.zeros(6), 0)[0].any()
 
 
 def test_icp_solve_with_gpu_correspondence_search(hip_lib, oracle):
