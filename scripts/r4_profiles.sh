@@ -25,5 +25,12 @@ python3 bench.py --mode numeric --variant literal --steps 100 --warmup 10 --no-c
 python3 bench.py --mode numeric --variant literal --n 1000000 --steps 100 --warmup 10 --no-cpu-baseline > $out/fd1m.json 2>/dev/null
 python3 bench.py --n 1000000 --steps 100 --warmup 10 --no-cpu-baseline > $out/an1m.json 2>/dev/null
 echo "== solve times"; ./tests/cpp/_build/bench_solve 1000 100000 1000000 10000000 > $out/solve.md 2>&1; cat $out/solve.md < /dev/null
-echo "== correspondence search"; python3 scripts/icp_timing.py 2>&1 | grep -v amdgpu.ids > $out/icp_timing.txt; cat $out/icp_timing.txt < /dev/null
+echo "== correspondence search"
+(python3 scripts/icp_timing.py; python3 scripts/icp_timing.py --dtype f32) 2>&1 | grep -v amdgpu.ids > $out/icp_timing.txt; cat $out/icp_timing.txt < /dev/null
+(for d in 1 2 4 8 16; do python3 scripts/icp_offsets_timing.py --per-cell $d --offsets 0,0.2,0.4,0.7,1.5 2>/dev/null; done
+ for d in 4 16; do MOPT_ICP_REACH=1 python3 scripts/icp_offsets_timing.py --per-cell $d --offsets 0,0.2,0.4,0.7,1.5 2>/dev/null; done) > $out/icp_density.txt
+(for k in 2 4 8 16; do python3 scripts/icp_offsets_timing.py --surface --radius-spacings $k --offsets 0,0.1,0.3,0.7 2>/dev/null; done
+ for k in 8 16; do MOPT_ICP_REACH=1 python3 scripts/icp_offsets_timing.py --surface --radius-spacings $k --offsets 0,0.1,0.3,0.7 2>/dev/null; done) > $out/icp_surface.txt
+python3 tests/tools/icp_lm_probe.py 2>&1 | grep -v "amdgpu.ids\|^[0-9]* dev" > $out/icp_solve.txt
+bash scripts/icp_pmc.sh r4 float64 > $out/icp_pmc.log 2>&1
 echo done
