@@ -839,7 +839,8 @@ def test_set_data_replaces_correspondences(hip_lib, oracle):
             assert abs(cost.compute_cost(x) - want) <= REL * want
 
 
-def _brute_force_matches(src, tgt, x, max_dist):
+def _se3(x):
+    """[R | t] of (t, omega) as so3.cpp:7-19,43-57 builds it."""
     T = np.eye(4)
     th = np.linalg.norm(x[3:])
     if th > 0:
@@ -847,6 +848,11 @@ def _brute_force_matches(src, tgt, x, max_dist):
         K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
         T[:3, :3] = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
     T[:3, 3] = x[:3]
+    return T
+
+
+def _brute_force_matches(src, tgt, x, max_dist):
+    T = _se3(x)
     w = src @ T[:3, :3].T + T[:3, 3]
     d2 = ((w[:, None, :] - tgt[None, :, :]) ** 2).sum(-1)
     j = d2.argmin(1)
@@ -929,6 +935,52 @@ def test_icp_ties_go_to_the_target_stored_first(hip_lib, dtype):
         assert n == int(ok.sum())
         cost.close()
     assert len(reaches) >= 2   # both the one-cell and the finer-cell walk have been through this
+
+
+@pytest.mark.parametrize("shape", ["volume", "surface"])
+def test_icp_search_is_exact_at_scale(hip_lib, shape):
+    """300 k x 300 k against a k-d tree (scipy), over radii from under one point spacing to many:
+    every grid resolution the build picks (one cell to the radius up to eight, the refinement by
+    occupied cells on a surface), both rounds of the search, sources inside, at the rim of and
+    outside the targets' box.  fp64: the same target for every source, or none for both."""
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(33)
+    n = 300_000
+    if shape == "volume":
+        tgt = rng.random((n, 3)) * 60.0
+        spacing = 60.0 / n ** (1.0 / 3.0)
+    else:
+        uv = rng.random((n, 2)) * 60.0
+        tgt = np.column_stack([uv, 6.0 * np.sin(uv[:, 0] / 6.0) * np.cos(uv[:, 1] / 9.0) + 30.0])
+        spacing = 60.0 / np.sqrt(n)
+    src = tgt[rng.permutation(n)] + rng.normal(0, 0.3 * spacing, (n, 3))
+    src[: n // 10] += rng.normal(0, 3.0 * spacing, (n // 10, 3))      # some far from their target
+    src[:1000] = rng.random((1000, 3)) * 80.0 - 10.0                    # some anywhere, also outside
+    tree = cKDTree(tgt)
+    x = np.array([0.2 * spacing, -0.1 * spacing, 0.15 * spacing, 0.001, -0.0005, 0.0008])
+    R = _se3(x)
+    warped = src @ R[:3, :3].T + R[:3, 3]
+    reaches = set()
+    for radius in (0.7 * spacing, 2.0 * spacing, 5.0 * spacing, 12.0 * spacing):
+        cost = hip_lib.IcpCost(src, tgt, radius)
+        reaches.add(cost.grid()[1])
+        n_matched = cost.update(x)
+        got = cost.matches()
+        dist, idx = tree.query(warped, k=1, distance_upper_bound=radius * (1 + 1e-12))
+        # (the library computes the warp with its own SE(3) arithmetic: a pair within rounding of the
+        # radius or of a tie may differ - none in these clouds beyond a handful)
+        miss_w = ~np.isfinite(dist)
+        miss_g = np.isnan(got[:, 0])
+        assert (miss_w != miss_g).sum() <= 3, (shape, radius)
+        both = ~miss_w & ~miss_g
+        differ = (got[both] != tgt[idx[both]]).any(1)
+        assert differ.sum() <= 3, (shape, radius, int(differ.sum()))
+        if differ.any():   # a differing pair must be a near-tie
+            d_got = np.linalg.norm(warped[both][differ] - got[both][differ], axis=1)
+            assert np.allclose(d_got, dist[both][differ], rtol=1e-9)
+        assert n_matched == int((~miss_g).sum())
+        cost.close()
+    assert len(reaches) >= 3, reaches
 
 
 def test_icp_clouds_with_non_finite_points(hip_lib):
