@@ -740,10 +740,12 @@ __global__ __launch_bounds__(kBlockThreads) void scalarModelResidentSetKernel(
 // One thread per source point: warp it with the current pose, look through the grid cells around
 // it — the 2 x 2 x 2 nearest first, the wave in lock step, then what of the (2 reach + 1)^3 block
 // the best so far still admits —, keep the nearest target within the maximum distance, and write
-// that target into the target planes of the point's slot (or the NaN marker).  The reference leaves this step to the user
-// model's update(x) (model.h:24-26; "setup can be i.e nearest neighboor search", docs/Cost.puml:14-17)
-// and ships no implementation, so semantics are defined here: exact nearest neighbour in the
-// Euclidean metric, ties resolved to the first candidate in (cell z, y, x; original index) order.
+// that target into the target planes of the point's slot (or the NaN marker).  The reference leaves
+// this step to the user model's update(x) (model.h:24-26; "setup can be i.e nearest neighboor
+// search", docs/Cost.puml:14-17) and ships no implementation, so semantics are defined here: exact
+// nearest neighbour in the Euclidean metric, ties resolved to the first candidate in (cell z, y, x;
+// original index) order.
+
 // candidates per lane and trip of the first round (4, 6 and 8 measure the same; 2 is slower)
 constexpr int kIcpTrip = 4;
 
