@@ -1222,9 +1222,8 @@ int commonCreate(mopt_cost *c, int device) {
                          size_t(c->max_grid) * kPartialRowSlots * sizeof(double)));
   MOPT_HIP_TRY(deviceAlloc(reinterpret_cast<void **>(&c->d_result), kResultSlots * sizeof(double)));
   // results (43) + padding + flag word in one mapped, coherent host allocation
-  MOPT_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_result),
-                             (kResultSlots + 16) * sizeof(double),
-                             hipHostMallocMapped | hipHostMallocCoherent));
+  MOPT_HIP_TRY(mappedHostAlloc(reinterpret_cast<void **>(&c->h_result),
+                               (kResultSlots + 16) * sizeof(double)));
   std::memset(c->h_result, 0, (kResultSlots + 16) * sizeof(double));
   c->h_flag = reinterpret_cast<unsigned long long *>(c->h_result + kResultSlots);
   MOPT_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->h_result_dev), c->h_result, 0));
@@ -1270,7 +1269,7 @@ void destroyCost(mopt_cost *c) {
   deviceRelease(c->d_tiles);
   deviceRelease(c->d_partials);
   deviceRelease(c->d_result);
-  if (c->h_result) (void)hipHostFree(c->h_result);
+  mappedHostRelease(c->device, c->h_result, (kResultSlots + 16) * sizeof(double));
   releaseStream(c->device, c->stream);  // synchronised at the top of this function
   delete c;
 }

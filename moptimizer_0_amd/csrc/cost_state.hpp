@@ -219,6 +219,9 @@ void releaseStream(int device, hipStream_t stream);
 // only after the work that used the block has completed.
 hipError_t deviceAlloc(void **out, size_t bytes);
 void deviceRelease(void *p);
+// mapped, coherent host blocks (a cost's published results), cached per device and size
+hipError_t mappedHostAlloc(void **out, size_t bytes);
+void mappedHostRelease(int device, void *p, size_t bytes);
 
 int commonCreate(mopt_cost *c, int device);  // device, stream, partial / result buffers
 // wait for everything enqueued for this cost, on its own stream and on callers' streams
@@ -262,12 +265,14 @@ int costAsyncImpl(mopt_cost *c, const void *x, double *d_sum, hipStream_t s,
 // H | b | sum_sq as doubles -> the caller's arrays in the cost's scalar type
 void storeResult(const mopt_cost *c, const double *res, void *hessian, void *b, void *sum_sq);
 
-struct DeviceScratch {  // hipFree on scope exit
+struct DeviceScratch {  // back to the device pool on scope exit (after whatever still uses it)
   void *p = nullptr;
   ~DeviceScratch() {
-    if (p) (void)hipFree(p);
+    if (!p) return;
+    (void)hipDeviceSynchronize();
+    deviceRelease(p);
   }
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+  hipError_t alloc(size_t bytes) { return deviceAlloc(&p, bytes ? bytes : 16); }
   template <typename T>
   T *as() const { return static_cast<T *>(p); }
 };

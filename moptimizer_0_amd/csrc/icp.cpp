@@ -265,7 +265,7 @@ int mopt_icp_get_matches(mopt_cost *c, void *tgt_out_xyz) {
   if (c->count == 0) return MOPT_OK;
   const size_t bytes = size_t(c->count) * 3 * c->scalar_bytes;
   void *d_tmp = nullptr;
-  MOPT_HIP_TRY(hipMalloc(&d_tmp, bytes));
+  MOPT_HIP_TRY(deviceAlloc(&d_tmp, bytes));
   hipError_t e = c->scalar_bytes == 8
                      ? mopt::launchGatherTargets<double>(static_cast<const double *>(c->d_tiles),
                                                          c->count, static_cast<double *>(d_tmp), c->stream)
@@ -275,8 +275,9 @@ int mopt_icp_get_matches(mopt_cost *c, void *tgt_out_xyz) {
   std::vector<unsigned char> staged(permuted ? bytes : 0);
   void *host_dst = permuted ? static_cast<void *>(staged.data()) : tgt_out_xyz;
   if (e == hipSuccess) e = hipMemcpyAsync(host_dst, d_tmp, bytes, hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  (void)hipFree(d_tmp);
+  const hipError_t synced = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) e = synced;
+  deviceRelease(d_tmp);
   if (e != hipSuccess) return fail(MOPT_ERR_HIP, std::string("gather: ") + hipGetErrorString(e));
   if (permuted) {  // slot k holds the caller's source order[k]
     const size_t triple = size_t(3) * c->scalar_bytes;

@@ -17,6 +17,11 @@
 
 #include "sweep.hpp"
 
+namespace mopt_detail {  // the size-class cache in front of hipMalloc / hipFree (device_pool.cpp):
+hipError_t deviceAlloc(void **out, size_t bytes);  // a grid is built per cloud pair, and hipFree
+void deviceRelease(void *p);                       // synchronises the device every time
+}  // namespace mopt_detail
+
 namespace mopt {
 namespace {
 
@@ -275,7 +280,7 @@ hipError_t icpBoundingBox(const S *d_xyz, long long m, double lo[3], double hi[3
   if (m <= 0) return hipSuccess;
   const int grid = blocksFor(m) < kBoxBlocks ? blocksFor(m) : kBoxBlocks;
   double *d_part = nullptr;
-  hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_part), size_t(grid) * 6 * sizeof(double));
+  hipError_t e = mopt_detail::deviceAlloc(reinterpret_cast<void **>(&d_part), size_t(grid) * 6 * sizeof(double));
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(boundingBoxKernel<S>, dim3(grid), dim3(kBlockThreads), 0, stream, d_xyz, m,
                      d_part);
@@ -284,8 +289,9 @@ hipError_t icpBoundingBox(const S *d_xyz, long long m, double lo[3], double hi[3
   if (e == hipSuccess)
     e = hipMemcpyAsync(part.data(), d_part, part.size() * sizeof(double), hipMemcpyDeviceToHost,
                        stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(stream);
-  (void)hipFree(d_part);
+  const hipError_t synced = hipStreamSynchronize(stream);  // (also before the block goes back)
+  if (e == hipSuccess) e = synced;
+  mopt_detail::deviceRelease(d_part);
   if (e != hipSuccess) return e;
   for (int a = 0; a < 3; ++a) {
     lo[a] = part[a];
@@ -329,20 +335,22 @@ hipError_t icpSortByCell(const S *d_xyz, long long m, const double origin[3], do
   unsigned int *keys = nullptr, *keys_alt = nullptr, *hist = nullptr, *tile_totals = nullptr;
   int *values_alt = nullptr;
   auto release = [&]() {
-    if (keys) (void)hipFree(keys);
-    if (keys_alt) (void)hipFree(keys_alt);
-    if (values_alt) (void)hipFree(values_alt);
-    if (hist) (void)hipFree(hist);
-    if (tile_totals) (void)hipFree(tile_totals);
+    (void)hipStreamSynchronize(stream);  // nothing queued may still use a block that goes back
+    mopt_detail::deviceRelease(keys);
+    mopt_detail::deviceRelease(keys_alt);
+    mopt_detail::deviceRelease(values_alt);
+    mopt_detail::deviceRelease(hist);
+    mopt_detail::deviceRelease(tile_totals);
   };
-  hipError_t e = hipMalloc(reinterpret_cast<void **>(&keys), size_t(m) * sizeof(unsigned int));
+  hipError_t e = mopt_detail::deviceAlloc(reinterpret_cast<void **>(&keys), size_t(m) * sizeof(unsigned int));
   if (e == hipSuccess)
-    e = hipMalloc(reinterpret_cast<void **>(&keys_alt), size_t(m) * sizeof(unsigned int));
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&values_alt), size_t(m) * sizeof(int));
+    e = mopt_detail::deviceAlloc(reinterpret_cast<void **>(&keys_alt), size_t(m) * sizeof(unsigned int));
   if (e == hipSuccess)
-    e = hipMalloc(reinterpret_cast<void **>(&hist), size_t(table) * sizeof(unsigned int));
+    e = mopt_detail::deviceAlloc(reinterpret_cast<void **>(&values_alt), size_t(m) * sizeof(int));
   if (e == hipSuccess)
-    e = hipMalloc(reinterpret_cast<void **>(&tile_totals), size_t(scan_tiles) * sizeof(unsigned int));
+    e = mopt_detail::deviceAlloc(reinterpret_cast<void **>(&hist), size_t(table) * sizeof(unsigned int));
+  if (e == hipSuccess)
+    e = mopt_detail::deviceAlloc(reinterpret_cast<void **>(&tile_totals), size_t(scan_tiles) * sizeof(unsigned int));
   if (e != hipSuccess) {
     release();
     return e;
@@ -379,7 +387,7 @@ hipError_t icpSortByCell(const S *d_xyz, long long m, const double origin[3], do
   }
   long long *d_parked = nullptr;
   if (e == hipSuccess && num_parked) {
-    e = hipMalloc(reinterpret_cast<void **>(&d_parked), sizeof(long long));
+    e = mopt_detail::deviceAlloc(reinterpret_cast<void **>(&d_parked), sizeof(long long));
     if (e == hipSuccess) {
       hipLaunchKernelGGL(countParkedKernel, dim3(1), dim3(1), 0, stream, keys_sorted, m,
                          (unsigned int)ncells, d_parked);
@@ -387,7 +395,7 @@ hipError_t icpSortByCell(const S *d_xyz, long long m, const double origin[3], do
     }
   }
   if (e == hipSuccess) e = hipStreamSynchronize(stream);  // the scratch arrays die here
-  if (d_parked) (void)hipFree(d_parked);
+  mopt_detail::deviceRelease(d_parked);
   release();
   return e;
 }
@@ -422,7 +430,7 @@ hipError_t icpCountOccupiedCells(const int *d_cell_start, long long ncells, long
   if (ncells <= 0) return hipSuccess;
   const unsigned blocks = unsigned((ncells + kBlockThreads - 1) / kBlockThreads);
   unsigned int *d_counts = nullptr;
-  hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_counts), size_t(blocks) * sizeof(unsigned int));
+  hipError_t e = mopt_detail::deviceAlloc(reinterpret_cast<void **>(&d_counts), size_t(blocks) * sizeof(unsigned int));
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(occupiedCellsKernel, dim3(blocks), dim3(kBlockThreads), 0, stream, d_cell_start,
                      ncells, d_counts);
@@ -431,8 +439,9 @@ hipError_t icpCountOccupiedCells(const int *d_cell_start, long long ncells, long
   if (e == hipSuccess)
     e = hipMemcpyAsync(counts.data(), d_counts, size_t(blocks) * sizeof(unsigned int),
                        hipMemcpyDeviceToHost, stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(stream);
-  (void)hipFree(d_counts);
+  const hipError_t synced = hipStreamSynchronize(stream);
+  if (e == hipSuccess) e = synced;
+  mopt_detail::deviceRelease(d_counts);
   if (e != hipSuccess) return e;
   for (unsigned int v : counts) *occupied += v;
   return hipSuccess;
