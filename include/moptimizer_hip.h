@@ -174,6 +174,12 @@ MOPT_API int mopt_point2point_set_data(mopt_cost *cost, const void *src_xyz, con
 MOPT_API int mopt_icp_create(mopt_cost **out, int device, int scalar_bytes, const void *src_xyz,
                              int64_t num_src, const void *tgt_xyz, int64_t num_tgt,
                              double max_distance);
+/* The same with creation flags: MOPT_INPUT_DEVICE takes both clouds from device memory on `device`
+ * (complete when the call is made: synchronise the stream that produced them) — a registration
+ * pipeline that keeps its scans on the GPU builds a cost without PCIe traffic. */
+MOPT_API int mopt_icp_create_from(mopt_cost **out, int device, int scalar_bytes, const void *src_xyz,
+                                  int64_t num_src, const void *tgt_xyz, int64_t num_tgt,
+                                  double max_distance, unsigned flags /* mopt_create_flags */);
 MOPT_API int mopt_icp_update(mopt_cost *cost, const void *x, int64_t *num_matched /* may be NULL */);
 /* current target of every source as packed xyz (NaN triple where unmatched), in the order of the
  * array handed to mopt_icp_create; host buffer of num_src * 3 scalars.  Works for any point2point

@@ -72,6 +72,8 @@ def load():
                                       ctypes.c_int64, ctypes.c_uint],
         "mopt_icp_create": [c_void_pp, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64,
                             ctypes.c_void_p, ctypes.c_int64, ctypes.c_double],
+        "mopt_icp_create_from": [c_void_pp, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64,
+                                 ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.c_uint],
         "mopt_icp_update": [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)],
         "mopt_icp_get_matches": [ctypes.c_void_p, ctypes.c_void_p],
         "mopt_icp_grid": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double),
@@ -448,9 +450,24 @@ class IcpCost(Point2PointCost):
     model's update step (nearest target of the warped source within max_distance)."""
 
     def __init__(self, src, tgt, max_distance, device=0, dtype=np.float64):
+        """src, tgt: host arrays (n, 3), or — both — contiguous torch tensors on `device`, taken from
+        device memory (mopt_icp_create_from with MOPT_INPUT_DEVICE; their stream is synchronised)."""
         _CostBase.__init__(self)
-        self.scalar_bytes = np.dtype(dtype).itemsize
         self.n_out = 3
+        if hasattr(src, "data_ptr") and hasattr(tgt, "data_ptr"):
+            import torch
+            assert src.is_cuda and tgt.is_cuda and src.dtype == tgt.dtype
+            assert src.is_contiguous() and tgt.is_contiguous()
+            self.scalar_bytes = src.element_size()
+            torch.cuda.synchronize(src.device)
+            n_src, n_tgt = src.numel() // 3, tgt.numel() // 3
+            check(load().mopt_icp_create_from(ctypes.byref(self._h), src.device.index or 0,
+                                              self.scalar_bytes, ctypes.c_void_p(src.data_ptr()), n_src,
+                                              ctypes.c_void_p(tgt.data_ptr()), n_tgt, float(max_distance),
+                                              1))
+            self.count = n_src
+            return
+        self.scalar_bytes = np.dtype(dtype).itemsize
         src = np.ascontiguousarray(src, dtype=dtype).reshape(-1, 3)
         tgt = np.ascontiguousarray(tgt, dtype=dtype).reshape(-1, 3)
         check(load().mopt_icp_create(ctypes.byref(self._h), device, self.scalar_bytes, _ptr(src),

@@ -18,7 +18,7 @@ namespace {
 // order (packed xyz) and matcher->order the original index of each.
 template <typename S>
 int buildIcpGrid(const S *src, long long n, const S *tgt, long long m, double max_distance,
-                 hipStream_t s, std::unique_ptr<IcpMatcher> &out_matcher,
+                 unsigned flags, hipStream_t s, std::unique_ptr<IcpMatcher> &out_matcher,
                  DeviceScratch &d_src_sorted) {
   auto mt = std::make_unique<IcpMatcher>();
   mt->max_dist = max_distance;
@@ -26,10 +26,11 @@ int buildIcpGrid(const S *src, long long n, const S *tgt, long long m, double ma
   DeviceScratch d_tgt, d_src, d_perm_t, d_perm_s;
   MOPT_HIP_TRY(d_tgt.alloc(size_t(m) * 3 * sizeof(S)));
   MOPT_HIP_TRY(d_src.alloc(size_t(n) * 3 * sizeof(S)));
-  if (m > 0)
-    MOPT_HIP_TRY(hipMemcpyAsync(d_tgt.p, tgt, size_t(m) * 3 * sizeof(S), hipMemcpyHostToDevice, s));
-  if (n > 0)
-    MOPT_HIP_TRY(hipMemcpyAsync(d_src.p, src, size_t(n) * 3 * sizeof(S), hipMemcpyHostToDevice, s));
+  // (clouds already in device memory are copied too: 24 B a point at HBM speed, and the caller's
+  // arrays are free again when this returns, as with host arrays)
+  const hipMemcpyKind kind = (flags & MOPT_INPUT_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  if (m > 0) MOPT_HIP_TRY(hipMemcpyAsync(d_tgt.p, tgt, size_t(m) * 3 * sizeof(S), kind, s));
+  if (n > 0) MOPT_HIP_TRY(hipMemcpyAsync(d_src.p, src, size_t(n) * 3 * sizeof(S), kind, s));
   double lo[3], hi[3];
   MOPT_HIP_TRY(mopt::icpBoundingBox<S>(d_tgt.as<S>(), m, lo, hi, s));
   // Cell edge: a hair above the search radius over `reach`, so that the (2 reach + 1)^3 cells around
@@ -178,6 +179,13 @@ extern "C" {
 
 int mopt_icp_create(mopt_cost **out, int device, int scalar_bytes, const void *src_xyz,
                     int64_t num_src, const void *tgt_xyz, int64_t num_tgt, double max_distance) {
+  return mopt_icp_create_from(out, device, scalar_bytes, src_xyz, num_src, tgt_xyz, num_tgt,
+                              max_distance, MOPT_INPUT_HOST);
+}
+
+int mopt_icp_create_from(mopt_cost **out, int device, int scalar_bytes, const void *src_xyz,
+                         int64_t num_src, const void *tgt_xyz, int64_t num_tgt, double max_distance,
+                         unsigned flags) {
   if (!out) return fail(MOPT_ERR_INVALID_ARGUMENT, "out is NULL");
   *out = nullptr;
   if (num_src < 0 || num_tgt < 0 || (num_src > 0 && !src_xyz) || (num_tgt > 0 && !tgt_xyz) ||
@@ -202,10 +210,10 @@ int mopt_icp_create(mopt_cost **out, int device, int scalar_bytes, const void *s
   int rc = scalar_bytes == 8
                ? buildIcpGrid<double>(static_cast<const double *>(src_xyz), num_src,
                                       static_cast<const double *>(tgt_xyz), num_tgt, max_distance,
-                                      build_stream, matcher, d_src_sorted)
+                                      flags, build_stream, matcher, d_src_sorted)
                : buildIcpGrid<float>(static_cast<const float *>(src_xyz), num_src,
                                      static_cast<const float *>(tgt_xyz), num_tgt, max_distance,
-                                     build_stream, matcher, d_src_sorted);
+                                     flags, build_stream, matcher, d_src_sorted);
   (void)hipStreamSynchronize(build_stream);
   releaseStream(device, build_stream);
   // the sources go into the resident tiles in cell order; the target planes are filled by the

@@ -88,11 +88,13 @@ def test_round2_entry_points_validate_their_arguments_without_a_device():
     assert lib.mopt_costs_link(None, 2) == 1 and lib.mopt_costs_link(None, 0) == 0
     assert lib.mopt_cost_link_stats(None, None) == 1
     assert lib.mopt_icp_grid(None, None, None, None, None) == 1   # not an ICP cost
+    assert lib.mopt_icp_create_from(None, 0, 8, None, 0, None, 0, 1.0, 1) == 1
     x = np.array([0.1, 0.2, 0.3, 0.0, 0.0, 0.0])
     out = mo.capi.se3_plus(x, np.array([1.0, 2.0, 3.0, 0.0, 0.0, 0.0]))  # pure translation adds
     assert np.allclose(out, [1.1, 2.2, 3.3, 0, 0, 0], atol=1e-15)
     names = declared_functions()
     for required in ("mopt_lm_minimize", "mopt_cost_hostcomm_attach", "mopt_cost_peer_export",
                      "mopt_cost_peer_attach", "mopt_cost_set_combine", "mopt_se3_plus",
-                     "mopt_se3_from_params", "mopt_costs_link", "mopt_cost_link_stats", "mopt_icp_grid"):
+                     "mopt_se3_from_params", "mopt_costs_link", "mopt_cost_link_stats", "mopt_icp_grid",
+                     "mopt_icp_create_from"):
         assert required in names

@@ -983,6 +983,29 @@ def test_icp_search_is_exact_at_scale(hip_lib, shape):
     assert len(reaches) >= 3, reaches
 
 
+def test_icp_cost_from_clouds_in_device_memory(hip_lib):
+    """mopt_icp_create_from with MOPT_INPUT_DEVICE: the clouds are torch tensors on the GPU; the cost
+    is the one built from the same clouds in host memory (matches, sums), and the tensors are the
+    caller's again when the constructor returns."""
+    import torch
+    rng = np.random.default_rng(44)
+    tgt = rng.random((20_000, 3)) * 10.0
+    src = tgt[rng.permutation(20_000)[:15_000]] + rng.normal(0, 0.01, (15_000, 3))
+    for dtype, tdtype in ((np.float64, torch.float64), (np.float32, torch.float32)):
+        host = hip_lib.IcpCost(src, tgt, 0.3, dtype=dtype)
+        d_src = torch.tensor(src, dtype=tdtype, device="cuda:0")
+        d_tgt = torch.tensor(tgt, dtype=tdtype, device="cuda:0")
+        dev = hip_lib.IcpCost(d_src, d_tgt, 0.3)
+        d_src.zero_(), d_tgt.zero_()          # the cost holds its own copy
+        torch.cuda.synchronize()
+        x = np.array([0.02, -0.01, 0.015, 0.003, -0.002, 0.001]).astype(dtype)
+        assert dev.update(x) == host.update(x) > 14_000
+        assert np.array_equal(dev.matches(), host.matches(), equal_nan=True)
+        a, b = dev.linearize(x, 2), host.linearize(x, 2)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+        dev.close(), host.close()
+
+
 def test_icp_clouds_with_non_finite_points(hip_lib):
     """NaN and infinite coordinates in either cloud (the invalid pixels of a depth image): such
     a target does not shape the grid and is nobody's nearest; such a source is left out of the cost
