@@ -1263,6 +1263,7 @@ void destroyCost(mopt_cost *c) {
     deviceRelease(c->matcher->d_sorted);
     deviceRelease(c->matcher->d_cell_start);
     deviceRelease(c->matcher->d_matched);
+    deviceRelease(c->matcher->d_order);
   }
   mopt::jitRelease(c->jit);
   releaseResident(c);

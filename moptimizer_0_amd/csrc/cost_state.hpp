@@ -68,8 +68,10 @@ struct IcpMatcher {
   double max_dist = 0.0;
   long long num_targets = 0;
   // Sources are stored in grid-cell order (of their un-warped position) so that neighbouring
-  // lanes visit neighbouring cells; slot k of the tiles holds the caller's source order[k].
-  std::vector<long long> order;
+  // lanes visit neighbouring cells; slot k of the tiles holds the caller's source d_order[k]
+  // (device memory, `kept` entries: the sources with finite coordinates).
+  int *d_order = nullptr;
+  long long kept = 0;
 };
 
 // How the sums of a sharded cost are added over the ranks (MOPT_COMBINE_* of the header).

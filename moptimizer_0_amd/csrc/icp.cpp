@@ -15,7 +15,7 @@ using namespace mopt_detail;
 namespace {
 // Grid over the targets and cell-ordered copy of the sources, built on the device (icp_grid.hip);
 // the host only chooses the resolution.  On return `d_src_sorted` holds the n sources in cell
-// order (packed xyz) and matcher->order the original index of each.
+// order (packed xyz) and matcher->d_order (device memory) the original index of each.
 template <typename S>
 int buildIcpGrid(const S *src, long long n, const S *tgt, long long m, double max_distance,
                  unsigned flags, hipStream_t s, std::unique_ptr<IcpMatcher> &out_matcher,
@@ -113,12 +113,10 @@ int buildIcpGrid(const S *src, long long n, const S *tgt, long long m, double ma
   MOPT_HIP_TRY(d_src_sorted.alloc(size_t(kept) * 3 * sizeof(S)));
   MOPT_HIP_TRY(mopt::icpGatherPoints<S>(d_src.as<S>(), d_perm_s.as<int>(), kept, d_src_sorted.as<S>(),
                                         false, s));
-  std::vector<int> perm(static_cast<size_t>(kept));
-  if (kept > 0)
-    MOPT_HIP_TRY(hipMemcpyAsync(perm.data(), d_perm_s.p, size_t(kept) * sizeof(int),
-                                hipMemcpyDeviceToHost, s));
   MOPT_HIP_TRY(hipStreamSynchronize(s));
-  g.order.assign(perm.begin(), perm.end());
+  g.d_order = d_perm_s.as<int>();  // the matcher keeps the order (its first `kept` entries) on the device
+  d_perm_s.p = nullptr;
+  g.kept = kept;
   return MOPT_OK;
 }
 
@@ -203,6 +201,7 @@ int mopt_icp_create_from(mopt_cost **out, int device, int scalar_bytes, const vo
     deviceRelease(matcher->d_sorted);
     deviceRelease(matcher->d_cell_start);
     deviceRelease(matcher->d_matched);
+    deviceRelease(matcher->d_order);
   };
   hipStream_t build_stream = nullptr;
   MOPT_HIP_TRY(acquireStream(device, &build_stream));
@@ -221,7 +220,7 @@ int mopt_icp_create_from(mopt_cost **out, int device, int scalar_bytes, const vo
   mopt_cost *raw = nullptr;
   if (rc == MOPT_OK)
     rc = mopt_point2point_create(&raw, device, scalar_bytes, d_src_sorted.p, d_src_sorted.p,
-                                 int64_t(matcher->order.size()), MOPT_INPUT_DEVICE);
+                                 int64_t(matcher->kept), MOPT_INPUT_DEVICE);
   if (rc != MOPT_OK) {
     freeMatcher();
     return rc;
@@ -261,38 +260,27 @@ int mopt_icp_get_matches(mopt_cost *c, void *tgt_out_xyz) {
   if (!c || !tgt_out_xyz) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
   if (c->model != kModelPoint2Point) return fail(MOPT_ERR_INVALID_ARGUMENT, "not a point2point cost");
   MOPT_HIP_TRY(hipSetDevice(c->device));
-  // sources an ICP cost left out (non-finite coordinates) have no target: NaN triples for them
-  if (c->matcher && c->matcher->num_sources > c->count) {
-    const double nan8 = std::numeric_limits<double>::quiet_NaN();
-    const float nan4 = std::numeric_limits<float>::quiet_NaN();
-    for (size_t k = 0; k < size_t(c->matcher->num_sources) * 3; ++k) {
-      if (c->scalar_bytes == 8) static_cast<double *>(tgt_out_xyz)[k] = nan8;
-      else static_cast<float *>(tgt_out_xyz)[k] = nan4;
-    }
-  }
-  if (c->count == 0) return MOPT_OK;
-  const size_t bytes = size_t(c->count) * 3 * c->scalar_bytes;
+  // An ICP cost keeps its sources in cell order and leaves out those with non-finite coordinates:
+  // the triples go to the caller's positions on the device (NaN — all bits set — where nothing is
+  // written), then one copy.
+  const int *order = c->matcher ? c->matcher->d_order : nullptr;
+  const long long rows = c->matcher ? c->matcher->num_sources : c->count;
+  if (rows == 0) return MOPT_OK;
+  const size_t bytes = size_t(rows) * 3 * c->scalar_bytes;
   void *d_tmp = nullptr;
   MOPT_HIP_TRY(deviceAlloc(&d_tmp, bytes));
-  hipError_t e = c->scalar_bytes == 8
-                     ? mopt::launchGatherTargets<double>(static_cast<const double *>(c->d_tiles),
-                                                         c->count, static_cast<double *>(d_tmp), c->stream)
-                     : mopt::launchGatherTargets<float>(static_cast<const float *>(c->d_tiles),
-                                                        c->count, static_cast<float *>(d_tmp), c->stream);
-  const bool permuted = c->matcher && !c->matcher->order.empty();
-  std::vector<unsigned char> staged(permuted ? bytes : 0);
-  void *host_dst = permuted ? static_cast<void *>(staged.data()) : tgt_out_xyz;
-  if (e == hipSuccess) e = hipMemcpyAsync(host_dst, d_tmp, bytes, hipMemcpyDeviceToHost, c->stream);
+  hipError_t e = order ? hipMemsetAsync(d_tmp, 0xff, bytes, c->stream) : hipSuccess;
+  if (e == hipSuccess)
+    e = c->scalar_bytes == 8
+            ? mopt::launchGatherTargets<double>(static_cast<const double *>(c->d_tiles), c->count, order,
+                                                static_cast<double *>(d_tmp), c->stream)
+            : mopt::launchGatherTargets<float>(static_cast<const float *>(c->d_tiles), c->count, order,
+                                               static_cast<float *>(d_tmp), c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(tgt_out_xyz, d_tmp, bytes, hipMemcpyDeviceToHost, c->stream);
   const hipError_t synced = hipStreamSynchronize(c->stream);
   if (e == hipSuccess) e = synced;
   deviceRelease(d_tmp);
   if (e != hipSuccess) return fail(MOPT_ERR_HIP, std::string("gather: ") + hipGetErrorString(e));
-  if (permuted) {  // slot k holds the caller's source order[k]
-    const size_t triple = size_t(3) * c->scalar_bytes;
-    for (long long k = 0; k < c->count; ++k)
-      std::memcpy(static_cast<unsigned char *>(tgt_out_xyz) + size_t(c->matcher->order[size_t(k)]) * triple,
-                  staged.data() + size_t(k) * triple, triple);
-  }
   return MOPT_OK;
 }
 

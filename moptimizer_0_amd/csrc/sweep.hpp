@@ -355,7 +355,8 @@ hipError_t launchIcpMatchResident(const IcpMatchArgs<S> &args, const P2PSweepArg
                                   const LmControl *control, hipStream_t stream);
 // target planes of the tile layout -> packed xyz (NaN where unmatched); for inspection / tests
 template <typename S>
-hipError_t launchGatherTargets(const S *tiles, long long count, S *out_xyz, hipStream_t stream);
+hipError_t launchGatherTargets(const S *tiles, long long count, const int *order /* or NULL */,
+                               S *out_xyz, hipStream_t stream);
 
 // Grid construction for the search (icp_grid.hip).  All pointers are device memory.
 //   icpBoundingBox   min / max of m packed points (synchronises the stream)

@@ -994,15 +994,18 @@ __global__ __launch_bounds__(kBlockThreads) void icpMatchResidentKernel(
   icpMatchBody<S, TRIP>(A, T);
 }
 
+// the target of slot i as a packed triple: to position i, or to position order[i] (the caller's
+// index of the source in that slot: an ICP cost keeps its sources in cell order)
 template <typename S>
 __global__ void gatherTargetsKernel(const S *__restrict__ tiles, long long count,
-                                    S *__restrict__ out_xyz) {
+                                    const int *__restrict__ order, S *__restrict__ out_xyz) {
   constexpr int TP = TileShape<S>::kPoints;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   const S *slot = tiles + (i / TP) * TileShape<S>::kP2PScalars + (i % TP);
+  const long long to = order ? order[i] : i;
 #pragma unroll
-  for (int k = 0; k < 3; ++k) out_xyz[3 * i + k] = slot[(3 + k) * TP];
+  for (int k = 0; k < 3; ++k) out_xyz[3 * to + k] = slot[(3 + k) * TP];
 }
 
 // ---- layout conversion (once per data set) -----------------------------------------------------
@@ -1713,15 +1716,18 @@ template hipError_t launchIcpMatchResident<double>(const IcpMatchArgs<double> &,
                                                    hipStream_t);
 
 template <typename S>
-hipError_t launchGatherTargets(const S *tiles, long long count, S *out_xyz, hipStream_t stream) {
+hipError_t launchGatherTargets(const S *tiles, long long count, const int *order, S *out_xyz,
+                               hipStream_t stream) {
   if (count == 0) return hipSuccess;
   const unsigned blocks = unsigned((count + 255) / 256);
   hipLaunchKernelGGL((gatherTargetsKernel<S>), dim3(blocks), dim3(256), 0, stream, tiles, count,
-                     out_xyz);
+                     order, out_xyz);
   return hipGetLastError();
 }
-template hipError_t launchGatherTargets<float>(const float *, long long, float *, hipStream_t);
-template hipError_t launchGatherTargets<double>(const double *, long long, double *, hipStream_t);
+template hipError_t launchGatherTargets<float>(const float *, long long, const int *, float *,
+                                               hipStream_t);
+template hipError_t launchGatherTargets<double>(const double *, long long, const int *, double *,
+                                                hipStream_t);
 
 // matched sources of the correspondence search: the per-wave counts (icpMatchBody) added up and
 // handed to mapped host memory as one double — no memset launch, no copy, no stream synchronisation
