@@ -17,7 +17,18 @@ sweep really streams from HBM).  Per-GPU work is fixed as N grows ("weak" scalin
 children, before anything touches the GPU) and relays rank 0's line; under torch.distributed.run
 (WORLD_SIZE set) it is one of the ranks.  MOPT_BENCH_BACKEND=gloo rehearses N ranks on fewer GPUs.
 
+Timed region: settle | W warm-up steps | barrier + torch.cuda.synchronize() | t0 | K blocking steps |
+barrier + synchronize | t1.
+
 Prints ONE JSON line on rank 0 (contract in the task statement) including
+  timing       — the K individual step times of rank 0 (per_step_us, median, min, first)
+  check.vs_oracle — one GPU linearize over rank 0's shard against the CPU restatement's H, b, cost
+                 on the same correspondences (the sums the cpu_baseline sweeps compute anyway), bar 1e-6
+  configs      — N = 1: BASELINE configs 2, 3 (default and literal evaluation) and 5, timed the same way
+  timing       — the K individual step times of rank 0 (per_step_us, median, min, first)
+  check.vs_oracle — one GPU linearize over rank 0's shard against the CPU restatement's H, b, cost
+                 on the same correspondences (the sums the cpu_baseline sweeps compute anyway), bar 1e-6
+  configs      — N = 1: BASELINE configs 2, 3 (default and literal evaluation) and 5, timed the same way
   roofline     — achieved algorithmic GB/s of the dominant (sweep) kernel from HIP events that
                  carry the dispatch's own timestamps, taken in a pass of their own AFTER the K
                  timed wall-clock steps (which run uninstrumented), vs the 8 TB/s HBM3E peak
@@ -90,7 +101,12 @@ def parse_args():
                          "(0 = min(steps, 100); the K wall-clock steps run with profiling off)")
     ap.add_argument("--settle-ms", type=float, default=500.0,
                     help="untimed sweeps before the warm-up steps, about this many milliseconds")
+    ap.add_argument("--pause-after-sync-ms", type=float, default=0.0,
+                    help="host spin between the barrier + synchronise that precedes the timed steps and "
+                         "t0 (the runtime releases its queued commands after a synchronisation; 0 = none)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="N=1: skip the configs block (BASELINE configs 2, 3 and 5 timed after the headline)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--deadline-s", type=float,
@@ -127,16 +143,19 @@ def quiesce_python_gc():
 
 def cpu_baseline(src_host, tgt_host, x, jac_mode, target_seconds):
     """Single-threaded restatement of the reference's linearize (the reference loop is
-    single-threaded: linearization.h:97,142) on a bounded prefix of the same workload."""
+    single-threaded: linearization.h:97,142) on a bounded prefix of the same workload.  Returns the
+    baseline record and the oracle's own (H, b, sum) at x over that prefix — the timed sweeps compute
+    them anyway — for the line's check.vs_oracle."""
     from tests import oracle_binding as ob
     oracle = ob.load()
     cost_class = ob.NUMERIC_DYN if jac_mode == 2 else ob.ANALYTIC_DYN
     layout = ob.LAYOUT_TST if jac_mode == 1 else ob.LAYOUT_ROW_MAJOR
     sample = src_host.shape[0]
     sweeps, dt = 0, 0.0
+    sums = None
     t0 = time.perf_counter()
     while dt < target_seconds and sweeps < 1000:
-        oracle.p2p_linearize(src_host, tgt_host, x, cost_class=cost_class, layout=layout)
+        sums = oracle.p2p_linearize(src_host, tgt_host, x, cost_class=cost_class, layout=layout)
         sweeps += 1
         dt = time.perf_counter() - t0
     out = {
@@ -146,33 +165,49 @@ def cpu_baseline(src_host, tgt_host, x, jac_mode, target_seconds):
         "kind": "port",
         "sample": "%d sweeps over the first %d correspondences of rank 0's shard, %.1f s of CPU "
                   "work (single thread, as the reference's linearize loop)" % (sweeps, sample, dt),
+        # the reference builds -O3 -march=native (CMakeLists.txt:19-22); the checker's objects travel
+        # to a host other than the one that compiled them, hence a named micro-architecture level
+        "compiler": oracle.build_flags(),
     }
     # for orientation only: the same sweep split over every host core (the reference parallelises
-    # only its cost-only sweep, linearization.h:52)
+    # only its cost-only sweep, linearization.h:52); the median of three, since a 256-thread sweep
+    # of a few tens of milliseconds swings with thread start-up
     cores = os.cpu_count() or 1
-    t0 = time.perf_counter()
-    oracle.p2p_linearize(src_host, tgt_host, x, cost_class=cost_class, layout=layout, threads=cores)
-    dt = time.perf_counter() - t0
-    out["all_cores"] = {"value": sample / dt, "cores": cores}
-    return out
+    rates = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        oracle.p2p_linearize(src_host, tgt_host, x, cost_class=cost_class, layout=layout, threads=cores)
+        rates.append(sample / (time.perf_counter() - t0))
+    out["all_cores"] = {"value": sorted(rates)[1], "cores": cores, "of": "median of 3 sweeps",
+                        "min": min(rates), "max": max(rates)}
+    return out, sums
 
 
-def camera_main(args):
-    """BASELINE config 5 (latency-dominated: 4 MB of input): one step = the multi-objective
-    linearization of levenberg_marquadt_dyn.cpp:48-60 — linearize both costs, add H, b, cost on the
-    host."""
-    import moptimizer_0_amd as mo
-    from tests import datasets as ds
-    quiesce_python_gc()
+def vs_oracle(got, want, bar):
+    """check.vs_oracle: norm-wise distance of the GPU's H, b (max |d| / max |want|) and of the cost
+    from the CPU restatement's on the same correspondences at the same x."""
+    H, b, c = got
+    Hr, br, cr = want
+    Hr, br = np.asarray(Hr, dtype=np.float64), np.asarray(br, dtype=np.float64)
+    h_rel = float(np.abs(np.asarray(H, dtype=np.float64) - Hr).max() / np.abs(Hr).max())
+    b_rel = float(np.abs(np.asarray(b, dtype=np.float64) - br).max() / np.abs(br).max())
+    c_rel = float(abs(float(c) - float(cr)) / abs(float(cr)))
+    return {"H_rel": h_rel, "b_rel": b_rel, "cost_rel": c_rel, "bar": bar,
+            "ok": bool(max(h_rel, b_rel, c_rel) <= bar)}
+
+
+def camera_problem(mo, ds):
+    """BASELINE config 5: 100 000 reprojection elements as two costs (40 k + 60 k, the split of
+    tst/multiple_objectives.cpp:110-117), Geman-McClure(100) on each (tst/loss_function.cpp:31-32),
+    forward differences.  Returns the costs and step(k): the optimizer's loop over its costs
+    (levenberg_marquadt_dyn.cpp:48-60) through pre-bound calls and reused buffers, as the point2point
+    workload is measured: what is timed is the library, not allocations."""
     n, split = 100_000, 40_000
     pts, pix = ds.synthetic_camera(n, seed=17)
     costs = [mo.ReprojectionCost(pts[:split], pix[:split]), mo.ReprojectionCost(pts[split:], pix[split:])]
     for c in costs:
         c.set_loss(mo.LOSS_GEMAN_MCCLURE, 100.0)
     x = np.zeros(6)
-
-    # the optimizer's loop over its costs (levenberg_marquadt_dyn.cpp:48-60) through pre-bound calls and
-    # reused buffers, as the point2point workload does: what is timed is the library, not allocations
     bound = [c.bound_linearize(mo.JAC_NUMERIC) for c in costs]
     H, b = np.zeros((6, 6), order="F"), np.zeros(6)
 
@@ -189,6 +224,29 @@ def camera_main(args):
             y += sc[0]
         return H, b, y
 
+    def kernel_ms(steps):
+        """both costs' sweep kernels per step, from a pass of its own (a profiled launch carries two events)"""
+        for c in costs:
+            c.set_profiling(True)
+        for k in range(steps):
+            step(k)
+        prof = [c.profile() for c in costs]
+        for c in costs:
+            c.set_profiling(False)
+        return sum(p[0] for p in prof) / max(prof[0][1], 1)
+
+    return n, costs, step, kernel_ms
+
+
+def camera_main(args):
+    """BASELINE config 5 (latency-dominated: 4 MB of input): one step = the multi-objective
+    linearization of levenberg_marquadt_dyn.cpp:48-60 — linearize both costs, add H, b, cost on the
+    host."""
+    import moptimizer_0_amd as mo
+    from tests import datasets as ds
+    quiesce_python_gc()
+    n, costs, step, kernel_pass_ms = camera_problem(mo, ds)
+
     def timed():
         for k in range(args.warmup):
             step(k)
@@ -203,12 +261,7 @@ def camera_main(args):
     mo.capi.link_costs(costs)
     elapsed, (H, b, y) = timed()
     mo.capi.link_costs([])
-    for c in costs:  # kernel times from a separate pass: a profiled launch carries two events
-        c.set_profiling(True)
-    for k in range(args.steps):
-        step(k)
-    prof = [c.profile() for c in costs]
-    kernel_ms = sum(p[0] for p in prof) / max(prof[0][1], 1)  # both costs' sweeps per step
+    kernel_ms = kernel_pass_ms(args.steps)
     achieved = n * 40 / (kernel_ms * 1e-3) / 1e9
     print(json.dumps({
         "metric": "point-correspondences/sec per LM linearization sweep; % HBM peak",
@@ -450,23 +503,29 @@ def main():
         est_step_s = 20e-6 + n_per_rank * BYTES_PER_CORRESPONDENCE[scalar_bytes] / 6.0e12
         return min(20000, max(50, int(ms * 1e-3 / est_step_s)))
 
-    def timed_pass(the_cost, combine, steps, warmup, settle, via_torch=None):
+    def timed_pass(the_cost, combine, steps, warmup, settle, via_torch=None, mode=None, step_fn=None):
         """barrier | K blocking steps | barrier, wall clock, max over ranks.  Profiling is off.
+        Returns (elapsed, H, sum, stamps): stamps[k] is this rank's clock after step k - 1
+        (stamps[0] = t0), read between the steps — one clock read each, ~50 ns.
         A step that fails (a peer that never delivers ends in MOPT_ERR_PEER_TIMEOUT, not in a
         hang) does not take this rank out of the sequence of collectives: it stops stepping, goes
         through both barriers and the max-reduce like everybody else, and raises afterwards."""
         err = None
         call = x_in = H_out = b_out = s_out = None
+        mode = jac_mode if mode is None else mode
         try:
-            if combine is not None:
-                the_cost.set_combine(modes[combine])
-            call, x_in, H_out, b_out, s_out = the_cost.bound_linearize(jac_mode)
+            if step_fn is None:
+                if combine is not None:
+                    the_cost.set_combine(modes[combine])
+                call, x_in, H_out, b_out, s_out = the_cost.bound_linearize(mode)
         except Exception as e:  # noqa: BLE001
             err = e
 
         def step(k):
+            if step_fn is not None:
+                return step_fn(k)
             if via_torch is not None:
-                return via_torch.linearize(xs[k % 16], jac_mode)
+                return via_torch.linearize(xs[k % 16], mode)
             x_in[:] = xs[k % 16]
             call()  # blocking C-ABI call: kernels, the sum over the ranks, the 43 results on the host
             return H_out, b_out, s_out[0]
@@ -478,12 +537,26 @@ def main():
                     step(k)
             except Exception as e:  # noqa: BLE001
                 err = e
+        stamps = [0.0] * (steps + 1)
+        clock = time.perf_counter
         barrier()
-        t0 = time.perf_counter()
+        # The synchronisation that has to precede t0 is not free for the steps that follow it: it hands
+        # the HIP runtime a marker, and when that completes a thread of the runtime releases every command
+        # queued since the previous marker — with a thousand commands in the batch the launching thread
+        # runs 5-15 us per call slower for the next 0.3-1 ms (scripts/probe_sync_effect.py,
+        # profiles/r5_sync_effect.txt).  The library now bounds those batches itself (a stream query every
+        # 32 blocking sweeps, c_abi.cpp boundCommandBatch), which takes the transient out of the driver's
+        # 20 steps (profiles/r5_marker_bench_ab.txt); the optional host spin here (GPU idle, nothing
+        # queued) did the same and costs the first launch after an idle GPU +10 us — off by default.
+        until = clock() + args.pause_after_sync_ms * 1e-3
+        while clock() < until:
+            pass
+        t0 = stamps[0] = clock()
         if err is None:
             try:
                 for k in range(steps):
                     H, b, s = step(k)
+                    stamps[k + 1] = clock()
             except Exception as e:  # noqa: BLE001
                 err = e
         barrier()
@@ -494,7 +567,22 @@ def main():
             elapsed = float(tmax.item())
         if err is not None:
             raise err
-        return elapsed, np.array(H, dtype=np.float64), float(s)
+        return elapsed, np.array(H, dtype=np.float64), float(s), stamps
+
+    def step_times(stamps, elapsed_s=None):
+        """timing block of a pass: the K individual step times of this rank, in microseconds."""
+        us = [(b - a) * 1e6 for a, b in zip(stamps[:-1], stamps[1:])]
+        srt = sorted(us)
+        closing = None if elapsed_s is None else elapsed_s * 1e6 - (stamps[-1] - stamps[0]) * 1e6
+        return {"per_step_us": [round(v, 2) for v in us[:400]], "median": srt[len(srt) // 2],
+                "min": srt[0], "max": srt[-1], "mean_of_steps": sum(us) / len(us),
+                # the barrier + torch.cuda.synchronize() that closes the timed region (inside it, as the
+                # contract has it): the runtime queues a marker behind the last kernel and waits for it
+                "closing_barrier_us": closing,
+                "first": us[0], "pause_after_sync_ms": args.pause_after_sync_ms,
+                "what": "rank 0's clock read after every blocking step of the timed "
+                "region; ms_per_step is the mean over the region, barriers included; the host spins "
+                "pause_after_sync_ms between the synchronisation and t0 (GPU idle, nothing queued)"}
 
     # ---- the measurement: W warm-up steps, then exactly K timed steps, uninstrumented ----------
     # Untimed settling first: a GPU that has just been handed its data is not yet in its steady
@@ -537,7 +625,7 @@ def main():
     cost.set_profiling(False)
     settle = settle_steps(total // world, args.settle_ms)
     if world == 1:
-        elapsed, H, s = timed_pass(cost, None, args.steps, args.warmup, settle)
+        elapsed, H, s, stamps = timed_pass(cost, None, args.steps, args.warmup, settle)
     else:
         order = [collective] + [c for c in usable + ["torch"] if c != collective]
         res = None
@@ -549,12 +637,12 @@ def main():
             usable = [c for c in usable if c != name]
         if res is None:
             raise SystemExit("rank %d: no way of adding the ranks' sums worked" % rank)
-        elapsed, H, s = res
+        elapsed, H, s, stamps = res
 
     # ---- kernel time: a pass of its own, every launch carrying its dispatch timestamps ---------
-    def kernel_pass(the_cost, steps):
+    def kernel_pass(the_cost, steps, mode=None):
         the_cost.set_combine(mo.COMBINE_NONE)  # the kernel's duration does not involve the ranks
-        call, x_in, _, _, _ = the_cost.bound_linearize(jac_mode)
+        call, x_in, _, _, _ = the_cost.bound_linearize(jac_mode if mode is None else mode)
         for k in range(5):
             x_in[:] = xs[k % 16]
             call()
@@ -566,9 +654,60 @@ def main():
         the_cost.set_profiling(False)
         return ms / max(launches, 1), launches
 
+    def baseline_configs():
+        """BASELINE.json configs 2, 3 and 5, measured as the headline is (same timed_pass /
+        kernel_pass): 1 M correspondences fit the Infinity Cache, 100 k reprojection elements are
+        pure latency — step times, with the kernel's share beside them."""
+        out = {}
+        n1 = 1_000_000
+        c1, s1, t1 = make_cost(n1)
+        del s1, t1
+        settle1 = settle_steps(n1, 50.0)
+
+        def p2p(mode, kvariant):
+            c1.set_kernel_variant(kvariant)
+            el, _, ssq, st = timed_pass(c1, None, args.steps, args.warmup, settle1, mode=mode)
+            k_ms, _ = kernel_pass(c1, min(ksteps, 30), mode=mode)
+            ms = el / args.steps * 1e3
+            return {"ms_per_step": ms, "value": n1 / (ms * 1e-3), "kernel_ms": k_ms,
+                    "frac": n1 * bpc / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "step_frac": n1 * bpc / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "median_step_us": step_times(st)["median"], "check_sum_sq": ssq}
+
+        out["cfg2"] = dict(p2p(mo.JAC_ANALYTIC, mo.KERNEL_AUTO),
+                           workload="point2point analytical Jacobian, 1M correspondences")
+        out["cfg3"] = dict(p2p(mo.JAC_NUMERIC, mo.KERNEL_AUTO),
+                           workload="point2point numerical (finite-difference) Jacobian, 1M "
+                                    "correspondences, default evaluation (moments where they meet 1e-6)")
+        out["cfg3_literal"] = dict(p2p(mo.JAC_NUMERIC, mo.KERNEL_LITERAL),
+                                   workload="the same evaluated as the reference does: 7 residuals, "
+                                            "18 quotients per point")
+        c1.close()
+        n5, costs5, step5, kernel5 = camera_problem(mo, ds)
+        mo.capi.link_costs(costs5)
+        el, _, y5, st = timed_pass(None, None, args.steps, args.warmup, 500, step_fn=step5)
+        mo.capi.link_costs([])
+        k_ms = kernel5(min(ksteps, 30))
+        ms = el / args.steps * 1e3
+        out["cfg5"] = {"ms_per_step": ms, "value": n5 / (ms * 1e-3), "unit": "residual-blocks/s",
+                       "kernel_ms": k_ms, "median_step_us": step_times(st)["median"],
+                       "check_sum_sq": y5,
+                       "workload": "camera-calibration reprojection cost: 100000 elements as two "
+                                   "linked costs (40k + 60k), Geman-McClure(100), forward differences, "
+                                   "both linearized and summed per step; kernel_ms = both sweeps"}
+        for c in costs5:
+            c.close()
+        out["note"] = ("1 GPU, f64, each timed as the headline: settle | %d warm-up | barrier | %d "
+                       "blocking steps | barrier; kernel_ms from a pass of its own" % (args.warmup, args.steps))
+        return out
+
     progress["stage"] = "kernel-time pass"
     ksteps = args.kernel_steps if args.kernel_steps > 0 else min(args.steps, 100)
     kernel_ms, launches = kernel_pass(cost, ksteps)
+    # one untimed sweep of this rank's own shard (combine off) at the x the CPU baseline sweeps at:
+    # what check.vs_oracle compares with the oracle's sums
+    x_check = ds.X_GENERIC.astype(np_dtype)
+    own_sums = cost.linearize(x_check, jac_mode)
 
     ms_per_step = elapsed / args.steps * 1e3
     achieved = args.n * bpc / (kernel_ms * 1e-3) / 1e9
@@ -643,6 +782,7 @@ def main():
         },
         "pct_hbm_peak": 100.0 * achieved / HBM_PEAK_GBS,
         "check": {"sum_sq": float(s), "H00": float(H[0, 0])},
+        "timing": step_times(stamps, elapsed if world == 1 else None),
     })
     if world > 1:
         # Always present for N > 1, and impossible to miss: the headline above is complete on its own;
@@ -652,17 +792,58 @@ def main():
         # split did not all finish (set by the watchdog when it has to report the line as it stands).
         line["rccl_incomplete"] = False
         line["extras_incomplete"] = False
+        # north_star asks for the scaling THROUGH the RCCL all-reduce: whatever transport the headline
+        # `value` used (config.collective), the whole-job rate with the sums added by ncclAllReduce is
+        # this key — the same number as rccl.value — and null where RCCL could not be attached (ranks
+        # sharing a GPU) or its pass did not finish
+        line["value_rccl"] = None
     per = {}
     if world > 1:
         per[collective] = as_step_sees_it(ms_per_step)
         line["by_collective"] = per
         line["roofline"]["step_frac_by_collective"] = {collective: per[collective]["step_frac"]}
 
+    if world == 1 and args.variant == "auto" and args.mode != "analytic_tst":
+        # the same sweep evaluated literally (every residual and Jacobian entry per point, as the
+        # reference does) — a driver-timed number for that kernel too
+        cost.set_kernel_variant(mo.KERNEL_LITERAL)
+        literal_ms, _ = kernel_pass(cost, min(ksteps, 30))
+        cost.set_kernel_variant(variant)
+        line["roofline"]["literal_kernel_ms"] = literal_ms
+        line["roofline"]["literal_frac"] = args.n * bpc / (literal_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+
+    # ---- the other BASELINE configs that fit one GPU, driver-timed in the same line ------------
+    if (world == 1 and not args.no_configs and args.dtype == "f64" and args.cov == "identity"
+            and args.loss == "none"):
+        progress["stage"] = "configs 2, 3, 5"
+        line["configs"] = baseline_configs()
+
     # ---- CPU baseline: rank 0's host cores, every world size -----------------------------------
     progress["stage"] = "cpu baseline"
     if rank == 0:
-        line["cpu_baseline"] = (cpu_baseline(src_host, tgt_host, ds.X_GENERIC, jac_mode, args.cpu_seconds)
-                                if keep_host else None)
+        line["cpu_baseline"] = None
+        if keep_host:
+            line["cpu_baseline"], oracle_sums = cpu_baseline(src_host, tgt_host, ds.X_GENERIC, jac_mode,
+                                                             args.cpu_seconds)
+            # the oracle swept the first `head` correspondences of rank 0's shard at X_GENERIC; the GPU
+            # sums to compare are the same shard's, no combine (own_sums) — or, for a shard longer than
+            # the CPU sample, a cost over exactly that prefix
+            if head == args.n:
+                got = own_sums
+            else:
+                prefix = mo.Point2PointCost(src_host.astype(np_dtype), tgt_host.astype(np_dtype),
+                                            device=local_rank, dtype=np_dtype)
+                prefix.set_kernel_variant(variant)
+                got = prefix.linearize(x_check, jac_mode)
+                prefix.close()
+            if args.cov == "identity" and args.loss == "none":
+                bar = 1e-6 if args.dtype == "f64" else 5e-3
+                line["check"]["vs_oracle"] = dict(
+                    vs_oracle(got, oracle_sums, bar),
+                    what="H, b, sum of squares of one GPU linearize over rank 0's first %d "
+                         "correspondences at x = X_GENERIC (kernel variant %r, no combine) against the "
+                         "CPU restatement's (oracle/, linearization.h:126-158 / :65-124) on the same "
+                         "correspondences; norm-wise max |d| / max |want|" % (head, args.variant))
     if world > 1:
         dist.barrier()  # the others wait here, not inside a combine with a 5 s limit
     # From here on the watchdog reports the line as it stands instead of failing: the headline
@@ -691,6 +872,7 @@ def main():
             if collective == "rccl":
                 info.update(per["rccl"])
                 info["timed_pass"] = "the headline pass"
+                line["value_rccl"] = per["rccl"]["value"]
             else:
                 line["rccl_incomplete"] = True
                 r = guarded_pass(cost, "rccl", args.steps, args.warmup, min(settle, 200))
@@ -699,6 +881,7 @@ def main():
                 if r is not None:
                     per["rccl"] = as_step_sees_it(r[0] / args.steps * 1e3)
                     info.update(per["rccl"])
+                    line["value_rccl"] = per["rccl"]["value"]
                     info["check"] = {"sum_sq": r[2], "H00": float(r[1][0, 0])}
                 else:
                     info["failed_in_timed_pass"] = True
@@ -719,15 +902,6 @@ def main():
         line["roofline"]["step_frac_by_collective"] = {k: v["step_frac"] for k, v in per.items()}
         if "none" in per:
             line["ms_per_step_without_collective"] = per["none"]["ms_per_step"]
-    if world == 1 and args.variant == "auto" and args.mode != "analytic_tst":
-        # the same sweep evaluated literally (every residual and Jacobian entry per point, as the
-        # reference does) — a driver-timed number for that kernel too
-        cost.set_kernel_variant(mo.KERNEL_LITERAL)
-        literal_ms, _ = kernel_pass(cost, min(ksteps, 30))
-        cost.set_kernel_variant(variant)
-        line["roofline"]["literal_kernel_ms"] = literal_ms
-        line["roofline"]["literal_frac"] = args.n * bpc / (literal_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-
     if world > 1 and not args.no_compare and not args.total_n:
         # BASELINE config 4: 10 M correspondences IN TOTAL split over the ranks (strong scaling;
         # 60 MB per GPU at 8 ranks, Infinity-Cache resident, latency-bound)
@@ -751,6 +925,7 @@ def main():
             "total_correspondences": total4, "correspondences_per_gpu": hi - lo,
             "ms_per_step_by_collective": {k: v["ms_per_step"] for k, v in per4.items()},
             "by_collective": per4, "rccl": per4.get("rccl"),
+            "value_rccl": per4["rccl"]["value"] if "rccl" in per4 else None,
             "collective": best[1], "ms_per_step": best[0],
             "value": (total4 / (best[0] * 1e-3)) if best[0] else None,
             "unit": "correspondences/s", "scaling": "strong",

@@ -457,14 +457,22 @@ MOPT_API int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int 
 MOPT_API int mopt_cost_set_profiling(mopt_cost *cost, int enabled);
 MOPT_API int mopt_cost_profile(mopt_cost *cost, double *sweep_ms_total, int64_t *sweep_launches);
 
-/* ---- single-process multi-GPU group (RCCL) ------------------------------------------------- */
+/* ---- single-process multi-GPU group ------------------------------------------------------- */
 
-/* Shard `count` correspondences contiguously over `num_devices` GPUs of this node, one
- * mopt_cost per device, and combine the n*n + n + 1 partial sums of every sweep with one
- * ncclAllReduce(sum, fp64) over xGMI.  The blocking calls below have the semantics of
- * mopt_cost_linearize / mopt_cost_compute on the whole data set.  (A device list that names a GPU
- * more than once — several shards on one GPU, to rehearse the sharding on a smaller machine —
- * cannot form an RCCL communicator; its shard sums are added on the host in shard order.) */
+/* Shard `count` correspondences contiguously over `num_devices` GPUs of this node — device k
+ * holds [k count / G, (k + 1) count / G) — one mopt_cost and one host worker thread per device.
+ * Every sweep runs on all devices at once; its n*n + n + 1 partial sums per device are added
+ *   - by DEFAULT on the host, in shard order: each device's finalize kernel publishes its sums
+ *     into mapped host memory and the calling thread adds the G rows (344 bytes per device: the
+ *     exchange is latency, and this is the shortest path — no collective launch);
+ *   - with MOPT_GROUP_COLLECTIVE=rccl in the environment when the group is created, by one
+ *     ncclAllReduce(sum, fp64) over xGMI on each shard's stream (ncclCommInitAll over `devices`),
+ *     the result then read from device 0.  A device list that names a GPU more than once (several
+ *     shards on one GPU, to rehearse the sharding on a smaller machine) cannot form an RCCL
+ *     communicator and always takes the host sum.
+ * Both give the same sums up to the association of G fp64 terms.  The blocking calls below have
+ * the semantics of mopt_cost_linearize / mopt_cost_compute on the whole data set.  For one process
+ * per GPU (torch.distributed, MPI) use mopt_cost_set_combine on per-rank costs instead. */
 MOPT_API int mopt_group_point2point_create(mopt_group **out, const int *devices, int num_devices,
                                            int scalar_bytes, const void *src_xyz,
                                            const void *tgt_xyz, int64_t count);

@@ -609,6 +609,24 @@ int waitPublished(mopt_cost *c, unsigned long long sequence) {
   return MOPT_OK;
 }
 
+// The HIP runtime keeps every command it has queued on a stream alive until a marker behind it
+// completes; then a thread of the runtime walks the whole batch and releases it (ROCclr's submission
+// batch: a marker goes in at a synchronisation, a query, an event, or after
+// DEBUG_CLR_MAX_BATCH_SIZE = 1000 commands).  A loop of blocking sweeps queues two kernels per call
+// and never synchronises, so the releases come a thousand commands at a time, and for the ~0.5-1 ms
+// each takes the launching thread runs 10-15 us per call slower (allocator and lock traffic with the
+// releasing thread; scripts/probe_sync_effect.py: 40 against 24 us per step of two linked
+// reprojection costs for the ~20 steps after a hipStreamSynchronize, 30 against 20 us at 1 M
+// correspondences).  Handing the runtime a marker every few launches keeps the batches short: the
+// release then costs a few microseconds on the other thread, spread evenly.  The query is issued
+// after this call's kernels are queued, while they run; its status is not used.
+void boundCommandBatch(mopt_cost *c) {
+  static const int every = envInt("MOPT_MARKER_EVERY", 32);  // sweeps; a huge value switches it off
+  if (++c->launches_since_marker < every) return;
+  c->launches_since_marker = 0;
+  (void)hipStreamQuery(c->stream);
+}
+
 mopt::HostPublish nextPublish(mopt_cost *c, int offset) {
   mopt::HostPublish pub;
   pub.host_result = c->h_result_dev + offset;
@@ -679,6 +697,7 @@ int blockingSweep(mopt_cost *c, bool cost_only, int jac_mode, const void *x) {
                                   ncclSum, c->comm, c->stream));
       mopt::HostPublish pub = nextPublish(c, offset);
       MOPT_HIP_TRY(mopt::launchPublish(c->d_result + offset, count, pub, c->stream));
+      boundCommandBatch(c);
       return waitPublished(c, pub.sequence);
     }
     case MOPT_COMBINE_HOST: {
@@ -691,6 +710,7 @@ int blockingSweep(mopt_cost *c, bool cost_only, int jac_mode, const void *x) {
       pub.sequence = seq;
       int rc = launch(pub);
       if (rc != MOPT_OK) return rc;
+      boundCommandBatch(c);
       return waitAndSumHostSlots(c, seq, offset, count);
     }
     case MOPT_COMBINE_PEER: {
@@ -701,6 +721,7 @@ int blockingSweep(mopt_cost *c, bool cost_only, int jac_mode, const void *x) {
       int rc = launch(pub);
       c->launch_peers = nullptr;
       if (rc != MOPT_OK) return rc;
+      boundCommandBatch(c);
       rc = waitPublished(c, pub.sequence);
       if (rc != MOPT_OK) return rc;
       if (__atomic_load_n(c->h_flag + 1, __ATOMIC_ACQUIRE) == mopt::kStatusPeerTimeout)
@@ -712,6 +733,7 @@ int blockingSweep(mopt_cost *c, bool cost_only, int jac_mode, const void *x) {
       mopt::HostPublish pub = nextPublish(c, offset);
       int rc = launch(pub);
       if (rc != MOPT_OK) return rc;
+      boundCommandBatch(c);
       return waitPublished(c, pub.sequence);
     }
   }
@@ -1154,8 +1176,10 @@ int launchPublishedSweep(mopt_cost *c, bool cost_only, int jac_mode, const void 
   const mopt::HostPublish pub = nextPublish(c, offset);
   c->stat_sweeps += 1;
   *sequence_out = pub.sequence;
-  return cost_only ? costAsyncImpl(c, x, c->d_result + offset, c->stream, pub)
-                   : linearizeAsyncImpl(c, jac_mode, x, c->d_result, c->stream, pub);
+  const int rc = cost_only ? costAsyncImpl(c, x, c->d_result + offset, c->stream, pub)
+                           : linearizeAsyncImpl(c, jac_mode, x, c->d_result, c->stream, pub);
+  if (rc == MOPT_OK) boundCommandBatch(c);
+  return rc;
 }
 int waitPublishedSweep(mopt_cost *c, unsigned long long sequence) {
   return waitPublished(c, sequence);

@@ -164,6 +164,8 @@ struct mopt_cost {
     double result[mopt_detail::kResultSlots] = {0};
   } cache;
   long long stat_sweeps = 0;
+  // blocking sweeps launched on `stream` since the runtime was last handed a marker (boundCommandBatch)
+  int launches_since_marker = 0;
   long long stat_cache_hits = 0;
 
   // Device-resident LM (mopt_lm_minimize, lm.cpp): this cost's sweep constants in HBM, written by

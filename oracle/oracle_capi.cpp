@@ -394,4 +394,10 @@ int oracle_state_minimize(const double *x_init, double *x, int max_iter, int *st
 
 int oracle_hardware_threads(void) { return int(std::thread::hardware_concurrency()); }
 
+// compiler and flags this checker was built with (oracle/Makefile), for bench.py's cpu_baseline
+#ifndef ORACLE_BUILD_FLAGS
+#define ORACLE_BUILD_FLAGS "unknown"
+#endif
+const char *oracle_build_flags(void) { return "g++ " __VERSION__ " " ORACLE_BUILD_FLAGS; }
+
 }  // extern "C"

@@ -67,6 +67,11 @@ class Oracle:
             ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
         lib.oracle_se3_from_x.argtypes = [ctypes.c_void_p] * 4
 
+    def build_flags(self):
+        """Compiler and flags the checker was built with (oracle/Makefile)."""
+        self.lib.oracle_build_flags.restype = ctypes.c_char_p
+        return self.lib.oracle_build_flags().decode()
+
     @staticmethod
     def _prep(src, tgt, x, cov, dtype):
         src = np.ascontiguousarray(src, dtype=dtype).reshape(-1, 3)

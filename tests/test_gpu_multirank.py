@@ -160,13 +160,23 @@ def _check_multirank_line(line, world, rehearsal):
     assert set(line["roofline"]["step_frac_by_collective"]) == set(line["by_collective"])
     assert {"none", "host", "peer"} <= set(line["ms_per_step_by_collective"])
     rccl = line["rccl"]
+    c4 = line["config4_strong"]
+    # the rate THROUGH the RCCL all-reduce (what north_star's scaling is judged on) is a top-level key
+    # whatever the headline transport was: a number wherever RCCL is attached, null on a shared GPU
+    assert "value_rccl" in line and "value_rccl" in c4
     if rehearsal:
         assert rccl["attached"] is False and "share" in rccl["reason"]
         assert cfg["rehearsal"] and cfg["rccl_ranks"] is None
+        assert line["value_rccl"] is None and c4["value_rccl"] is None and c4["rccl"] is None
     else:
         assert rccl["attached"] and rccl["ranks"] == world and rccl["spans_all_ranks"]
         assert rccl["ms_per_step"] > 0 and cfg["rccl_ranks"] == world
         assert "rccl" in line["by_collective"]
+        assert line["value_rccl"] == rccl["value"] > 0
+        assert c4["value_rccl"] == c4["rccl"]["value"] > 0
+    vs = line["check"]["vs_oracle"]   # rank 0's shard, combine off, against the CPU restatement
+    assert vs["ok"] and max(vs["H_rel"], vs["b_rel"], vs["cost_rel"]) <= vs["bar"] == 1e-6, vs
+    assert len(line["timing"]["per_step_us"]) == line["steps"]
     cpu = line["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["value"] > 1e6
     # the two flags a reader of a one-shot multi-GPU run looks at first: always there, both clear
@@ -174,7 +184,6 @@ def _check_multirank_line(line, world, rehearsal):
     assert cfg["collective_requested"] in ("auto", "host", "peer", "rccl", "torch")
     if rccl.get("timed_pass") in ("done", "the headline pass"):
         assert 0 < rccl["step_frac"] < 1.2 and rccl["ms_per_step"] > 0
-    c4 = line["config4_strong"]
     assert c4["total_correspondences"] == 10_000_000 and c4["ms_per_step"] > 0
     assert c4["kernel_ms"] > 0 and set(c4["by_collective"]) >= {"none", "host", "peer"}
 
@@ -249,5 +258,5 @@ def test_driver_command_rehearsed_with_four_ranks(hip_lib):
     keep = os.path.join(ds.ROOT, "gpurun_out")
     if os.path.isdir(keep):
         line["_rehearsal_wall_s"] = elapsed
-        with open(os.path.join(keep, "r4_4rank_driver_command_rehearsal.json"), "w") as f:
+        with open(os.path.join(keep, "r5_4rank_driver_command_rehearsal.json"), "w") as f:
             json.dump(line, f, indent=1)

@@ -317,9 +317,54 @@ def test_full_size_properties(hip_lib):
     assert rel_err(Hm, Hn) < 1e-6 and rel_err(bm, bn) < 1e-6 and abs(sm - sn) < 1e-12 * sn
 
 
+def test_metric_size_10M_against_oracle(hip_lib, oracle):
+    """The metric's own size — 10 M correspondences (BASELINE.json), the workload of bench.py's
+    headline, generated as bench.py generates it — directly against the CPU restatement on the same
+    inputs at the north-star bar (1e-6 norm-wise on H, b; 1e-6 on the cost): the analytic sweep in
+    its default (moments) and literal evaluations (linearization.h:126-158), forward differences
+    evaluated as the reference does (linearization.h:65-124), and the same under a symmetric
+    covariance with Geman-McClure.  One single-threaded oracle sweep over 10 M takes 0.6 s
+    (analytic) to ~4 s (forward differences) here."""
+    mo = hip_lib
+    import torch
+    n = 10_000_000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(42)
+    src = torch.rand((n, 3), generator=g, device="cuda", dtype=torch.float64) * 10.0
+    R = torch.tensor(ds.fixture_rotation(), device="cuda", dtype=torch.float64)
+    t = torch.tensor(ds.FIXTURE_T, device="cuda", dtype=torch.float64)
+    tgt = (src @ R.T + t + 0.01 * torch.randn((n, 3), generator=g, device="cuda",
+                                               dtype=torch.float64)).contiguous()
+    torch.cuda.synchronize()
+    cost = mo.Point2PointCost(src.data_ptr(), tgt.data_ptr(), device_ptrs=True, count=n)
+    src_h, tgt_h = src.cpu().numpy(), tgt.cpu().numpy()
+    x = ds.X_GENERIC
+    cov = np.array([[2.0, 0.3, -0.1], [0.3, 0.5, 0.2], [-0.1, 0.2, 1.5]])
+    want_analytic = oracle_ref(oracle, src_h, tgt_h, x, mo.JAC_ANALYTIC)
+    for variant in (mo.KERNEL_AUTO, mo.KERNEL_LITERAL):
+        cost.set_kernel_variant(variant)
+        check(cost.linearize(x, mo.JAC_ANALYTIC), want_analytic)
+    cost.set_speculation(False)
+    assert abs(cost.compute_cost(x) - want_analytic[2]) <= REL * want_analytic[2]
+    cost.set_kernel_variant(mo.KERNEL_LITERAL)
+    check(cost.linearize(x, mo.JAC_NUMERIC), oracle_ref(oracle, src_h, tgt_h, x, mo.JAC_NUMERIC))
+    cost.set_covariance(cov)
+    cost.set_loss(mo.LOSS_GEMAN_MCCLURE, 100.0)
+    check(cost.linearize(x, mo.JAC_NUMERIC),
+          oracle_ref(oracle, src_h, tgt_h, x, mo.JAC_NUMERIC, cov=cov, loss_kind=1, loss_param=100.0))
+    # the default evaluation of forward differences at this x (every |x_j| >= 0.1: moments), same bar
+    cost.set_kernel_variant(mo.KERNEL_AUTO)
+    cost.set_covariance(None)
+    cost.set_loss(mo.LOSS_NONE, 0.0)
+    check(cost.linearize(x, mo.JAC_NUMERIC), oracle_ref(oracle, src_h, tgt_h, x, mo.JAC_NUMERIC),
+          tol=fd_tolerance(x, mo.KERNEL_AUTO))
+    cost.close()
+
+
 def test_metric_size_properties_10M(hip_lib):
-    """The metric's own size, 10 M correspondences (BASELINE.json), where the CPU restatement would take
-    minutes: size-independent properties of every sweep the round-3 kernels serve.
+    """The metric's own size, 10 M correspondences (BASELINE.json): size-independent properties of
+    every sweep the round-3 kernels serve (the direct comparison with the CPU restatement at this size
+    is test_metric_size_10M_against_oracle).
       * the three evaluations of the analytic linearization agree (moments, literal);
       * forward differences evaluated as the reference does agree with the moments form where that
         meets the bar (|x_j| >= 0.1), under Sigma = I, a symmetric and a non-symmetric covariance;
