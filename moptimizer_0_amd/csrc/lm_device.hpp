@@ -638,23 +638,23 @@ __device__ __forceinline__ void lmStepBodyFor(const LmProblem &P, bool init, con
     // (H + lambda D) delta = -b ; xi = x0 + delta  (levenberg_marquadt_dyn.cpp:78-83)
     auto proposeTrial = [&]() {
       MOPT_TICK(5);
+      // The unpivoted solve in registers where every pivot is clearly positive; where one is not
+      // (a singular or indefinite H: the as-written test Jacobian's zero row, a cost with no valid
+      // residual) the pivoted statement of the host runs from LDS — solveDamped, run-time n, the same
+      // operations in the same order as the register form of rounds 2-4 (solveDampedFixed) but cold:
+      // that form's predicated exchanges kept ~80 lane masks alive across the hot path (118 spilled
+      // SGPRs in lmStepKernel<double>, 52 in the fused finalize-and-step kernels).
       bool solved = false;
       if constexpr (kInRegisters) {  // (the 16-wide instantiation never sees these n)
         switch (n) {
           case 6:
-            if (!solveDampedPositive<S, 6>(Hcur, bsrc, lambda, delta))
-              solveDampedFixed<S, 6>(Hcur, bsrc, lambda, delta);
-            solved = true;
+            solved = solveDampedPositive<S, 6>(Hcur, bsrc, lambda, delta);
             break;
           case 4:
-            if (!solveDampedPositive<S, 4>(Hcur, bsrc, lambda, delta))
-              solveDampedFixed<S, 4>(Hcur, bsrc, lambda, delta);
-            solved = true;
+            solved = solveDampedPositive<S, 4>(Hcur, bsrc, lambda, delta);
             break;
           case 2:
-            if (!solveDampedPositive<S, 2>(Hcur, bsrc, lambda, delta))
-              solveDampedFixed<S, 2>(Hcur, bsrc, lambda, delta);
-            solved = true;
+            solved = solveDampedPositive<S, 2>(Hcur, bsrc, lambda, delta);
             break;
           default:
             break;

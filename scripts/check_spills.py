@@ -27,15 +27,10 @@ DEVICE_SOURCES = ("sweep_kernels", "fd_kernels", "icp_grid", "lm_kernels")
 # Known and accepted: (kernel-name prefix, most scalar registers it may spill, why).  Nothing here may
 # spill a VGPR or use scratch, and every kernel that streams data per element must stay off this list.
 ACCEPTED_SGPR_SPILLS = (
-    # one workgroup, once per LM step: the lane masks of the pivoted LDL^T's predicated row / column
-    # exchanges and permutation selects (lm_device.hpp solveDampedFixed) — ~80 v_writelane /
-    # v_readlane on a ~8 us serial kernel; passing LmProblem through a pointer instead of by value
-    # (the round-3 guess at the source) changed nothing: measured in round 4
-    ("mopt::lmStepKernel<", 130, "LM step body"),
-    ("mopt::finalizeDenseResidentKernel<4>", 70, "LM step body"),
-    ("mopt::finalizeDenseResidentKernel<8>", 90, "LM step body"),
-    ("mopt::finalizeMomentsResidentKernel<4>", 70, "LM step body"),
-    ("mopt::finalizeMomentsResidentKernel<8>", 90, "LM step body"),
+    # one workgroup, once per LM step: what is left after round 5 took the pivoted LDL^T's predicated
+    # exchanges out of the step (the pivoted solve runs from LDS, cold: lm_device.hpp proposeTrial) —
+    # 118 -> 18 in lmStepKernel<double>, 52 -> 0 in the fused finalize-and-step kernels
+    ("mopt::lmStepKernel<", 24, "LM step body"),
     # fp32, symmetric covariance, arguments from HBM: <= 20 values (partials pointer, counts, the
     # set's block bounds) parked in a VGPR's lanes once per launch, outside the tile loop
     ("mopt::p2pForwardDiffResidentArgsKernel<float,", 20, "parked outside the tile loop"),
