@@ -875,90 +875,130 @@ __device__ __forceinline__ void icpMatchBody(const IcpMatchArgs<S> &A, const S (
 
   // Everything else lies across a far face of that block: only a lane whose best so far (or the
   // maximum distance, while it has none) reaches the nearest of the three goes on — at about one
-  // target per cell and a source within half a cell of its target, none.  Those that do walk the
-  // (2 reach + 1)^3 block row by row under the running bound, the own cell first; cells seen above
-  // are seen again, which changes nothing (same distances, same positions).
+  // target per cell and a source within half a cell of its target, none.
   const S far_x = (sx < 0 ? A.cell - fx : fx) - ex;
   const S far_y = (sy < 0 ? A.cell - fy : fy) - ey;
   const S far_z = (sz < 0 ? A.cell - fz : fz) - ez;
-  if (inside && (!first_round || within(sq(fmin(far_x, fmin(far_y, far_z)))))) {
-    const int first_round_k = best_k;
-    // cells [xa, xb] of row (y, z) are consecutive in storage: one candidate range, two bounds
-    auto visit = [&](int y, int z, int xa, int xb) {
+  const bool go = inside && (!first_round || within(sq(fmin(far_x, fmin(far_y, far_z)))));
+  const int first_round_k = best_k;
+  // Second round, in lock step too (round 5; rounds 3-4 walked the rows one after the other, each
+  // lane under its running bound: fewer candidates per lane, but two dependent waits of the whole
+  // wave for every row ANY of its lanes visited).  The rows of the (2 reach + 1)^2 block around the
+  // own one are taken nine (then eight) at a time: every lane that goes on lists, under the bound
+  // it has now, the stretch of cells of each row it still has to see — a stretch is consecutive in
+  // storage: one candidate range, two bounds —, the 18 bounds are fetched together, and the wave
+  // walks the stretches laid end to end four candidates per trip like the first round: one wait
+  // for the bounds and one per trip, every lane that has something active in every trip.  A cell is
+  // listed only if its box can hold something at least as close as what has been found (or within
+  // the maximum distance while nothing has); the bound is taken from the own cell's faces and
+  // tightens from one group of rows to the next.
+  const S gx[2] = {fx - ex, (A.cell - fx) - ex};
+  const S gy[2] = {fy - ey, (A.cell - fy) - ey};
+  const S gz[2] = {fz - ez, (A.cell - fz) - ez};
+  const int R = A.reach;
+  auto gapAlong = [&](const S (&gap)[2], int d) {  // to the slab of cells d steps away
+    return d == 0 ? S(0) : gap[d < 0 ? 0 : 1] + S((d < 0 ? -d : d) - 1) * A.cell;
+  };
+  // rows(r, dy, dz) names row r < 9 of the group (the same for every lane of the wave) or says there
+  // is none; skip_block: the rows of the 2 x 2 x 2 block have only their far cell left (reach 1)
+  auto walkRows = [&](bool active, auto rows, auto skip_block) {
+    int at_a[9], at_b[9];
+    bool some = false;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      int dy = 0, dz = 0;
+      const bool valid = rows(r, dy, dz);
+      const int y = c[1] + dy, z = c[2] + dz;
+      const S yz = sq(gapAlong(gy, dy)) + sq(gapAlong(gz, dz));
+      int left = 0, right = 0;
+      for (int step = 0; step < R; ++step) {
+        left += (left == step && within(yz + sq(gx[0] + S(step) * A.cell))) ? 1 : 0;
+        right += (right == step && within(yz + sq(gx[1] + S(step) * A.cell))) ? 1 : 0;
+      }
+      bool ok = valid && active && within(yz) && y >= 0 && y < A.dims[1] && z >= 0 && z < A.dims[2];
+      int xa = c[0] - left, xb = c[0] + right;
+      if constexpr (decltype(skip_block)::value) {
+        // cells c0 + sx and c0 + sx + 1 of a row of the block were candidates of the first round
+        const bool in_block = first_round && (dy == sy || dy == sy + 1) && (dz == sz || dz == sz + 1);
+        xa = in_block ? (sx < 0 ? c[0] + 1 : c[0] - 1) : xa;
+        xb = in_block ? xa : xb;
+        ok = ok && (!in_block || (sx < 0 ? right > 0 : left > 0));
+      }
       xa = xa < 0 ? 0 : xa;
       xb = xb >= A.dims[0] ? A.dims[0] - 1 : xb;
-      if (z < 0 || z >= A.dims[2] || y < 0 || y >= A.dims[1] || xa > xb) return;
+      ok = ok && xa <= xb;
+      some = some || ok;
       const int row = (z * A.dims[1] + y) * A.dims[0];
-      const int lo = A.cell_start[row + xa], hi = A.cell_start[row + xb + 1];
-      // two candidates per step, both loads issued before either is used
-      for (int k = lo; k < hi; k += 2) {
-        S qa[3], qb[3];
-        const bool pair = k + 1 < hi;
-        fetch(k, qa);
-        fetch(pair ? k + 1 : k, qb);
-        consider(qa, k, true, std::false_type());
-        consider(qb, k + 1, pair, std::false_type());
-      }
-    };
-    // Every cell is visited only if its box can hold something at least as close as what has been
-    // found (or within the maximum distance while nothing has) — the bound is the distance to the
-    // own cell's faces.  Range bounds are fetched only for what is visited.
-    const S gx[2] = {fx - ex, (A.cell - fx) - ex};
-    const S gap_y[3] = {fy - ey, S(0), (A.cell - fy) - ey};
-    const S gap_z[3] = {fz - ez, S(0), (A.cell - fz) - ez};
-    if (A.reach == 1) {
-      visit(c[1], c[2], c[0], c[0]);
+      at_a[r] = ok ? row + xa : 0;  // (entry 0 twice: an empty stretch)
+      at_b[r] = ok ? row + xb + 1 : 0;
+    }
+    if (!__any(some)) return;
+    int lo[9], upto[9];
 #pragma unroll
-      for (int r = 0; r < 9; ++r) {
-        const int y = c[1] + r % 3 - 1, z = c[2] + r / 3 - 1;
-        const S yz = sq(gap_y[r % 3]) + sq(gap_z[r / 3]);
-        if (!within(yz)) continue;
-        const bool left = within(yz + sq(gx[0])), right = within(yz + sq(gx[1]));
-        if (r == 4) {  // the own row: its centre cell is done
-          if (left) visit(y, z, c[0] - 1, c[0] - 1);
-          if (right) visit(y, z, c[0] + 1, c[0] + 1);
-        } else {
-          visit(y, z, left ? c[0] - 1 : c[0], right ? c[0] + 1 : c[0]);
-        }
+    for (int r = 0; r < 9; ++r) {
+      lo[r] = A.cell_start[at_a[r]];
+      upto[r] = A.cell_start[at_b[r]];
+    }
+    upto[0] -= lo[0];  // upto[r]: the list position one past row r's last candidate
+#pragma unroll
+    for (int r = 1; r < 9; ++r) upto[r] = upto[r - 1] + (upto[r] - lo[r]);
+    const int listed = upto[8];
+    for (int j = 0; __any(j < listed); j += kIcpTrip) {
+      int k[kIcpTrip];
+      bool present[kIcpTrip];
+      S q[kIcpTrip][3];
+#pragma unroll
+      for (int u = 0; u < kIcpTrip; ++u) {
+        const int jj = j + u;
+        present[u] = jj < listed;
+        int at = lo[8] + (jj - upto[7]);
+#pragma unroll
+        for (int r = 7; r >= 1; --r) at = jj < upto[r] ? lo[r] + (jj - upto[r - 1]) : at;
+        at = jj < upto[0] ? lo[0] + jj : at;
+        k[u] = present[u] ? at : 0;
       }
+#pragma unroll
+      for (int u = 0; u < kIcpTrip; ++u) fetch(k[u], q[u]);
+      // (distance and position only: the coordinates of a winner found here are read once, at the end)
+#pragma unroll
+      for (int u = 0; u < kIcpTrip; ++u) consider(q[u], k[u], present[u], std::false_type());
+    }
+  };
+  if (__any(go)) {
+    // the own row and the ring of eight around it
+    auto inner = [](int r, int &dy, int &dz) {
+      dy = r % 3 - 1;
+      dz = r / 3 - 1;
+      return true;
+    };
+    if (R == 1) {
+      walkRows(go, inner, std::true_type());
     } else {
-      // Cells finer than the radius (icp.cpp picks them so where the targets are dense): the
-      // (2 reach + 1)^3 block, its rows ring by ring around the own one — nearest first, so that the
-      // bound tightens early —, each row over the stretch of cells the bound still admits.  A ring
-      // whose nearest face is out of reach ends the walk.
-      // (every loop counter here is the same for all lanes of the wave: the loops are scalar, only
-      // the decisions inside are per lane — a lane that is done with a ring simply skips the rest)
-      const int R = A.reach;
-      auto gapAlong = [&](S near_gap, S far_gap, int d) {  // to the slab of cells d steps away
-        return d == 0 ? S(0) : (d < 0 ? near_gap : far_gap) + S((d < 0 ? -d : d) - 1) * A.cell;
-      };
-      bool walking = true;
-      for (int ring = 0; ring <= R; ++ring) {
-        if (ring > 0) {
-          const S nearest = fmin(fmin(gapAlong(gap_y[0], gap_y[2], -ring), gapAlong(gap_y[0], gap_y[2], ring)),
-                                 fmin(gapAlong(gap_z[0], gap_z[2], -ring), gapAlong(gap_z[0], gap_z[2], ring)));
-          walking = walking && within(sq(nearest));
-          if (!__any(walking)) break;
-        }
-        const int rows = ring == 0 ? 1 : 8 * ring;
-        for (int u = 0; u < rows; ++u) {
-          // row u of the ring, counter-clockwise from its (-ring, -ring) corner
-          const int side = ring == 0 ? 0 : u / (2 * ring), along = ring == 0 ? 0 : u % (2 * ring);
-          const int dy = side == 0 ? -ring + along : side == 1 ? ring : side == 2 ? ring - along : -ring;
-          const int dz = side == 0 ? -ring : side == 1 ? -ring + along : side == 2 ? ring : ring - along;
-          const S yz = sq(gapAlong(gap_y[0], gap_y[2], dy)) + sq(gapAlong(gap_z[0], gap_z[2], dz));
-          if (!(walking && within(yz))) continue;
-          int left = 0, right = 0;
-          for (int step = 0; step < R; ++step) {
-            left += (left == step && within(yz + sq(gx[0] + S(step) * A.cell))) ? 1 : 0;
-            right += (right == step && within(yz + sq(gx[1] + S(step) * A.cell))) ? 1 : 0;
-          }
-          visit(c[1] + dy, c[2] + dz, c[0] - left, c[0] + right);
+      // Cells finer than the radius (icp.cpp picks them so where the targets are dense): after the
+      // inner nine rows the rings further out, eight rows at a time, counter-clockwise from each
+      // ring's (-ring, -ring) corner.  A lane is done once a ring's nearest face is out of its reach;
+      // the walk ends when every lane is.  (Ring and row counters are the same for all lanes.)
+      walkRows(go, inner, std::false_type());
+      bool walking = go;
+      for (int ring = 2; ring <= R; ++ring) {
+        const S nearest = fmin(fmin(gapAlong(gy, -ring), gapAlong(gy, ring)),
+                               fmin(gapAlong(gz, -ring), gapAlong(gz, ring)));
+        walking = walking && within(sq(nearest));
+        if (!__any(walking)) break;
+        for (int base = 0; base < 8 * ring; base += 8) {
+          auto outer = [&](int r, int &dy, int &dz) {
+            const int u = base + r;
+            const int side = u / (2 * ring), along = u % (2 * ring);
+            dy = side == 0 ? -ring + along : side == 1 ? ring : side == 2 ? ring - along : -ring;
+            dz = side == 0 ? -ring : side == 1 ? -ring + along : side == 2 ? ring : ring - along;
+            return r < 8;
+          };
+          walkRows(walking, outer, std::false_type());
         }
       }
     }
-    if (best_k != first_round_k) fetch(best_k, best);
   }
+  if (go && best_k != first_round_k) fetch(best_k, best);
   const S nan = S(__builtin_nan(""));
   slot[3 * TP] = found ? best[0] : nan;
   slot[4 * TP] = found ? best[1] : nan;
