@@ -103,7 +103,12 @@ enum mopt_create_flags {
 
 /* How a sweep evaluates the reference's per-residual arithmetic. */
 enum mopt_kernel_variant {
-  MOPT_KERNEL_AUTO = 0,    /* fastest variant that meets the parity bar for the mode         */
+  MOPT_KERNEL_AUTO = 0,    /* fastest variant that meets the parity bar for the mode.  Blocking
+                              and asynchronous calls: moments, except forward differences at an x
+                              with some 0 < |x_j| < 0.08 (literal).  Device-resident loop
+                              (mopt_lm_minimize), which picks its sweep once per minimisation and
+                              not per iterate: analytic modes through moments, forward differences
+                              literally at every iterate                                      */
   MOPT_KERNEL_LITERAL = 1, /* every residual and Jacobian entry formed per point, then
                               w * J^T * S * J accumulated entry by entry, as the reference does */
   MOPT_KERNEL_MOMENTS = 2, /* Jacobians that are affine in the source point (all point2point
@@ -112,12 +117,11 @@ enum mopt_kernel_variant {
                               evaluation leaves the 1e-6 bar (it lacks the reference's own
                               per-point cancellation noise eps |R p + t| / h_j) and the literal
                               evaluation is used.  That rule is the blocking and asynchronous
-                              calls'; the device-resident loop (mopt_lm_minimize) decides per
-                              minimisation, not per point, and under this variant evaluates
-                              forward differences through moments at every iterate — its
+                              calls'; under this variant the device-resident loop evaluates
+                              forward differences through moments at EVERY iterate — its
                               Jacobians can then differ from mopt_cost_linearize's at a point
-                              with a small |x_j| by the amount given under _ALWAYS; ask for
-                              MOPT_KERNEL_LITERAL where that matters                            */
+                              with a small |x_j| by the amount given under _ALWAYS (the speed of
+                              the moments sweep, asked for by name; AUTO does not do this)      */
   MOPT_KERNEL_MOMENTS_ALWAYS = 3 /* moments whatever the step size: for measurements; forward
                               differences then differ from the reference's by up to
                               2e-8 / min |x_j| relative (0.97 at |x_j| ~ 1e-8)                  */

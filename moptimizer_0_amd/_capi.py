@@ -295,9 +295,10 @@ class _CostBase:
         """Pre-bound form for tight loops (bench): returns (call, x, H, b, s) where x is a reusable
         input array, H/b/s are reused outputs and call() runs one blocking linearize."""
         dt = _dtype_of(self.scalar_bytes)
-        x = np.zeros(6, dtype=dt)
-        H = np.zeros((6, 6), dtype=dt, order="F")
-        b = np.zeros(6, dtype=dt)
+        n = self.n_params
+        x = np.zeros(n, dtype=dt)
+        H = np.zeros((n, n), dtype=dt, order="F")
+        b = np.zeros(n, dtype=dt)
         s = np.zeros(1, dtype=dt)
         fn = load().mopt_cost_linearize
         args = (self._h, int(jac_mode), _ptr(x), _ptr(H), _ptr(b), _ptr(s))
@@ -457,6 +458,8 @@ class IcpCost(Point2PointCost):
         if hasattr(src, "data_ptr") and hasattr(tgt, "data_ptr"):
             import torch
             assert src.is_cuda and tgt.is_cuda and src.dtype == tgt.dtype
+            if src.dtype not in (torch.float32, torch.float64):
+                raise TypeError("IcpCost takes float32 or float64 clouds, not %s" % src.dtype)
             assert src.is_contiguous() and tgt.is_contiguous()
             self.scalar_bytes = src.element_size()
             torch.cuda.synchronize(src.device)

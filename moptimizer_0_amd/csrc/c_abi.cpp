@@ -776,13 +776,22 @@ int residentPrepareP2P(mopt_cost *c, int jac_mode, bool moments, double *partial
   return MOPT_OK;
 }
 
-bool usesMoments(const mopt_cost *c) { return c->variant != MOPT_KERNEL_LITERAL; }
+// The device-resident loop chooses its sweep once per minimisation, not per iterate, so the rule of
+// the blocking calls (forward differences literally where some 0 < |x_j| < 0.08) cannot be applied
+// point by point: MOPT_KERNEL_AUTO — "meets the parity bar" — therefore evaluates forward differences
+// literally at every iterate (an LM path from x = 0 passes through small |x_j| as a rule), and only
+// the explicit MOPT_KERNEL_MOMENTS / _ALWAYS take the moments there.  Analytic modes: moments.
+bool usesMoments(const mopt_cost *c, int jac_mode) {
+  if (c->variant == MOPT_KERNEL_LITERAL) return false;
+  if (c->variant == MOPT_KERNEL_AUTO && jac_mode == MOPT_JAC_NUMERIC) return false;
+  return true;
+}
 }  // namespace
 
-int residentGrid(const mopt_cost *c) {
+int residentGrid(const mopt_cost *c, int jac_mode) {
   switch (c->model) {
     case kModelPoint2Point:
-      return gridFor(c, blocksPerCu(usesMoments(c) ? 1 : 2));
+      return gridFor(c, blocksPerCu(usesMoments(c, jac_mode) ? 1 : 2));
     case kModelReprojection:
       return gridFor(c, blocksPerCu(2));
     case kModelScalar:
@@ -794,11 +803,11 @@ int residentGrid(const mopt_cost *c) {
   }
 }
 
-int residentDenseRow(const mopt_cost *c) {
+int residentDenseRow(const mopt_cost *c, int jac_mode) {
   const int n = c->n_params;
   switch (c->model) {
     case kModelPoint2Point:
-      if (usesMoments(c)) return 0;  // rows of moments, contracted by their own finalize kernel
+      if (usesMoments(c, jac_mode)) return 0;  // rows of moments, contracted by their own finalize kernel
       return c->cov_mode == mopt::kCovGeneral ? mopt::kAccFull : mopt::kAccSym;
     case kModelReprojection:
       return c->cov_mode == mopt::kCovGeneral ? mopt::kAccFull : mopt::kAccSym;
@@ -828,7 +837,7 @@ int residentPrepare(mopt_cost *c, int jac_mode, hipStream_t s, mopt::LmCostDesc 
   switch (c->model) {
     case kModelPoint2Point: {
       desc->model = mopt::kLmPoint2Point;
-      desc->moments = usesMoments(c) ? 1 : 0;
+      desc->moments = usesMoments(c, jac_mode) ? 1 : 0;
       if (stale)
         rc = c->scalar_bytes == 8
                  ? residentPrepareP2P<double>(c, jac_mode, desc->moments, partials, s)
@@ -966,7 +975,7 @@ bool residentSetSupported(mopt_cost *const *costs, int num_costs, const int *jac
       case kModelReprojection:
         break;
       case kModelPoint2Point:
-        if (usesMoments(c)) return false;  // rows of moments: one finalize per cost anyway
+        if (usesMoments(c, jac_modes[k])) return false;  // rows of moments: one finalize per cost anyway
         break;
       case kModelScalar:
         if (c->scalar_model != first->scalar_model) return false;
@@ -1074,8 +1083,8 @@ int residentSweep(mopt_cost *c, int jac_mode, mopt::LmControl *control, hipStrea
   }
   switch (c->model) {
     case kModelPoint2Point: {
-      if (usesMoments(c)) {
-        const int grid = residentGrid(c);
+      if (usesMoments(c, jac_mode)) {
+        const int grid = residentGrid(c, jac_mode);
         if (c->scalar_bytes == 8)
           MOPT_HIP_TRY(mopt::launchP2PMomentsResident<double>(
               static_cast<const double *>(c->d_tiles), c->num_tiles,
@@ -1089,8 +1098,8 @@ int residentSweep(mopt_cost *c, int jac_mode, mopt::LmControl *control, hipStrea
                                                          c->d_result, control, s, peers, step,
                                                          own_index, c->scalar_bytes));
       } else {
-        const int grid = residentGrid(c);
-        const int nacc = residentDenseRow(c);
+        const int grid = residentGrid(c, jac_mode);
+        const int nacc = residentDenseRow(c, jac_mode);
         if (c->scalar_bytes == 8)
           MOPT_HIP_TRY(mopt::launchP2PLiteralResident<double>(
               static_cast<const mopt::P2PSweepArgs<double> *>(c->d_lm_args), control, jac_mode,
@@ -1107,8 +1116,8 @@ int residentSweep(mopt_cost *c, int jac_mode, mopt::LmControl *control, hipStrea
       return MOPT_OK;
     }
     case kModelReprojection: {
-      const int grid = residentGrid(c);
-      const int nacc = residentDenseRow(c);
+      const int grid = residentGrid(c, jac_mode);
+      const int nacc = residentDenseRow(c, jac_mode);
       MOPT_HIP_TRY(mopt::launchReprojResident(
           static_cast<const mopt::ReprojSweepArgs *>(c->d_lm_args), control, c->cov_mode, grid, site));
       if (finalize)
@@ -1118,8 +1127,8 @@ int residentSweep(mopt_cost *c, int jac_mode, mopt::LmControl *control, hipStrea
       return MOPT_OK;
     }
     case kModelScalar: {
-      const int grid = residentGrid(c);
-      const int nacc = residentDenseRow(c);
+      const int grid = residentGrid(c, jac_mode);
+      const int nacc = residentDenseRow(c, jac_mode);
       if (c->scalar_bytes == 8)
         MOPT_HIP_TRY(mopt::launchScalarModelResident<double>(
             static_cast<const mopt::ScalarSweepArgs<double> *>(c->d_lm_args), control,
@@ -1138,8 +1147,8 @@ int residentSweep(mopt_cost *c, int jac_mode, mopt::LmControl *control, hipStrea
       const mopt::JitVariant *variant =
           mopt::jitVariant(c->jit, jac_mode == MOPT_JAC_NUMERIC ? 2 : 1, c->cov_mode);
       if (!variant) return fail(MOPT_ERR_INVALID_ARGUMENT, mopt::jitLastError());
-      const int grid = residentGrid(c);
-      const int nacc = residentDenseRow(c);
+      const int grid = residentGrid(c, jac_mode);
+      const int nacc = residentDenseRow(c, jac_mode);
       MOPT_HIP_TRY(mopt::jitLaunchResident(*variant, c->d_lm_args, control, grid, s));
       if (finalize)
         MOPT_HIP_TRY(mopt::launchFinalizeDenseResident(c->d_partials, grid, nacc, n, c->d_result,

@@ -241,8 +241,8 @@ int waitHostPublished(mopt_cost *c, unsigned long long sequence);
 // rows of several costs behind one another, reduced by one finalize kernel)
 int residentPrepare(mopt_cost *c, int jac_mode, hipStream_t s, mopt::LmCostDesc *desc,
                     double *partials_override = nullptr);
-int residentGrid(const mopt_cost *c);      // workgroups (= partial rows) of a resident sweep
-int residentDenseRow(const mopt_cost *c);  // values per partial row; 0: rows of moments
+int residentGrid(const mopt_cost *c, int jac_mode);      // workgroups (= partial rows) of a resident sweep
+int residentDenseRow(const mopt_cost *c, int jac_mode);  // values per partial row; 0: rows of moments
 // one finalize (+ LM step) over `rows` rows of `row_length` values in last->d_partials
 int residentFinalizeMerged(mopt_cost *last, int rows, int row_length, mopt::LmControl *control,
                            hipStream_t s, const mopt::LmProblem *step, int own_index);
@@ -269,11 +269,19 @@ int costAsyncImpl(mopt_cost *c, const void *x, double *d_sum, hipStream_t s,
 // H | b | sum_sq as doubles -> the caller's arrays in the cost's scalar type
 void storeResult(const mopt_cost *c, const double *res, void *hessian, void *b, void *sum_sq);
 
-struct DeviceScratch {  // back to the device pool on scope exit (after whatever still uses it)
+// Back to the device pool on scope exit, after whatever was queued on `stream` — the stream the
+// block was used on — has run (an early return may leave work behind; on the normal path the
+// stream has been synchronised already and this costs nothing).  Only that stream: a device-wide
+// synchronisation here stalled every other cost sweeping on the GPU, five times per ICP cost made.
+struct DeviceScratch {
   void *p = nullptr;
+  hipStream_t stream = nullptr;
+  explicit DeviceScratch(hipStream_t used_on = nullptr) : stream(used_on) {}
+  DeviceScratch(const DeviceScratch &) = delete;
+  DeviceScratch &operator=(const DeviceScratch &) = delete;
   ~DeviceScratch() {
     if (!p) return;
-    (void)hipDeviceSynchronize();
+    (void)hipStreamSynchronize(stream);
     deviceRelease(p);
   }
   hipError_t alloc(size_t bytes) { return deviceAlloc(&p, bytes ? bytes : 16); }

@@ -23,7 +23,7 @@ int buildIcpGrid(const S *src, long long n, const S *tgt, long long m, double ma
   auto mt = std::make_unique<IcpMatcher>();
   mt->max_dist = max_distance;
   mt->num_targets = m;
-  DeviceScratch d_tgt, d_src, d_perm_t, d_perm_s;
+  DeviceScratch d_tgt(s), d_src(s), d_perm_t(s), d_perm_s(s);
   MOPT_HIP_TRY(d_tgt.alloc(size_t(m) * 3 * sizeof(S)));
   MOPT_HIP_TRY(d_src.alloc(size_t(n) * 3 * sizeof(S)));
   // (clouds already in device memory are copied too: 24 B a point at HBM speed, and the caller's
@@ -52,9 +52,14 @@ int buildIcpGrid(const S *src, long long n, const S *tgt, long long m, double ma
   };
   int reach = 1;
   static const int forced_reach = envInt("MOPT_ICP_REACH", 0);  // tests and measurements
+  // (a box thinner than a cell along some axis — a wall, a line, coincident points — says nothing
+  // about the targets per cell by its volume: there the resolution comes from the occupied cells
+  // below alone)
+  bool thin_box = false;
+  for (int a = 0; a < 3; ++a) thin_box = thin_box || !(hi[a] - lo[a] >= radius_cell);
   if (forced_reach > 0) {
     reach = mostReach(forced_reach > 8 ? 8 : forced_reach);
-  } else {
+  } else if (!thin_box) {
     while (reach < 8 && double(m) > 1.5 * cellsAt(radius_cell / reach) && mostReach(reach + 1) > reach)
       ++reach;
   }
@@ -64,7 +69,12 @@ int buildIcpGrid(const S *src, long long n, const S *tgt, long long m, double ma
   // The box's volume says little about how the targets fill it (a scanned surface occupies a thin
   // sheet of the cells): after the first binning the cells that hold anything are counted, and while
   // they hold more than three targets each on average the grid is made finer and the targets are
-  // binned again (at most twice more; a binning is ~0.25 ms per million).
+  // binned again (at most twice more; a binning is ~0.25 ms per million).  Finer cells that do not
+  // thin the targets out (coincident points; fewer than 1.5 times fewer per occupied cell) only add
+  // empty rows to every search: the grid then goes back to the resolution before, and stays.
+  int reach_before = 0;
+  double per_cell_before = 0.0;
+  bool settled = false;
   for (int attempt = 0;; ++attempt) {
     double cell = radius_cell / reach;
     while (cellsAt(cell) > kMostCells) cell *= 1.26;  // (only ever with reach == 1)
@@ -81,14 +91,22 @@ int buildIcpGrid(const S *src, long long n, const S *tgt, long long m, double ma
     MOPT_HIP_TRY(deviceAlloc(reinterpret_cast<void **>(&g.d_cell_start), size_t(ncells + 1) * sizeof(int)));
     MOPT_HIP_TRY(mopt::icpSortByCell<S>(d_tgt.as<S>(), m, g.origin, g.cell, g.dims, d_perm_t.as<int>(),
                                         g.d_cell_start, s));
-    if (forced_reach > 0 || m == 0 || attempt == 2 || reach == 8) break;
+    if (settled || forced_reach > 0 || m == 0 || attempt == 3) break;
+    if (reach == 8 && reach_before == 0) break;  // by the volume rule, nothing finer to try
     long long occupied = 0;
     MOPT_HIP_TRY(mopt::icpCountOccupiedCells(g.d_cell_start, ncells, &occupied, s));
     const double per_cell = double(m) / double(occupied > 0 ? occupied : 1);
-    if (per_cell <= 3.0) break;
+    if (reach_before > 0 && per_cell * 1.5 > per_cell_before) {
+      reach = reach_before;
+      settled = true;
+      continue;
+    }
+    if (per_cell <= 3.0 || attempt == 2) break;
     const int wanted = int(std::ceil(reach * std::sqrt(per_cell / 1.5)));
     const int finer = mostReach(std::min(8, std::max(reach + 1, wanted)));
     if (finer <= reach) break;
+    reach_before = reach;
+    per_cell_before = per_cell;
     reach = finer;
   }
   // (one matched count per wave of the search: whole tiles of sources, 64 to a wave)
@@ -190,6 +208,11 @@ int mopt_icp_create_from(mopt_cost **out, int device, int scalar_bytes, const vo
       num_tgt > std::numeric_limits<int>::max() || num_src > std::numeric_limits<int>::max())
     return fail(MOPT_ERR_INVALID_ARGUMENT, "bad clouds");
   if (!(max_distance > 0.0)) return fail(MOPT_ERR_INVALID_ARGUMENT, "max_distance must be > 0");
+  // (before any copy is sized by it: a 2-byte scalar type would be read as fp32, past the caller's buffer)
+  if (scalar_bytes != 4 && scalar_bytes != 8)
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "scalar_bytes must be 4 (float) or 8 (double)");
+  if (flags & ~unsigned(MOPT_INPUT_DEVICE))
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "unknown flag bits (MOPT_INPUT_HOST or MOPT_INPUT_DEVICE)");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(MOPT_ERR_NO_DEVICE, "no HIP device is visible to this process");
@@ -205,7 +228,7 @@ int mopt_icp_create_from(mopt_cost **out, int device, int scalar_bytes, const vo
   };
   hipStream_t build_stream = nullptr;
   MOPT_HIP_TRY(acquireStream(device, &build_stream));
-  DeviceScratch d_src_sorted;
+  DeviceScratch d_src_sorted(build_stream);  // (read once more by the cost's own stream, which the create call synchronises)
   int rc = scalar_bytes == 8
                ? buildIcpGrid<double>(static_cast<const double *>(src_xyz), num_src,
                                       static_cast<const double *>(tgt_xyz), num_tgt, max_distance,

@@ -119,7 +119,7 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
   // reduces them all, instead of one finalize launch per cost.  (Not for sharded costs, whose
   // sums are exchanged per cost, nor for rows of moments, which each cost contracts itself.)
   mopt_cost *last = costs[num_costs - 1];
-  const int row_length = residentDenseRow(last);
+  const int row_length = residentDenseRow(last, jacobian_modes[num_costs - 1]);
   static const bool merge_enabled = [] {  // MOPT_LM_MERGE=0: one finalize per cost (for comparison)
     const char *v = std::getenv("MOPT_LM_MERGE");
     return !(v && v[0] == '0');
@@ -127,9 +127,9 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
   bool merged = merge_enabled && num_costs > 1 && row_length > 0;
   int row_offset[mopt::kLmMaxCosts + 1] = {0};
   for (int k = 0; k < num_costs; ++k) {
-    merged = merged && residentDenseRow(costs[k]) == row_length && !costs[k]->matcher &&
+    merged = merged && residentDenseRow(costs[k], jacobian_modes[k]) == row_length && !costs[k]->matcher &&
              costs[k]->combine.mode == MOPT_COMBINE_NONE;
-    row_offset[k + 1] = row_offset[k] + residentGrid(costs[k]);
+    row_offset[k + 1] = row_offset[k] + residentGrid(costs[k], jacobian_modes[k]);
     for (int j = 0; j < k; ++j) merged = merged && costs[j] != costs[k];
   }
   // all rows must fit the last cost's buffer in doubles, not only in rows: a wide model's row is up

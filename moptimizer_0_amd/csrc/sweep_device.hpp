@@ -156,6 +156,11 @@ __device__ __forceinline__ void blockReduceStore(double (&acc)[NACC], double *ou
   constexpr int kChunk = NACC <= kReduceOnePass ? NACC : kReduceChunk;
   constexpr int kPasses = (NACC + kChunk - 1) / kChunk;
   __shared__ double lds[kWaves][kChunk][kReduceRow];
+  // two workgroups of the VALU-heavy sweeps share a CU's 160 KB (gfx950): a row length that takes
+  // the one-pass form past half of it would silently drop them to one — or not link at all on a
+  // part with 64 KB
+  static_assert(sizeof(double) * kWaves * kChunk * kReduceRow <= 80 * 1024,
+                "blockReduceStore: more than half of a gfx950 CU's LDS for one workgroup");
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int k_read = threadIdx.x >> 3;  // value handled in the read phase (0..31)

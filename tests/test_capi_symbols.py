@@ -89,6 +89,12 @@ def test_round2_entry_points_validate_their_arguments_without_a_device():
     assert lib.mopt_cost_link_stats(None, None) == 1
     assert lib.mopt_icp_grid(None, None, None, None, None) == 1   # not an ICP cost
     assert lib.mopt_icp_create_from(None, 0, 8, None, 0, None, 0, 1.0, 1) == 1
+    # a scalar size that is neither float nor double, and unknown flag bits, are refused up front
+    # (before the device is even looked for: error 1 = invalid argument, not 2 = no device)
+    import ctypes
+    h = ctypes.c_void_p()
+    assert lib.mopt_icp_create_from(ctypes.byref(h), 0, 2, None, 0, None, 0, 1.0, 1) == 1
+    assert lib.mopt_icp_create_from(ctypes.byref(h), 0, 8, None, 0, None, 0, 1.0, 6) == 1
     x = np.array([0.1, 0.2, 0.3, 0.0, 0.0, 0.0])
     out = mo.capi.se3_plus(x, np.array([1.0, 2.0, 3.0, 0.0, 0.0, 0.0]))  # pure translation adds
     assert np.allclose(out, [1.1, 2.2, 3.3, 0, 0, 0], atol=1e-15)

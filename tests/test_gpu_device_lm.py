@@ -11,7 +11,7 @@ boundary path, where both sides call glibc), so a Jacobian column carries a rela
 ~1e-8 that is a different realisation on the two sides — as it would be between any two libms.  The
 iterates then agree to that noise (measured <= 2e-8 |x|, bound used 1e-7), the fixed point is the
 same, and the iteration at which the noise-level stopping tests (cost < 8 eps, rho < 0 with
-|delta| < sqrt eps) fire may differ by one."""
+|delta| < sqrt eps) fire may differ by one or two."""
 FD_ITERATE_TOL = 1e-7
 import numpy as np
 import pytest
@@ -96,11 +96,58 @@ def test_iterates_match_the_cpu_loop(hip_lib, oracle, n, jac):
         if jac == 0:
             assert (rep["status"], rep["iterations"]) == (status, iters), (k, rep, status, iters)
         else:
-            # the noise-level stop may fire one iteration apart — and then one side may run into
-            # the iteration limit instead
-            assert abs(rep["iterations"] - iters) <= 1, (k, rep, iters)
+            # the noise-level stop (rho < 0 with |delta| < sqrt eps) fires on the last bits of two
+            # costs that are stationary to twelve digits by then: one or two iterations apart (literal
+            # forward differences, AUTO's choice in the device loop since round 5: 4 against 6 at
+            # n = 1000, 5 against 6 at 100 k; scripts/probes/device_loop_stop.py) — and then one side
+            # may run into the iteration limit instead.  Same pose, same cost.
+            assert abs(rep["iterations"] - iters) <= 2, (k, rep, iters)
             assert rep["status"] == status or MAX_ITERATIONS in (rep["status"], status), (k, rep, status)
+            want_cost = oracle.p2p_cost(src, tgt, xr)
+            if k > 2:
+                assert abs(rep["cost"] - want_cost) <= 1e-9 * want_cost, (k, rep["cost"], want_cost)
         assert np.abs(x - xr).max() < tol * max(1.0, np.abs(xr).max()), (k, x, xr)
+    cost.close()
+
+
+def test_forward_differences_at_small_parameters(hip_lib, oracle):
+    """A registration between nearly aligned clouds: every iterate has 0 < |x_j| < 0.08, where the
+    moments form of the forward differences lacks the reference's own per-point cancellation noise
+    (eps |R p + t| / h_j, part of what linearization.h:101-105 computes) and leaves the bar.  The
+    device loop chooses its sweep per minimisation: MOPT_KERNEL_AUTO evaluates forward differences
+    literally there, and its first iterate — H, b at x0 from transforms the host formed, one damped
+    solve — is the CPU loop's to rounding; the moments form (asked for by name) is 1e5 times further
+    away.  Later iterates carry the device's own sincos (module docstring)."""
+    mo = hip_lib
+    rng = np.random.default_rng(3)
+    n = 100_000
+    src = rng.random((n, 3)) * 10.0
+    x_true = np.array([0.02, -0.03, 0.01, 0.004, -0.006, 0.005])
+    T = oracle.se3_from_x(x_true)
+    tgt = src @ T[:3, :3].T + T[:3, 3] + rng.normal(0, 0.01, (n, 3))
+    x0 = 0.5 * x_true
+    cost = mo.Point2PointCost(src, tgt)
+    xr1, _, _ = oracle.p2p_minimize(src, tgt, x0, cost_class=ob.NUMERIC_DYN, layout=ob.LAYOUT_ROW_MAJOR,
+                                    max_iter=1)
+    for variant in (mo.KERNEL_AUTO, mo.KERNEL_LITERAL):
+        cost.set_kernel_variant(variant)
+        x1, rep = mo.capi.lm_minimize([cost], [mo.JAC_NUMERIC], x0, max_iterations=1)
+        assert rep["iterations"] == 1 and np.abs(x1 - xr1).max() < 1e-12, (variant, x1 - xr1)
+        for k in (2, 3, 15):
+            x, rep = mo.capi.lm_minimize([cost], [mo.JAC_NUMERIC], x0, max_iterations=k)
+            xr, status, iters = oracle.p2p_minimize(src, tgt, x0, cost_class=ob.NUMERIC_DYN,
+                                                    layout=ob.LAYOUT_ROW_MAJOR, max_iter=k)
+            assert abs(rep["iterations"] - iters) <= 2, (k, rep, iters)
+            assert np.abs(x - xr).max() < FD_ITERATE_TOL, (k, x - xr)
+    cost.set_kernel_variant(mo.KERNEL_MOMENTS_ALWAYS)
+    xm, _ = mo.capi.lm_minimize([cost], [mo.JAC_NUMERIC], x0, max_iterations=1)
+    assert 1e-10 < np.abs(xm - xr1).max() < 1e-7, xm - xr1   # the deviation the header documents
+    # (analytic Jacobians have no step: moments under AUTO, same iterate)
+    cost.set_kernel_variant(mo.KERNEL_AUTO)
+    xa, _ = mo.capi.lm_minimize([cost], [mo.JAC_ANALYTIC], x0, max_iterations=1)
+    xar, _, _ = oracle.p2p_minimize(src, tgt, x0, cost_class=ob.ANALYTIC_DYN, layout=ob.LAYOUT_ROW_MAJOR,
+                                    max_iter=1)
+    assert np.abs(xa - xar).max() < 1e-12
     cost.close()
 
 

@@ -1094,6 +1094,40 @@ def test_icp_clouds_with_non_finite_points(hip_lib):
     assert not none.linearize(np.zeros(6), 0)[0].any()
 
 
+def test_icp_degenerate_target_clouds(hip_lib):
+    """Target clouds whose bounding box says nothing about their density — a wall (flat box), a
+    line, coincident points: the grid's resolution comes from the occupied cells, finer cells are
+    kept only where they thin the targets out (coincident points: one cell to the radius, not
+    eight with 17 x 17 empty rows to every search), and the search is exact on all of them."""
+    rng = np.random.default_rng(31)
+    n = 3000
+    wall = np.column_stack([rng.random(n) * 10.0, rng.random(n) * 6.0, np.full(n, 2.5)])
+    line = np.column_stack([rng.random(n) * 10.0, np.full(n, 1.0), np.full(n, -3.0)])
+    same = np.tile(np.array([[1.0, 2.0, 3.0]]), (n, 1))
+    for name, tgt, max_dist in (("wall", wall, 0.5), ("line", line, 0.3), ("same", same, 0.4)):
+        src = tgt[rng.permutation(n)[:2000]] + rng.normal(0, 0.3 * max_dist, (2000, 3))
+        cost = hip_lib.IcpCost(src, tgt, max_dist)
+        cell, reach, dims, origin = cost.grid()
+        if name == "same":
+            assert reach == 1 and (dims == 1).all(), (reach, dims)
+        else:
+            assert 1 <= reach <= 8 and dims.min() == 1, (name, reach, dims)
+        for x in (np.zeros(6), np.array([0.1, -0.05, 0.08, 0.01, -0.02, 0.015])):
+            m = cost.update(x)
+            got = cost.matches()
+            want = _brute_force_matches(src, tgt, x, max_dist)
+            miss = np.isnan(want[:, 0])
+            assert np.array_equal(np.isnan(got[:, 0]), miss), name
+            assert np.array_equal(got[~miss], want[~miss]) and m == int((~miss).sum()), name
+        cost.close()
+    # argument checks of the device-memory entry point: a scalar size that is neither float nor
+    # double is refused before anything is copied
+    import torch
+    half = torch.zeros((8, 3), dtype=torch.float16, device="cuda")
+    with pytest.raises(TypeError):
+        hip_lib.IcpCost(half, half, 0.5)
+
+
 def test_icp_solve_with_gpu_correspondence_search(hip_lib, oracle):
     """Real ICP: unknown correspondences, re-matched at the top of every outer LM iteration
     (cost->update(x), levenberg_marquadt_dyn.cpp:54).  Target = moved source + noise, shuffled,
