@@ -103,12 +103,19 @@ enum mopt_create_flags {
 
 /* How a sweep evaluates the reference's per-residual arithmetic. */
 enum mopt_kernel_variant {
-  MOPT_KERNEL_AUTO = 0,    /* fastest variant that meets the parity bar for the mode.  Blocking
-                              and asynchronous calls: moments, except forward differences at an x
-                              with some 0 < |x_j| < 0.08 (literal).  Device-resident loop
-                              (mopt_lm_minimize), which picks its sweep once per minimisation and
-                              not per iterate: analytic modes through moments, forward differences
-                              literally at every iterate                                      */
+  MOPT_KERNEL_AUTO = 0,    /* fastest variant that meets the parity bar (1e-6 on H, b, cost) for
+                              the mode — in the blocking and asynchronous calls: moments, except
+                              forward differences at an x with some 0 < |x_j| < 0.08 (literal).
+                              NOT in the device-resident loop (mopt_lm_minimize), which picks its
+                              sweep once per minimisation and not per iterate: there AUTO takes
+                              the moments at every iterate, so at an iterate with a small |x_j|
+                              its forward-difference Jacobian differs from mopt_cost_linearize's
+                              (and the reference's) by the amount given under _ALWAYS — the
+                              reference's own cancellation noise, which the moments lack; same
+                              fixed point, iterates within 1e-8 (first iterate at |x_j| ~ 0.005:
+                              5e-9 against 5e-14 under _LITERAL).  Ask for MOPT_KERNEL_LITERAL
+                              where the device loop must reproduce the reference's arithmetic
+                              at every iterate (18-20 % slower per sweep at 1-10 M)            */
   MOPT_KERNEL_LITERAL = 1, /* every residual and Jacobian entry formed per point, then
                               w * J^T * S * J accumulated entry by entry, as the reference does */
   MOPT_KERNEL_MOMENTS = 2, /* Jacobians that are affine in the source point (all point2point
@@ -117,11 +124,7 @@ enum mopt_kernel_variant {
                               evaluation leaves the 1e-6 bar (it lacks the reference's own
                               per-point cancellation noise eps |R p + t| / h_j) and the literal
                               evaluation is used.  That rule is the blocking and asynchronous
-                              calls'; under this variant the device-resident loop evaluates
-                              forward differences through moments at EVERY iterate — its
-                              Jacobians can then differ from mopt_cost_linearize's at a point
-                              with a small |x_j| by the amount given under _ALWAYS (the speed of
-                              the moments sweep, asked for by name; AUTO does not do this)      */
+                              calls'; the device-resident loop: as under AUTO                 */
   MOPT_KERNEL_MOMENTS_ALWAYS = 3 /* moments whatever the step size: for measurements; forward
                               differences then differ from the reference's by up to
                               2e-8 / min |x_j| relative (0.97 at |x_j| ~ 1e-8)                  */

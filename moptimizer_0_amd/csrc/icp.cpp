@@ -36,10 +36,16 @@ int buildIcpGrid(const S *src, long long n, const S *tgt, long long m, double ma
   // Cell edge: a hair above the search radius over `reach`, so that the (2 reach + 1)^3 cells around
   // a query hold every target within the radius.  reach = 1 while that leaves about one target per
   // cell; where the radius spans many targets the cells are made finer (up to 8 to the radius, and
-  // never more than ~16 M cells: a 64 MB offset table): the search's first round looks at 2 x 2 x 2 cells whatever the
+  // never more than ~64 M cells: a 256 MB offset table): the search's first round looks at 2 x 2 x 2 cells whatever the
   // radius, and what it costs goes with the targets in them.  Enlarged instead when even cells of
   // the radius's size would be more than that.
-  const double kMostCells = double(1 << 24);
+  // 2^26 cells (a 256 MB offset table at most) since round 5: a scanned surface fills a thin sheet of
+  // its bounding box, and with 2^24 a million-point scan searched within 4 point spacings stayed at one
+  // cell to the radius, ~12 targets per occupied cell — whole ICP solves 1 M x 1 M, radius 2 / 4 / 8
+  // spacings: 1.29 / 2.16 / 1.90 ms -> 1.21 / 1.30 / 1.46 (profiles/r5_icp_cells_cap.txt; 2^28 gains
+  // nothing more: finer cells speed the first round up and slow the second down)
+  static const int cells_log2 = envInt("MOPT_ICP_MAX_CELLS_LOG2", 26);  // (measurements: 20 ... 28)
+  const double kMostCells = double(1ll << (cells_log2 < 20 ? 20 : cells_log2 > 28 ? 28 : cells_log2));
   auto cellsAt = [&](double edge) {
     double cells = 1.0;
     for (int a = 0; a < 3; ++a) cells *= std::floor((hi[a] - lo[a]) / edge) + 1.0;
@@ -160,6 +166,12 @@ void fillIcpArgs(const mopt_cost *c, mopt::IcpMatchArgs<S> &a) {
   a.max_dist2 = S(mt.max_dist * mt.max_dist);
   for (int k = 0; k < 12; ++k) a.T[k] = S(k % 5 == 0 ? 1 : 0);
   a.matched = nullptr;
+  // The inner nine rows in lock step, the rings beyond row by row under the running bound: with every
+  // ring in lock step (MOPT_ICP_LOCK_RINGS=8) reach 3 took 0.154 / 0.178 / 0.229 ms per 1 M at 0.4 / 0.7 /
+  // 1.5 radii apart against 0.139 / 0.163 / 0.214, reach 8 on a surface 1.09 against 0.97, reach 2 the
+  // same (profiles/r5_icp_lock_rings.txt)
+  static const int lock_rings = envInt("MOPT_ICP_LOCK_RINGS", 1);
+  a.lock_rings = lock_rings;
 }
 template void fillIcpArgs<float>(const mopt_cost *, mopt::IcpMatchArgs<float> &);
 template void fillIcpArgs<double>(const mopt_cost *, mopt::IcpMatchArgs<double> &);

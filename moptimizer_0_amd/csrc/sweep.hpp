@@ -121,6 +121,7 @@ struct IcpMatchArgs {
   S max_dist2;
   S T[12];                // row-major [R | t] applied to the source before the search
   unsigned int *matched;  // optional: matched sources per wave, [workgroups x waves per workgroup]
+  int lock_rings;         // second round: rings of rows up to this one in lock step, the rest row by row
 };
 
 // Where a sweep kernel is launched.

@@ -836,7 +836,7 @@ __device__ __forceinline__ void icpMatchBody(const IcpMatchArgs<S> &A, const S (
     for (int r = 0; r < 4; ++r) {
       const int y = c[1] + sy + (r & 1), z = c[2] + sz + (r >> 1);
       const bool ok = inside && xa <= xb && y >= 0 && y < A.dims[1] && z >= 0 && z < A.dims[2];
-      const int row = (z * A.dims[1] + y) * A.dims[0];  // the grid has at most 2^24 cells (icp.cpp)
+      const int row = (z * A.dims[1] + y) * A.dims[0];  // the grid has at most 2^28 cells (icp.cpp)
       at_a[r] = ok ? row + xa : 0;  // (entry 0 twice: an empty run)
       at_b[r] = ok ? row + xb + 1 : 0;
     }
@@ -979,12 +979,46 @@ __device__ __forceinline__ void icpMatchBody(const IcpMatchArgs<S> &A, const S (
       // ring's (-ring, -ring) corner.  A lane is done once a ring's nearest face is out of its reach;
       // the walk ends when every lane is.  (Ring and row counters are the same for all lanes.)
       walkRows(go, inner, std::false_type());
+      // (further out fewer and fewer lanes admit anything, and what they admit depends on what the
+      // rows before have found: past ring A.lock_rings the rows are walked one after the other under
+      // the running bound, the form of rounds 3-4 — a wave skips a row none of its lanes admits)
+      auto visit = [&](int y, int z, int xa, int xb) {
+        xa = xa < 0 ? 0 : xa;
+        xb = xb >= A.dims[0] ? A.dims[0] - 1 : xb;
+        if (z < 0 || z >= A.dims[2] || y < 0 || y >= A.dims[1] || xa > xb) return;
+        const int row = (z * A.dims[1] + y) * A.dims[0];
+        const int lo = A.cell_start[row + xa], hi = A.cell_start[row + xb + 1];
+        for (int k = lo; k < hi; k += 2) {  // two candidates per step, both loads issued before either is used
+          S qa[3], qb[3];
+          const bool pair = k + 1 < hi;
+          fetch(k, qa);
+          fetch(pair ? k + 1 : k, qb);
+          consider(qa, k, true, std::false_type());
+          consider(qb, k + 1, pair, std::false_type());
+        }
+      };
       bool walking = go;
       for (int ring = 2; ring <= R; ++ring) {
         const S nearest = fmin(fmin(gapAlong(gy, -ring), gapAlong(gy, ring)),
                                fmin(gapAlong(gz, -ring), gapAlong(gz, ring)));
         walking = walking && within(sq(nearest));
         if (!__any(walking)) break;
+        if (ring > A.lock_rings) {
+          for (int u = 0; u < 8 * ring; ++u) {
+            const int side = u / (2 * ring), along = u % (2 * ring);
+            const int dy = side == 0 ? -ring + along : side == 1 ? ring : side == 2 ? ring - along : -ring;
+            const int dz = side == 0 ? -ring : side == 1 ? -ring + along : side == 2 ? ring : ring - along;
+            const S yz = sq(gapAlong(gy, dy)) + sq(gapAlong(gz, dz));
+            if (!(walking && within(yz))) continue;
+            int left = 0, right = 0;
+            for (int step = 0; step < R; ++step) {
+              left += (left == step && within(yz + sq(gx[0] + S(step) * A.cell))) ? 1 : 0;
+              right += (right == step && within(yz + sq(gx[1] + S(step) * A.cell))) ? 1 : 0;
+            }
+            visit(c[1] + dy, c[2] + dz, c[0] - left, c[0] + right);
+          }
+          continue;
+        }
         for (int base = 0; base < 8 * ring; base += 8) {
           auto outer = [&](int r, int &dy, int &dz) {
             const int u = base + r;

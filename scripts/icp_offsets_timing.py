@@ -32,7 +32,9 @@ offsets = [float(v) for v in arg("--offsets", "0,0.2,0.7,1.5").split(",")]
 for offset in offsets:
     shift = np.array([1.0, -1.0, 1.0]) / np.sqrt(3.0) * offset * max_dist
     src = tgt[rng.permutation(n)] + rng.normal(0, 0.01 * max_dist, (n, 3)) + shift
+    t0 = time.perf_counter()
     cost = mo.IcpCost(src, tgt, max_dist, dtype=dtype)
+    create_ms = (time.perf_counter() - t0) * 1e3
     x = np.zeros(6)
     cost.update(x)
     ts = []
@@ -41,6 +43,6 @@ for offset in offsets:
     dt = float(np.median(ts))
     what = ("surface, radius %s spacings" % arg("--radius-spacings", "3")) if "--surface" in sys.argv \
         else "targets per radius cube~%.0f" % per_cell
-    print("first_round=%s reach=%d %s n=%d %s offset %.2f radii: update %.3f ms, %d matched"
-          % (os.environ.get("MOPT_ICP_FIRST_ROUND", "1"), cost.grid()[1], arg("--dtype", "f64"), n, what, offset, dt * 1e3, m), flush=True)
+    print("first_round=%s reach=%d %s n=%d %s offset %.2f radii: update %.3f ms, %d matched (create %.1f ms)"
+          % (os.environ.get("MOPT_ICP_FIRST_ROUND", "1"), cost.grid()[1], arg("--dtype", "f64"), n, what, offset, dt * 1e3, m, create_ms), flush=True)
     cost.close()

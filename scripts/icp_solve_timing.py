@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""A whole ICP solve at the size of BASELINE configs 2 / 3: N sources against N targets (the moved
+"""(--surface [--shift-radii 0.5]: both scans on a wavy sheet instead of filling the box)
+A whole ICP solve at the size of BASELINE configs 2 / 3: N sources against N targets (the moved
 sources plus noise, shuffled), correspondences searched again at the top of every outer iteration
 (cost->update(x), levenberg_marquadt_dyn.cpp:54), point2point forward differences, under the
 device-resident loop (search, sweep and LM step all queued on the GPU).
@@ -20,6 +21,15 @@ max_dist = float(arg("--max-dist-spacings", "1.0")) * spacing
 rng = np.random.default_rng(9)
 src = rng.random((n, 3)) * side
 x_true = np.array([0.2 * spacing, -0.15 * spacing, 0.1 * spacing, 0.0008, -0.0005, 0.0011])
+if "--surface" in sys.argv:
+    # a scanned surface (a wavy sheet through the box), the radius in point spacings ON THE SHEET, the
+    # second scan moved by --shift-radii of the radius plus a small rotation
+    spacing = side / np.sqrt(n)
+    max_dist = float(arg("--max-dist-spacings", "4.0")) * spacing
+    uv = rng.random((n, 2)) * side
+    src = np.column_stack([uv, 10.0 * np.sin(uv[:, 0] / 10.0) * np.cos(uv[:, 1] / 15.0) + 50.0])
+    shift = float(arg("--shift-radii", "0.5")) * max_dist
+    x_true = np.array([0.6 * shift, -0.5 * shift, 0.62 * shift, 0.0008, -0.0005, 0.0011])
 th = np.linalg.norm(x_true[3:]); a = x_true[3:] / th
 K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
 R = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
