@@ -16,7 +16,7 @@ LIBDIR      = moptimizer_0_amd/lib
 LIB         = $(LIBDIR)/libmoptimizer_hip.so
 
 PUBLIC_HEADERS = include/moptimizer_hip.h include/moptimizer_amd/so3.hpp $(CSRC)/sweep.hpp \
-                 $(CSRC)/sweep_device.hpp $(CSRC)/jit_model.hpp $(CSRC)/cost_state.hpp $(CSRC)/lm_device.hpp
+                 $(CSRC)/sweep_device.hpp $(CSRC)/jit_model.hpp $(CSRC)/cost_state.hpp $(CSRC)/lm_device.hpp $(CSRC)/aql.hpp
 
 all: $(LIB)
 
@@ -41,10 +41,10 @@ $(OBJDIR)/lm_kernels.o: $(CSRC)/lm_kernels.hip $(PUBLIC_HEADERS) | $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) $(INCLUDES) -c $< -o $@
 
 OBJS = $(OBJDIR)/sweep_kernels.o $(OBJDIR)/fd_kernels.o $(OBJDIR)/icp_grid.o $(OBJDIR)/c_abi.o $(OBJDIR)/icp.o \
-       $(OBJDIR)/group.o $(OBJDIR)/jit_model.o $(OBJDIR)/device_pool.o $(OBJDIR)/combine.o $(OBJDIR)/lm.o $(OBJDIR)/lm_kernels.o
+       $(OBJDIR)/group.o $(OBJDIR)/aql.o $(OBJDIR)/jit_model.o $(OBJDIR)/device_pool.o $(OBJDIR)/combine.o $(OBJDIR)/lm.o $(OBJDIR)/lm_kernels.o
 
 $(LIB): $(OBJS) | $(LIBDIR)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -L$(ROCM)/lib -lrccl -lhiprtc -lpthread -lrt \
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -L$(ROCM)/lib -lrccl -lhiprtc -lhsa-runtime64 -lpthread -lrt \
 	    -Wl,-rpath,$(ROCM)/lib -Wl,--no-undefined
 
 oracle:

@@ -81,8 +81,15 @@ struct SweepTimer {
   mopt::LaunchSite site;
   hipEvent_t start = nullptr, stop_ev = nullptr;
   bool dispatch_stamped = false;
+  bool aql_used = false;  // the sweep kernel went to the cost's own queue (aql.hpp): so must its finalize
+  const mopt_detail::AqlSite *aql() const { return aql_used ? &site.aql : nullptr; }
+  SweepTimer(const SweepTimer &) = delete;
   SweepTimer(mopt_cost *cost, hipStream_t stream, bool stamp_dispatch = false) : c(cost) {
     site.stream = stream;
+    if (cost->aql_now.queue && stream == cost->stream && cost->profiling <= 0) {
+      site.aql = cost->aql_now;
+      site.aql_used = &aql_used;
+    }
     // Streaming (non-temporal) loads once the tiles exceed the 32 MiB of aggregate L2: measured
     // faster both beyond the 256 MiB Infinity Cache (10 M points: 82 -> 77 us) and inside it
     // (1 M points: 12.3 -> 11.6 us); below that the default policy lets sweeps re-hit L2.
@@ -280,7 +287,8 @@ int p2pLinearizeAsync(mopt_cost *c, int jac_mode, const S *x, double *d_result, 
     SweepTimer timer(c, s, true);
     MOPT_HIP_TRY(mopt::launchP2PMoments<S>(args, grid, timer.site));
     timer.stop();
-    MOPT_HIP_TRY(mopt::launchFinalizeMoments(c->d_partials, grid, basis, d_result, pub, s, c->launch_peers));
+    MOPT_HIP_TRY(mopt::launchFinalizeMoments(c->d_partials, grid, basis, d_result, pub, s, c->launch_peers,
+                                             timer.aql()));
   } else {
     // forward differences: two workgroups per CU (VALU-heavy: the second wave per SIMD pays); the
     // analytic patterns stream like the moments sweep: one (70.8 vs 72.1 us at 10 M, and half the
@@ -291,8 +299,8 @@ int p2pLinearizeAsync(mopt_cost *c, int jac_mode, const S *x, double *d_result, 
     SweepTimer timer(c, s, true);
     MOPT_HIP_TRY(mopt::launchP2PLinearizeLiteral<S>(args, jac_mode, c->cov_mode, grid, timer.site));
     timer.stop();
-    MOPT_HIP_TRY(
-        mopt::launchFinalizeDense(c->d_partials, grid, nacc, kNumParams, d_result, pub, s, c->launch_peers));
+    MOPT_HIP_TRY(mopt::launchFinalizeDense(c->d_partials, grid, nacc, kNumParams, d_result, pub, s,
+                                           c->launch_peers, timer.aql()));
   }
   return MOPT_OK;
 }
@@ -306,7 +314,7 @@ int p2pCostAsync(mopt_cost *c, const S *x, double *d_sum, hipStream_t s,
   SweepTimer timer(c, s, true);
   MOPT_HIP_TRY(mopt::launchP2PCost<S>(args, grid, timer.site));
   timer.stop();
-  MOPT_HIP_TRY(mopt::launchFinalizeCost(c->d_partials, grid, d_sum, pub, s, c->launch_peers));
+  MOPT_HIP_TRY(mopt::launchFinalizeCost(c->d_partials, grid, d_sum, pub, s, c->launch_peers, timer.aql()));
   return MOPT_OK;
 }
 
@@ -372,8 +380,8 @@ int reprojLinearizeAsync(mopt_cost *c, int jac_mode, const double *x, double *d_
   SweepTimer timer(c, s, true);
   MOPT_HIP_TRY(mopt::launchReprojLinearize(args, c->cov_mode, grid, timer.site));
   timer.stop();
-  MOPT_HIP_TRY(
-      mopt::launchFinalizeDense(c->d_partials, grid, nacc, kNumParams, d_result, pub, s, c->launch_peers));
+  MOPT_HIP_TRY(mopt::launchFinalizeDense(c->d_partials, grid, nacc, kNumParams, d_result, pub, s,
+                                         c->launch_peers, timer.aql()));
   return MOPT_OK;
 }
 
@@ -385,7 +393,7 @@ int reprojCostAsync(mopt_cost *c, const double *x, double *d_sum, hipStream_t s,
   SweepTimer timer(c, s, true);
   MOPT_HIP_TRY(mopt::launchReprojCost(args, grid, timer.site));
   timer.stop();
-  MOPT_HIP_TRY(mopt::launchFinalizeCost(c->d_partials, grid, d_sum, pub, s, c->launch_peers));
+  MOPT_HIP_TRY(mopt::launchFinalizeCost(c->d_partials, grid, d_sum, pub, s, c->launch_peers, timer.aql()));
   return MOPT_OK;
 }
 
@@ -593,6 +601,16 @@ int waitPublished(mopt_cost *c, unsigned long long sequence) {
   const auto started = std::chrono::steady_clock::now();
   while (__atomic_load_n(c->h_flag, __ATOMIC_ACQUIRE) != sequence) {
     if ((++spins & 0x3fff) == 0) {
+      if (c->waiting_direct) {
+        // the sweep went through the cost's own queue (aql.hpp): nothing on the HIP stream to ask; a
+        // faulted kernel reaches the queue's error callback
+        if (mopt_detail::aqlFaulted(c->aql_queue))
+          return fail(MOPT_ERR_HIP, "sweep failed: the direct-dispatch queue reported an error");
+        if (std::chrono::steady_clock::now() - started > std::chrono::seconds(60))
+          return fail(MOPT_ERR_HIP, "timed out waiting for the sweep result (60 s)");
+        __builtin_ia32_pause();
+        continue;
+      }
       const hipError_t q = hipStreamQuery(c->stream);
       if (q == hipSuccess) {
         if (__atomic_load_n(c->h_flag, __ATOMIC_ACQUIRE) == sequence) break;
@@ -622,9 +640,50 @@ int waitPublished(mopt_cost *c, unsigned long long sequence) {
 // after this call's kernels are queued, while they run; its status is not used.
 void boundCommandBatch(mopt_cost *c) {
   static const int every = envInt("MOPT_MARKER_EVERY", 32);  // sweeps; a huge value switches it off
+  if (c->waiting_direct) return;  // (the sweep bypassed the runtime: aql.hpp)
   if (++c->launches_since_marker < every) return;
   c->launches_since_marker = 0;
   (void)hipStreamQuery(c->stream);
+}
+
+// Where the blocking sweep about to be launched goes: the cost's own queue (aql.hpp) when nothing
+// about the call needs the HIP stream — no combine that launches on it (RCCL), no profiled launches, a
+// model whose sweeps the direct path knows (point2point, reprojection) — else the stream.  A switch
+// of path waits once for whatever the other path still has queued for this cost.
+void chooseDispatchPath(mopt_cost *c) {
+  c->aql_now = mopt_detail::AqlSite();
+  // (a cost with a correspondence search stays on the stream: its update(x) is queued there every
+  // outer iteration, and a sweep on another queue would have to wait for it with a synchronisation)
+  const bool eligible = (c->model == kModelPoint2Point || c->model == kModelReprojection) &&
+                        c->combine.mode == MOPT_COMBINE_NONE && c->profiling <= 0 && !c->comm &&
+                        !c->matcher;
+  if (eligible && !c->aql_tried) {
+    c->aql_tried = true;
+    c->aql_queue = mopt_detail::aqlAcquireQueue(c->device);
+    if (c->aql_queue) {
+      mopt_detail::AqlSite site;
+      site.queue = c->aql_queue;
+      site.device = c->device;
+      if (!mopt::aqlFinalizersLoaded(site)) c->aql_queue = nullptr;
+    }
+  }
+  if (eligible && c->aql_queue && !mopt_detail::aqlFaulted(c->aql_queue)) {
+    if (c->hip_pending) {  // e.g. a correspondence search queued on the stream: the sweep reads its output
+      (void)hipStreamSynchronize(c->stream);
+      c->hip_pending = false;
+    }
+    c->aql_now.queue = c->aql_queue;
+    c->aql_now.device = c->device;
+    c->aql_touched = true;
+    c->waiting_direct = true;
+    return;
+  }
+  if (c->aql_touched && c->aql_queue) {  // (a superseded prefetch may still be queued there)
+    (void)mopt_detail::aqlDrain(c->aql_queue);
+    c->aql_touched = false;
+  }
+  c->hip_pending = true;
+  c->waiting_direct = false;
 }
 
 mopt::HostPublish nextPublish(mopt_cost *c, int offset) {
@@ -685,9 +744,12 @@ int blockingSweep(mopt_cost *c, bool cost_only, int jac_mode, const void *x) {
   const int offset = cost_only ? costOffset(c) : 0;
   const int count = cost_only ? 1 : resultCount(c);
   c->stat_sweeps += 1;
+  chooseDispatchPath(c);
   auto launch = [&](const mopt::HostPublish &pub) {
-    return cost_only ? costAsyncImpl(c, x, c->d_result + offset, c->stream, pub)
-                     : linearizeAsyncImpl(c, jac_mode, x, c->d_result, c->stream, pub);
+    const int rc = cost_only ? costAsyncImpl(c, x, c->d_result + offset, c->stream, pub)
+                             : linearizeAsyncImpl(c, jac_mode, x, c->d_result, c->stream, pub);
+    c->aql_now = mopt_detail::AqlSite();
+    return rc;
   };
   switch (c->combine.mode) {
     case MOPT_COMBINE_RCCL: {  // also for a 1-rank communicator: same code path as N ranks
@@ -1187,8 +1249,10 @@ int launchPublishedSweep(mopt_cost *c, bool cost_only, int jac_mode, const void 
   const mopt::HostPublish pub = nextPublish(c, offset);
   c->stat_sweeps += 1;
   *sequence_out = pub.sequence;
+  chooseDispatchPath(c);
   const int rc = cost_only ? costAsyncImpl(c, x, c->d_result + offset, c->stream, pub)
                            : linearizeAsyncImpl(c, jac_mode, x, c->d_result, c->stream, pub);
+  c->aql_now = mopt_detail::AqlSite();
   if (rc == MOPT_OK) boundCommandBatch(c);
   return rc;
 }
@@ -1268,7 +1332,12 @@ int commonCreate(mopt_cost *c, int device) {
 
 hipError_t quiesceCost(mopt_cost *c) {
   hipError_t first = hipSuccess;
+  if (c->aql_touched && c->aql_queue) {  // the finalize kernel of the last direct sweep may still be retiring
+    (void)mopt_detail::aqlDrain(c->aql_queue);
+    c->aql_touched = false;
+  }
   if (c->stream) first = hipStreamSynchronize(c->stream);
+  c->hip_pending = false;
   c->own_async_pending = false;
   if (c->foreign_pending && c->foreign_done) {
     const hipError_t e = hipEventSynchronize(c->foreign_done);
@@ -1732,6 +1801,7 @@ namespace {
 int markForeignStream(mopt_cost *c, hipStream_t s) {
   if (s == c->stream) {
     c->own_async_pending = true;
+    c->hip_pending = true;
     return MOPT_OK;
   }
   if (!c->foreign_done)

@@ -128,6 +128,17 @@ struct mopt_cost {
   ShardCombine combine;  // latency-optimised alternatives to the RCCL all-reduce (combine.cpp)
   // set around the launches of one sweep: the finalize kernel then also adds over the ranks
   const mopt::PeerCombine *launch_peers = nullptr;
+  // Direct dispatch of the blocking sweeps (aql.hpp).  `aql_queue`: this cost's queue of the device's
+  // pool (drawn on first use); `aql_now`: set around the launches of a sweep that may go there;
+  // `aql_touched`: something was dispatched there since the queue was last drained (memory of this
+  // cost must not be recycled before a drain); `hip_pending`: something was queued on `stream` that
+  // a direct sweep would have to wait for (a path switch synchronises once).
+  mopt_detail::AqlQueue *aql_queue = nullptr;
+  bool aql_tried = false;
+  mopt_detail::AqlSite aql_now;
+  bool aql_touched = false;
+  bool hip_pending = false;
+  bool waiting_direct = false;  // the sweep being waited for went through the direct path
 
   double cov[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // row-major, stride 3 (m <= 3), as double
   double cov_m[mopt::kMaxWideOutputs * mopt::kMaxWideOutputs] = {1};  // row-major m x m compact (generic models)

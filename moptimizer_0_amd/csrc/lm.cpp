@@ -104,6 +104,9 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
   int rc = ensureWorkspace(lead);
   if (rc != MOPT_OK) return rc;
   hipStream_t s = lead->stream;
+  // the loop's kernels go to the HIP stream: a later blocking sweep of these costs on the direct
+  // path (aql.hpp) waits for whatever the loop leaves queued (its window of early-exit launches)
+  for (int k = 0; k < num_costs; ++k) costs[k]->hip_pending = true;
 
   mopt::LmProblem problem;
   problem.num_costs = num_costs;

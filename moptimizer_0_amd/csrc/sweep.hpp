@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include "aql.hpp"
 
 #include <cstdint>
 
@@ -131,6 +132,10 @@ struct LaunchSite {
   // when set, the sweep kernel's own dispatch is timestamped into these events (hipExtLaunch):
   // exactly the kernel's duration, as a kernel trace reports it
   hipEvent_t time_start = nullptr, time_stop = nullptr;
+  // direct dispatch (aql.hpp): when `aql.queue` is set the launch helper writes the packet itself and
+  // reports it through *aql_used; when that fails (kernel not found) it launches on `stream` instead
+  mopt_detail::AqlSite aql;
+  bool *aql_used = nullptr;
 };
 
 // Optional hand-over of a finalize kernel's 43 (or 1) results straight into mapped host memory:
@@ -330,15 +335,22 @@ hipError_t launchReprojCost(const ReprojSweepArgs &args, int grid, const LaunchS
 
 // partials[grid][nacc] -> result[n*n + n + 1] (H column-major | b | sum_sq)
 // `peers` (optional): add the sums over the ranks inside the same kernel (PeerCombine above)
+// `aql` (optional): the queue the sweep before it went to (aql.hpp) — the finalize kernel must follow
+// it there; the three kernels are looked up beforehand (aqlFinalizersLoaded), so this cannot fail over
 hipError_t launchFinalizeDense(const double *partials, int grid, int nacc, int n, double *result,
                                const HostPublish &pub, hipStream_t stream,
-                               const PeerCombine *peers = nullptr);
+                               const PeerCombine *peers = nullptr,
+                               const mopt_detail::AqlSite *aql = nullptr);
 hipError_t launchFinalizeMoments(const double *partials, int grid, const AffineBasis &basis,
                                  double *result, const HostPublish &pub, hipStream_t stream,
-                                 const PeerCombine *peers = nullptr);
+                                 const PeerCombine *peers = nullptr,
+                                 const mopt_detail::AqlSite *aql = nullptr);
 hipError_t launchFinalizeCost(const double *partials, int grid, double *result,
                               const HostPublish &pub, hipStream_t stream,
-                              const PeerCombine *peers = nullptr);
+                              const PeerCombine *peers = nullptr,
+                              const mopt_detail::AqlSite *aql = nullptr);
+// true when the three finalize kernels above can be dispatched directly on `site`'s device
+bool aqlFinalizersLoaded(const mopt_detail::AqlSite &site);
 // Small parametric models: one launch computes the workgroup partial rows of the linearization
 // (or of the cost when cost_only); finish with launchFinalizeDense(n) / launchFinalizeCost.
 template <typename S>

@@ -202,6 +202,12 @@ __device__ __forceinline__ int costOfBlock(const ResidentSweepSet &set) {
 // arguments are preloaded into SGPRs at wave launch); optionally a timestamped dispatch
 template <typename Kernel, typename S>
 hipError_t launchTiled(Kernel kernel, int grid, const LaunchSite &site, const P2PSweepArgs<S> &args) {
+  if (site.aql.queue && site.aql_used && !site.time_start &&
+      mopt_detail::aqlLaunch(site.aql, kernel, uint32_t(grid), uint32_t(kBlockThreads), args.tiles,
+                             args.num_tiles, args)) {
+    *site.aql_used = true;
+    return hipSuccess;
+  }
   if (site.time_start && site.time_stop)
     hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(kBlockThreads), 0, site.stream, site.time_start,
                           site.time_stop, 0, args.tiles, args.num_tiles, args);

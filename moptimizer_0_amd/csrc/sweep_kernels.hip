@@ -1584,6 +1584,11 @@ hipError_t launchRelayoutReproj(const double *points_xyzw, const int32_t *pixels
 namespace {
 template <typename Kernel, typename Args>
 hipError_t launchSweep(Kernel kernel, int grid, const LaunchSite &site, const Args &args) {
+  if (site.aql.queue && site.aql_used && !site.time_start &&
+      mopt_detail::aqlLaunch(site.aql, kernel, uint32_t(grid), uint32_t(kBlockThreads), args)) {
+    *site.aql_used = true;
+    return hipSuccess;
+  }
   if (site.time_start && site.time_stop)
     hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(kBlockThreads), 0, site.stream, site.time_start,
                           site.time_stop, 0, args);
@@ -1667,12 +1672,24 @@ hipError_t launchReprojCost(const ReprojSweepArgs &args, int grid, const LaunchS
   return launchSweep(reprojKernel<kCovIdentity, true>, grid, site, args);
 }
 
+bool aqlFinalizersLoaded(const mopt_detail::AqlSite &site) {
+  return site.queue &&
+         mopt_detail::aqlLookup(site.device, reinterpret_cast<const void *>(finalizeDenseKernel)) &&
+         mopt_detail::aqlLookup(site.device, reinterpret_cast<const void *>(finalizeMomentsKernel)) &&
+         mopt_detail::aqlLookup(site.device, reinterpret_cast<const void *>(finalizeCostKernel));
+}
+
 hipError_t launchFinalizeDense(const double *partials, int grid, int nacc, int n, double *result,
                                const HostPublish &pub, hipStream_t stream,
-                               const PeerCombine *peers) {
+                               const PeerCombine *peers, const mopt_detail::AqlSite *aql) {
   if (n < 1 || n > kMaxWideParams || (nacc != n * (n + 1) / 2 + n + 1 && nacc != n * n + n + 1))
     return hipErrorInvalidValue;
   if (peers && peers->num_ranks > 0 && n * n + n + 1 > kSlotData) return hipErrorInvalidValue;
+  if (aql)  // the sweep went to this queue: so must its finalize (looked up beforehand)
+    return mopt_detail::aqlLaunch(*aql, finalizeDenseKernel, 1u, uint32_t(kFinalThreads), partials, grid,
+                                  nacc, n, result, pub, peers ? *peers : PeerCombine())
+               ? hipSuccess
+               : hipErrorLaunchFailure;
   hipLaunchKernelGGL(finalizeDenseKernel, dim3(1), dim3(kFinalThreads), 0, stream, partials, grid,
                      nacc, n, result, pub, peers ? *peers : PeerCombine());
   return hipGetLastError();
@@ -1680,7 +1697,12 @@ hipError_t launchFinalizeDense(const double *partials, int grid, int nacc, int n
 
 hipError_t launchFinalizeMoments(const double *partials, int grid, const AffineBasis &basis,
                                  double *result, const HostPublish &pub, hipStream_t stream,
-                                 const PeerCombine *peers) {
+                                 const PeerCombine *peers, const mopt_detail::AqlSite *aql) {
+  if (aql)
+    return mopt_detail::aqlLaunch(*aql, finalizeMomentsKernel, 1u, uint32_t(kFinalThreads), partials, grid,
+                                  basis, result, pub, peers ? *peers : PeerCombine())
+               ? hipSuccess
+               : hipErrorLaunchFailure;
   hipLaunchKernelGGL(finalizeMomentsKernel, dim3(1), dim3(kFinalThreads), 0, stream, partials,
                      grid, basis, result, pub, peers ? *peers : PeerCombine());
   return hipGetLastError();
@@ -1688,7 +1710,12 @@ hipError_t launchFinalizeMoments(const double *partials, int grid, const AffineB
 
 hipError_t launchFinalizeCost(const double *partials, int grid, double *result,
                               const HostPublish &pub, hipStream_t stream,
-                              const PeerCombine *peers) {
+                              const PeerCombine *peers, const mopt_detail::AqlSite *aql) {
+  if (aql)
+    return mopt_detail::aqlLaunch(*aql, finalizeCostKernel, 1u, uint32_t(kFinalThreads), partials, grid,
+                                  result, pub, peers ? *peers : PeerCombine())
+               ? hipSuccess
+               : hipErrorLaunchFailure;
   hipLaunchKernelGGL(finalizeCostKernel, dim3(1), dim3(kFinalThreads), 0, stream, partials, grid,
                      result, pub, peers ? *peers : PeerCombine());
   return hipGetLastError();

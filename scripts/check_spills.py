@@ -71,7 +71,60 @@ def kernel_metadata(stem, workdir):
             kernels.append(current)
         elif current is not None and key in FIELDS:
             current[key] = int(value)
-    return [k for k in kernels if "sgpr_count" in k]
+    kernels = [k for k in kernels if "sgpr_count" in k]
+    # kernel arguments as the code object lays them out: (offset, size, value_kind) per kernel, for the
+    # check of the direct-dispatch path's own packing (csrc/aql.cpp)
+    by_name = {k["name"]: k for k in kernels}
+    for record in re.split(r"\n\s+- \.agpr_count:", notes)[1:]:
+        names = [n for n in re.findall(r"\.name:\s+(_Z\S+)", record) if n in by_name]
+        if not names:
+            continue
+        args = re.findall(r"\.offset:\s+(\d+)\n\s+\.size:\s+(\d+)\n\s+\.value_kind:\s+(\S+)", record)
+        by_name[names[-1]]["args"] = [(int(o), int(z), kind) for o, z, kind in args]
+        m = re.search(r"\.kernarg_segment_size:\s+(\d+)", record)
+        by_name[names[-1]]["kernarg_segment_size"] = int(m.group(1)) if m else 0
+    return kernels
+
+
+# code object v5 implicit arguments, relative to the first one, as csrc/aql.cpp fills them
+IMPLICIT_LAYOUT = {"hidden_block_count_x": 0, "hidden_block_count_y": 4, "hidden_block_count_z": 8,
+                   "hidden_group_size_x": 12, "hidden_group_size_y": 14, "hidden_group_size_z": 16,
+                   "hidden_remainder_x": 18, "hidden_remainder_y": 20, "hidden_remainder_z": 22,
+                   "hidden_global_offset_x": 40, "hidden_global_offset_y": 48, "hidden_global_offset_z": 56,
+                   "hidden_grid_dims": 64}
+# implicit arguments a dispatcher would have to provide real objects for: no kernel of the library may use them
+IMPLICIT_UNSUPPORTED = ("hidden_printf_buffer", "hidden_hostcall_buffer", "hidden_multigrid_sync_arg",
+                        "hidden_heap_v1", "hidden_default_queue", "hidden_completion_action",
+                        "hidden_dynamic_lds_size", "hidden_queue_ptr")
+
+
+def check_kernarg_layout(kernel):
+    """Problems (strings) with a kernel's argument layout as the direct-dispatch path assumes it: explicit
+    arguments first, each at its natural alignment (nothing to check: that is the ABI), then — from the
+    next 8-byte boundary — the implicit block in IMPLICIT_LAYOUT's order; everything inside one
+    4 KB argument slot."""
+    problems = []
+    args = kernel.get("args", [])
+    explicit_end, first_hidden = 0, None
+    for offset, size, kind in args:
+        if kind.startswith("hidden_"):
+            if first_hidden is None:
+                first_hidden = offset
+        else:
+            if first_hidden is not None:
+                problems.append("explicit argument behind an implicit one")
+            explicit_end = max(explicit_end, offset + size)
+    if first_hidden is not None:
+        if first_hidden != (explicit_end + 7) // 8 * 8:
+            problems.append("implicit block at %d, explicit arguments end at %d" % (first_hidden, explicit_end))
+        for offset, size, kind in args:
+            if kind in IMPLICIT_LAYOUT and offset - first_hidden != IMPLICIT_LAYOUT[kind]:
+                problems.append("%s at +%d, expected +%d" % (kind, offset - first_hidden, IMPLICIT_LAYOUT[kind]))
+            if kind in IMPLICIT_UNSUPPORTED:
+                problems.append("uses %s" % kind)
+    if kernel.get("kernarg_segment_size", 0) > 4096 or explicit_end > 3072:
+        problems.append("argument segment of %d bytes (explicit %d)" % (kernel.get("kernarg_segment_size", 0), explicit_end))
+    return problems
 
 
 def demangle(names):
@@ -106,6 +159,10 @@ def main():
                 elif sgpr_spills:
                     status = "known"
                     accepted += 1
+                for problem in check_kernarg_layout(k):
+                    # (every kernel is checked; the direct path dispatches the blocking sweeps and finalizes)
+                    print("KERNARG %s.hip  %s: %s" % (stem, name, problem))
+                    bad += 1
                 if status != "ok" or args.table:
                     print("%-6s %s.hip  sgpr %3d (spill %3d)  vgpr %3d (spill %3d)  scratch %4d  %s" % (
                         status, stem, k["sgpr_count"], sgpr_spills, k["vgpr_count"],
