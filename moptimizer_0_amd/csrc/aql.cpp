@@ -35,12 +35,15 @@ static_assert(offsetof(ImplicitArgs, group_size) == 12 && offsetof(ImplicitArgs,
 
 constexpr size_t kArgSlotBytes = 4096;  // >= kAqlMaxExplicitArgs + the 256-byte implicit block
 constexpr int kArgSlots = 256;          // a slot comes round again after this many dispatches of its queue
-constexpr int kQueuesPerDevice = 4;
+constexpr int kQueuesPerDevice = 2;  // (two linked costs sweep side by side; every queue is a hardware queue of the GPU)
 constexpr uint32_t kQueuePackets = 1024;
 
 struct AqlQueue {
   hsa_queue_t *queue = nullptr;
   hsa_signal_t drained{};             // completion signal of the drain's barrier packet
+  hsa_signal_t stamped{};             // completion signal of the last timed dispatch
+  hsa_agent_t agent{};
+  const void *stamp_owner = nullptr;  // whose timed dispatch the signal belongs to (null: none outstanding)
   unsigned char *arg_ring = nullptr;  // device memory, host-writable
   uint64_t dispatched = 0;            // packets written (this library is the only producer)
   std::mutex mutex;                   // a queue is shared by the costs that drew it
@@ -174,6 +177,11 @@ bool createQueue(DeviceState &d, AqlQueue &q) {
   }
   q.arg_ring = static_cast<unsigned char *>(ring);
   if (hsa_signal_create(0, 0, nullptr, &q.drained) != HSA_STATUS_SUCCESS) q.drained.handle = 0;
+  q.agent = d.gpu;
+  // (timestamps are written for dispatches that carry a completion signal only: the timed ones)
+  if (hsa_signal_create(0, 0, nullptr, &q.stamped) != HSA_STATUS_SUCCESS ||
+      hsa_amd_profiling_set_profiler_enabled(q.queue, 1) != HSA_STATUS_SUCCESS)
+    q.stamped.handle = 0;
   return true;
 }
 
@@ -295,8 +303,29 @@ bool aqlDrain(AqlQueue *q) {
   return true;
 }
 
+double aqlDispatchNanoseconds(AqlQueue *q, const void *timed_for) {
+  if (!q || !q->stamped.handle || !timed_for) return -1.0;
+  std::lock_guard<std::mutex> lock(q->mutex);
+  if (q->stamp_owner != timed_for) return -1.0;
+  const auto started = std::chrono::steady_clock::now();
+  while (hsa_signal_wait_scacquire(q->stamped, HSA_SIGNAL_CONDITION_LT, 1, 1000000, HSA_WAIT_STATE_ACTIVE) >= 1) {
+    if (q->faulted.load(std::memory_order_acquire)) return -1.0;
+    if (std::chrono::steady_clock::now() - started > std::chrono::seconds(10)) return -1.0;
+  }
+  q->stamp_owner = nullptr;
+  hsa_amd_profiling_dispatch_time_t t{};
+  if (hsa_amd_profiling_get_dispatch_time(q->agent, q->stamped, &t) != HSA_STATUS_SUCCESS || t.end < t.start)
+    return -1.0;
+  static const double ns_per_tick = [] {
+    uint64_t hz = 0;
+    if (hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP_FREQUENCY, &hz) != HSA_STATUS_SUCCESS || hz == 0) return 10.0;
+    return 1e9 / double(hz);
+  }();
+  return double(t.end - t.start) * ns_per_tick;
+}
+
 bool aqlDispatch(AqlQueue *q, const AqlKernel *kernel, uint32_t grid, uint32_t block, const void *args,
-                 size_t args_bytes) {
+                 size_t args_bytes, const void *timed_for) {
   if (!q || !kernel || q->faulted.load(std::memory_order_acquire)) return false;
   const size_t implicit_at = (args_bytes + 7) & ~size_t(7);
   if (args_bytes > kernel->kernarg_size || kernel->kernarg_size > kArgSlotBytes ||
@@ -347,6 +376,11 @@ bool aqlDispatch(AqlQueue *q, const AqlKernel *kernel, uint32_t grid, uint32_t b
   packet->kernarg_address = slot;
   packet->reserved2 = 0;
   packet->completion_signal.handle = 0;
+  if (timed_for && q->stamped.handle && (!q->stamp_owner || q->stamp_owner == timed_for)) {
+    hsa_signal_store_relaxed(q->stamped, 1);
+    packet->completion_signal = q->stamped;
+    q->stamp_owner = timed_for;
+  }
   constexpr uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) |
                               (1 << HSA_PACKET_HEADER_BARRIER) |
                               (HSA_FENCE_SCOPE_AGENT << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |

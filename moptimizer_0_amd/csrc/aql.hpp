@@ -58,8 +58,14 @@ const AqlKernel *aqlLookup(int device, const void *host_function);
 // One dispatch: `grid` workgroups of `block` threads; `args` are the explicit arguments as the
 // compiler lays them out (packKernelArgs).  Returns false (nothing queued) when the arguments do
 // not fit the kernel's segment or the queue has faulted.
+// `timed_for` (a cost, or null): the dispatch carries the queue's profiling signal on that owner's
+// behalf; aqlDispatchNanoseconds reads its start and end timestamps afterwards (one timed dispatch at a
+// time per queue — the blocking sweeps' use; a request while another is outstanding is not timed).
 bool aqlDispatch(AqlQueue *queue, const AqlKernel *kernel, uint32_t grid, uint32_t block,
-                 const void *args, size_t args_bytes);
+                 const void *args, size_t args_bytes, const void *timed_for = nullptr);
+// Duration of the queue's last timed dispatch as the packet processor stamped it (waits for it to
+// complete); a negative value when there is none or the timestamps cannot be read.
+double aqlDispatchNanoseconds(AqlQueue *queue, const void *timed_for);
 // true once the queue has reported an error (a faulted kernel): waits on it must give up
 bool aqlFaulted(const AqlQueue *queue);
 // Waits until everything dispatched on the queue so far has completed and its writes are visible
@@ -90,6 +96,7 @@ inline size_t packKernelArgs(unsigned char (&buffer)[kAqlMaxExplicitArgs], const
 struct AqlSite {
   AqlQueue *queue = nullptr;
   int device = 0;
+  const void *timed_for = nullptr;  // stamp this dispatch (profiling) for this owner
 };
 
 // hipLaunchKernelGGL's shape for the direct path; false = not dispatched (the caller falls back to
@@ -144,7 +151,7 @@ inline bool aqlLaunch(const AqlSite &site, void (*kernel)(Params...), uint32_t g
   const size_t bytes =
       packKernelArgs(buffer, static_cast<typename std::decay<Params>::type>(args)...);
   if (bytes == 0 && sizeof...(Args) > 0) return false;
-  return aqlDispatch(site.queue, k, grid, block, buffer, bytes);
+  return aqlDispatch(site.queue, k, grid, block, buffer, bytes, site.timed_for);
 }
 
 }  // namespace mopt_detail

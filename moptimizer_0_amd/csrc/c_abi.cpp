@@ -82,11 +82,17 @@ struct SweepTimer {
   hipEvent_t start = nullptr, stop_ev = nullptr;
   bool dispatch_stamped = false;
   bool aql_used = false;  // the sweep kernel went to the cost's own queue (aql.hpp): so must its finalize
-  const mopt_detail::AqlSite *aql() const { return aql_used ? &site.aql : nullptr; }
+  mopt_detail::AqlSite finalize_site;  // the same queue, never timed (the timing is the sweep's)
+  const mopt_detail::AqlSite *aql() {
+    if (!aql_used) return nullptr;
+    finalize_site = site.aql;
+    finalize_site.timed_for = nullptr;
+    return &finalize_site;
+  }
   SweepTimer(const SweepTimer &) = delete;
   SweepTimer(mopt_cost *cost, hipStream_t stream, bool stamp_dispatch = false) : c(cost) {
     site.stream = stream;
-    if (cost->aql_now.queue && stream == cost->stream && cost->profiling <= 0) {
+    if (cost->aql_now.queue && stream == cost->stream) {
       site.aql = cost->aql_now;
       site.aql_used = &aql_used;
     }
@@ -97,6 +103,15 @@ struct SweepTimer {
     const size_t bytes = size_t(cost->count) * 6 * size_t(cost->scalar_bytes);
     site.streaming = force == 2 || (force != 1 && bytes > (size_t(32) << 20));
     if (cost->profiling <= 0 || (cost->profiling_tick++ % cost->profiling) != 0) return;
+    if (site.aql.queue && stamp_dispatch) {
+      // the direct path stamps its own dispatch: the packet processor's start and end of this very
+      // kernel, read after the call's results have arrived (blockingSweep)
+      site.aql.timed_for = cost;
+      cost->aql_timed = true;
+      return;
+    }
+    site.aql = mopt_detail::AqlSite();  // (a sweep timed with recorded events goes to the stream)
+    site.aql_used = nullptr;
     if (cost->pending_events.size() >= 4096 && resolvePendingEvents(cost) != MOPT_OK) return;
     hipEvent_t ev[2] = {nullptr, nullptr};
     for (auto &e : ev) {
@@ -654,9 +669,13 @@ void chooseDispatchPath(mopt_cost *c) {
   c->aql_now = mopt_detail::AqlSite();
   // (a cost with a correspondence search stays on the stream: its update(x) is queued there every
   // outer iteration, and a sweep on another queue would have to wait for it with a synchronisation)
+  // (a cost that has a combine transport attached is a shard of a multi-rank job: it stays on the
+  // stream whatever mode is selected now — its ranks may share a GPU, where every extra hardware
+  // queue per process counts; 4 ranks + a parent with two queues each oversubscribed the GPU's
+  // queues and the combines' bounded waits ran out, profiles/NOTES.md round 5)
+  const bool sharded = c->combine.host_block != nullptr || c->combine.peer_attached || c->comm != nullptr;
   const bool eligible = (c->model == kModelPoint2Point || c->model == kModelReprojection) &&
-                        c->combine.mode == MOPT_COMBINE_NONE && c->profiling <= 0 && !c->comm &&
-                        !c->matcher;
+                        c->combine.mode == MOPT_COMBINE_NONE && !sharded && !c->matcher;
   if (eligible && !c->aql_tried) {
     c->aql_tried = true;
     c->aql_queue = mopt_detail::aqlAcquireQueue(c->device);
@@ -793,10 +812,20 @@ int blockingSweep(mopt_cost *c, bool cost_only, int jac_mode, const void *x) {
     }
     default: {
       mopt::HostPublish pub = nextPublish(c, offset);
+      c->aql_timed = false;
       int rc = launch(pub);
       if (rc != MOPT_OK) return rc;
       boundCommandBatch(c);
-      return waitPublished(c, pub.sequence);
+      rc = waitPublished(c, pub.sequence);
+      if (c->aql_timed) {  // a profiled sweep on the direct path: its dispatch's own timestamps
+        c->aql_timed = false;
+        const double ns = rc == MOPT_OK ? mopt_detail::aqlDispatchNanoseconds(c->aql_queue, c) : -1.0;
+        if (ns >= 0.0) {
+          c->sweep_ms_total += ns * 1e-6;
+          c->sweep_launches += 1;
+        }
+      }
+      return rc;
     }
   }
 }

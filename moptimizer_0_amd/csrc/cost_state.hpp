@@ -139,6 +139,7 @@ struct mopt_cost {
   bool aql_touched = false;
   bool hip_pending = false;
   bool waiting_direct = false;  // the sweep being waited for went through the direct path
+  bool aql_timed = false;       // ... and its dispatch is being timed (profiling)
 
   double cov[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // row-major, stride 3 (m <= 3), as double
   double cov_m[mopt::kMaxWideOutputs * mopt::kMaxWideOutputs] = {1};  // row-major m x m compact (generic models)

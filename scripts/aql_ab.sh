@@ -2,7 +2,7 @@
 # The blocking sweeps through the library's own AQL queues (MOPT_AQL=1, default) against the HIP stream
 # (MOPT_AQL=0): default bench line and the driver's command, interleaved, same box.
 mkdir -p gpurun_out/r5
-for rep in 1 2 3; do for a in 0 1; do
+for rep in 1 2; do for a in 0 1; do
   for form in "--steps 200 --warmup 20" "--steps 20 --warmup 5"; do
     MOPT_AQL=$a python3 bench.py $form --cpu-seconds 1 2>/dev/null > gpurun_out/r5/aqlab.json
     python3 - "$a" "$rep" "$form" <<'PY'
