@@ -360,6 +360,10 @@ def main():
     # host / peer combines work between ranks that share a GPU; RCCL refuses to.  Everything else —
     # shards, barriers, timing, the JSON line — is the real code path.
     backend = os.environ.get("MOPT_BENCH_BACKEND", "nccl")
+    if world > 1 and backend != "nccl":
+        # ranks sharing a GPU: no extra hardware queues per rank (the library's direct-dispatch queues;
+        # with one rank per GPU — the real thing — sharded costs use them like any other)
+        os.environ.setdefault("MOPT_AQL_SHARDED", "0")
     if not torch.cuda.is_available():
         raise SystemExit("rank %d of %d: no HIP device is visible — bench.py measures the HIP path "
                          "and has no CPU substitute for it" % (rank, world))

@@ -669,13 +669,20 @@ void chooseDispatchPath(mopt_cost *c) {
   c->aql_now = mopt_detail::AqlSite();
   // (a cost with a correspondence search stays on the stream: its update(x) is queued there every
   // outer iteration, and a sweep on another queue would have to wait for it with a synchronisation)
-  // (a cost that has a combine transport attached is a shard of a multi-rank job: it stays on the
-  // stream whatever mode is selected now — its ranks may share a GPU, where every extra hardware
-  // queue per process counts; 4 ranks + a parent with two queues each oversubscribed the GPU's
-  // queues and the combines' bounded waits ran out, profiles/NOTES.md round 5)
+  // A shard of a multi-rank job (a combine transport attached) takes the direct path like any other
+  // cost — the host-slot and peer combines live inside the finalize kernel and its wait; RCCL needs
+  // the stream — unless MOPT_AQL_SHARDED=0: ranks that SHARE a GPU (rehearsals, tests) add two
+  // hardware queues per process on it, and 4 ranks + their parent oversubscribed the GPU's queues
+  // until the combines' bounded waits ran out (profiles/NOTES.md round 5).
+  static const bool sharded_allowed = [] {
+    const char *v = std::getenv("MOPT_AQL_SHARDED");
+    return !(v && v[0] == '0');
+  }();
   const bool sharded = c->combine.host_block != nullptr || c->combine.peer_attached || c->comm != nullptr;
   const bool eligible = (c->model == kModelPoint2Point || c->model == kModelReprojection) &&
-                        c->combine.mode == MOPT_COMBINE_NONE && !sharded && !c->matcher;
+                        (c->combine.mode == MOPT_COMBINE_NONE || c->combine.mode == MOPT_COMBINE_HOST ||
+                         c->combine.mode == MOPT_COMBINE_PEER) &&
+                        (!sharded || sharded_allowed) && !c->matcher;
   if (eligible && !c->aql_tried) {
     c->aql_tried = true;
     c->aql_queue = mopt_detail::aqlAcquireQueue(c->device);

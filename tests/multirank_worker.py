@@ -23,6 +23,10 @@ def main():
 
     ndev = torch.cuda.device_count()
     own_gpu = ndev >= world
+    if not own_gpu and world > 2:
+        # more than two ranks on one GPU: no extra hardware queues per rank (the library's direct-dispatch
+        # queues, csrc/aql.hpp); two ranks keep them, so that sharded costs are tested on that path too
+        os.environ.setdefault("MOPT_AQL_SHARDED", "0")
     device = rank if own_gpu else 0
     torch.cuda.set_device(device)
     dist.init_process_group("gloo")
