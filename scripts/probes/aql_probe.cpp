@@ -204,6 +204,54 @@ int main(int argc, char **argv) {
           hsa_signal_store_screlease(q->doorbell_signal, idx + 1);
         });
   }
+  // ---- kernels queued back to back (the device-resident loop's situation): 64 pairs per wait -------
+  {
+    const int burst = 64, rounds = 40;
+    auto timeBurst = [&](const char *name, auto enqueue) {
+      std::vector<double> us;
+      for (int r = 0; r < rounds; ++r) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int b = 0; b < burst; ++b) { ++sequence; enqueue(double(b)); }
+        while (*host_flag != sequence) __builtin_ia32_pause();
+        us.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / burst);
+      }
+      std::sort(us.begin(), us.end());
+      std::printf("%-44s %6.2f us per pair, 64 pairs queued back to back (median of %d bursts)\n", name, us[us.size() / 2], rounds);
+      std::fflush(stdout);
+    };
+    timeBurst("hip, back to back", [&](double seed) {
+      void *a1[] = {&rows, &seed};
+      (void)hipModuleLaunchKernel(fwriter, 256, 1, 1, 256, 1, 1, 0, stream, a1, nullptr);
+      void *a2[] = {&rows, &num_rows, &host_values_dev, &host_flag_dev, &sequence};
+      (void)hipModuleLaunchKernel(fpublish, 1, 1, 1, 256, 1, 1, 0, stream, a2, nullptr);
+    });
+    HIPCHECK(hipStreamSynchronize(stream));
+    char *arena = nullptr;
+    const size_t slot = 256, slots = 256;
+    if (pools.have_local &&
+        hsa_amd_memory_pool_allocate(pools.local, slot * slots * 2, 0, reinterpret_cast<void **>(&arena)) == HSA_STATUS_SUCCESS &&
+        hsa_amd_agents_allow_access(1, &f.cpu, nullptr, arena) == HSA_STATUS_SUCCESS) {
+      for (int scope = 2; scope >= 1; --scope) {
+        g_acquire[0] = g_acquire[1] = scope; g_release[0] = g_release[1] = scope;
+        uint64_t n = 0;
+        char label[96];
+        std::snprintf(label, sizeof label, "aql, back to back, fences %d%d/%d%d", scope, scope, scope, scope);
+        timeBurst(label, [&](double seed) {
+          char *block = arena + (n % slots) * slot * 2;
+          ++n;
+          auto *wa = reinterpret_cast<WriterArgs *>(block);
+          auto *pa = reinterpret_cast<PublishArgs *>(block + slot);
+          wa->rows = rows; wa->seed = seed;
+          pa->rows = rows; pa->num_rows = num_rows; pa->pad = 0; pa->host_values = host_values_dev;
+          pa->host_flag = host_flag_dev; pa->sequence = sequence;
+          const uint64_t idx = hsa_queue_add_write_index_relaxed(q, 2);
+          dispatch(q, idx, kw, 256 * 256, wa, 0);
+          dispatch(q, idx + 1, kp, 256, pa, 1);
+          hsa_signal_store_screlease(q->doorbell_signal, idx + 1);
+        });
+      }
+    }
+  }
   // the same hip loop once more (ordering effects)
   run("hip again", [&](double seed) {
     void *a1[] = {&rows, &seed};
