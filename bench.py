@@ -769,6 +769,11 @@ def main():
             "kernel_variant": args.variant,
             "covariance": args.cov,
             "loss": args.loss,
+            # how the blocking sweeps reached the GPU: AQL packets with agent-scope fences written by the
+            # library into an HSA queue of its own (csrc/aql.hpp; MOPT_AQL=0 switches it off), or
+            # launches on the cost's HIP stream
+            "dispatch": ("direct AQL packets, agent-scope fences (library's own HSA queue)"
+                         if cost.direct_dispatches() > 0 else "HIP stream"),
         },
         "roofline": {
             "bound": "hbm",
@@ -780,8 +785,10 @@ def main():
             "traffic_bytes": traffic["bytes"] if traffic else None,
             "kernel_ms": kernel_ms,
             "kernel_launches_timed": launches,
-            "kernel_timing": "separate pass after the timed steps; every launch carries its "
-                             "dispatch timestamps (hipExtLaunchKernelGGL); rank 0's GPU",
+            "kernel_timing": "separate pass after the timed steps, same dispatch path as the steps; every "
+                             "launch carries its own dispatch timestamps (the packet processor's start / "
+                             "end of the kernel: the profiling signal of the library's queue, or "
+                             "hipExtLaunchKernelGGL on the HIP stream); rank 0's GPU",
             "algorithmic_bytes_per_launch": args.n * bpc,
         },
         "pct_hbm_peak": 100.0 * achieved / HBM_PEAK_GBS,

@@ -301,6 +301,11 @@ MOPT_API int mopt_cost_compute(mopt_cost *cost, const void *x, void *sum_sq);
 MOPT_API int mopt_cost_set_speculation(mopt_cost *cost, int enabled);
 /* sweeps launched and calls answered from the kept result since creation */
 MOPT_API int mopt_cost_stats(const mopt_cost *cost, int64_t *sweeps, int64_t *cache_hits);
+/* How many of those sweeps the library dispatched itself — AQL packets with agent-scope fences written
+ * into an HSA queue of its own instead of a launch on the cost's HIP stream (blocking sweeps of
+ * point2point and reprojection costs; csrc/aql.hpp says why: 2-3 us per call).  Same kernels, same
+ * numbers.  MOPT_AQL=0 in the environment keeps everything on HIP streams. */
+MOPT_API int mopt_cost_direct_dispatches(const mopt_cost *cost, int64_t *sweeps);
 
 /* Costs of one problem.  The optimizer asks the costs it holds one after the other at the same x:
  * `for (cost : costs_) { cost->update(x0); y0 += cost->linearize(x0, H, b); ... }` and the same for

@@ -108,6 +108,7 @@ def load():
         "mopt_cost_set_speculation": [ctypes.c_void_p, ctypes.c_int],
         "mopt_costs_link": [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int],
         "mopt_cost_link_stats": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)],
+        "mopt_cost_direct_dispatches": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)],
         "mopt_cost_stats": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64),
                             ctypes.POINTER(ctypes.c_int64)],
         "mopt_comm_unique_id": [ctypes.c_void_p, ctypes.c_int],
@@ -273,6 +274,12 @@ class _CostBase:
         hits = ctypes.c_int64(0)
         check(load().mopt_cost_link_stats(self._h, ctypes.byref(hits)))
         return hits.value
+
+    def direct_dispatches(self):
+        """sweeps the library dispatched itself (AQL packets into its own HSA queue) instead of on the HIP stream"""
+        n = ctypes.c_int64(0)
+        check(load().mopt_cost_direct_dispatches(self._h, ctypes.byref(n)))
+        return n.value
 
     def stats(self):
         sweeps, hits = ctypes.c_int64(0), ctypes.c_int64(0)

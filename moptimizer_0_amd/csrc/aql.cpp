@@ -71,7 +71,19 @@ std::map<int, DeviceState *> g_devices;
 bool enabled() {
   static const bool on = [] {
     const char *v = std::getenv("MOPT_AQL");
-    return !(v && v[0] == '0');
+    if (v && v[0] == '0') return false;
+    // A profiler that collects hardware counters per dispatch (rocprofv3 --pmc: ROCPROF_COUNTER_COLLECTION /
+    // ROCPROF_COUNTERS; rocprof v1 / v2: ROCP_INPUT) serialises the dispatches of every queue it
+    // intercepts with packets and signals of its own; with this library's packets — no completion
+    // signal, the host waiting on memory the kernel writes — `rocprofv3 --pmc` stopped making
+    // progress (round 5, bench.py under `--pmc FETCH_SIZE`: killed after 7 silent minutes; kernel
+    // tracing, `--kernel-trace --stats`, works and is how the direct path's kernels are profiled).
+    // Counters are about the kernels, which are the same on either path: stay on the HIP stream.
+    const char *cc = std::getenv("ROCPROF_COUNTER_COLLECTION");
+    const char *counters = std::getenv("ROCPROF_COUNTERS");
+    const char *v1 = std::getenv("ROCP_INPUT");
+    if ((cc && cc[0] == '1') || (counters && *counters) || (v1 && *v1)) return v && v[0] == '2';  // MOPT_AQL=2 forces it
+    return true;
   }();
   return on;
 }

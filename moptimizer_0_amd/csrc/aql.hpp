@@ -28,7 +28,8 @@
 // Scope.  Only the blocking sweeps with no combine, the host-slot combine or the peer combine, with
 // profiling off and nothing pending on the cost's HIP stream; everything else (asynchronous calls,
 // the device-resident loop, RCCL, profiled launches, run-time compiled models) stays on the HIP
-// stream.  MOPT_AQL=0 switches the direct path off.
+// stream.  MOPT_AQL=0 switches the direct path off; it is off by itself under a profiler that collects
+// hardware counters per dispatch (rocprofv3 --pmc), which hung with these packets — kernel tracing works.
 #pragma once
 
 #include <hip/hip_runtime.h>

@@ -85,6 +85,7 @@ struct SweepTimer {
   mopt_detail::AqlSite finalize_site;  // the same queue, never timed (the timing is the sweep's)
   const mopt_detail::AqlSite *aql() {
     if (!aql_used) return nullptr;
+    c->stat_direct_sweeps += 1;
     finalize_site = site.aql;
     finalize_site.timed_for = nullptr;
     return &finalize_site;
@@ -2065,6 +2066,12 @@ int mopt_cost_set_speculation(mopt_cost *c, int enabled) {
   return MOPT_OK;
 }
 
+int mopt_cost_direct_dispatches(const mopt_cost *c, int64_t *sweeps) {
+  if (!c || !sweeps) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
+  *sweeps = c->stat_direct_sweeps;
+  return MOPT_OK;
+}
+
 int mopt_cost_stats(const mopt_cost *c, int64_t *sweeps, int64_t *cache_hits) {
   if (!c) return fail(MOPT_ERR_INVALID_ARGUMENT, "cost is NULL");
   if (sweeps) *sweeps = c->stat_sweeps;
@@ -2124,8 +2131,13 @@ int mopt_cost_stream(mopt_cost *c, void **hip_stream) {
 int mopt_cost_synchronize(mopt_cost *c) {
   if (!c) return fail(MOPT_ERR_INVALID_ARGUMENT, "cost is NULL");
   MOPT_HIP_TRY(hipSetDevice(c->device));
+  if (c->aql_touched && c->aql_queue) {  // whatever went through the direct path (aql.hpp) as well
+    (void)mopt_detail::aqlDrain(c->aql_queue);
+    c->aql_touched = false;
+  }
   MOPT_HIP_TRY(hipStreamSynchronize(c->stream));
   c->own_async_pending = false;
+  c->hip_pending = false;
   return MOPT_OK;
 }
 

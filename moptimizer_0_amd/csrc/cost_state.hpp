@@ -176,6 +176,7 @@ struct mopt_cost {
     double result[mopt_detail::kResultSlots] = {0};
   } cache;
   long long stat_sweeps = 0;
+  long long stat_direct_sweeps = 0;  // of them: dispatched by the library itself (aql.hpp)
   // blocking sweeps launched on `stream` since the runtime was last handed a marker (boundCommandBatch)
   int launches_since_marker = 0;
   long long stat_cache_hits = 0;

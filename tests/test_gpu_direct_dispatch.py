@@ -1,0 +1,100 @@
+"""The blocking sweeps dispatched by the library itself (csrc/aql.hpp: AQL packets with agent-scope
+fences into HSA queues of its own) against the same calls on the HIP stream (MOPT_AQL=0): the same
+kernels with the same arguments, so the same bits — every sweep kind the direct path serves, a path
+switch in the middle (profiling, a device-resident solve, an asynchronous call on the cost's stream),
+linked costs, and many costs sharing the two queues."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import datasets as ds
+
+pytestmark = pytest.mark.gpu
+
+SCRIPT = r"""
+import json, os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+import moptimizer_0_amd as mo
+from tests import datasets as ds
+
+out = {}
+src, tgt = ds.synthetic_pair(200_003, seed=3, noise=0.02)
+x = ds.X_GENERIC
+cov = np.array([[2.0, 0.3, -0.1], [0.3, 0.5, 0.2], [-0.1, 0.2, 1.5]])
+c = mo.Point2PointCost(src, tgt)
+c.set_speculation(False)
+rows = []
+for variant in (mo.KERNEL_AUTO, mo.KERNEL_LITERAL):
+    c.set_kernel_variant(variant)
+    for mode in (mo.JAC_ANALYTIC, mo.JAC_ANALYTIC_TST_LAYOUT, mo.JAC_NUMERIC, mo.JAC_ANALYTIC_LEFT, mo.JAC_ANALYTIC_RIGHT):
+        for cv, loss in ((None, 0), (cov, 1)):
+            c.set_covariance(cv)
+            c.set_loss(loss, 100.0)
+            H, b, s = c.linearize(x, mode)
+            rows.append(np.concatenate([H.ravel(), b, [s, c.compute_cost(x)]]))
+c.set_covariance(None); c.set_loss(0, 0.0); c.set_kernel_variant(mo.KERNEL_AUTO)
+direct_before = c.direct_dispatches()
+# path switches: profiled sweeps, a device-resident solve on the stream, then blocking sweeps again
+c.set_profiling(1)
+H, b, s = c.linearize(x, mo.JAC_ANALYTIC); rows.append(np.concatenate([H.ravel(), b, [s, 0.0]]))
+ms, launches = c.profile(); c.set_profiling(0)
+xs, rep = mo.capi.lm_minimize([c], [mo.JAC_ANALYTIC], np.zeros(6), max_iterations=3)
+rows.append(np.concatenate([xs, np.zeros(38)]))
+H, b, s = c.linearize(xs, mo.JAC_NUMERIC); rows.append(np.concatenate([H.ravel(), b, [s, c.compute_cost(xs)]]))
+out["profiled_launches"] = int(launches)
+out["profiled_ms"] = float(ms)
+# float32, and the reprojection costs of config 5 (linked)
+f = mo.Point2PointCost(src.astype(np.float32), tgt.astype(np.float32), dtype=np.float32)
+H, b, s = f.linearize(x.astype(np.float32), mo.JAC_NUMERIC)
+rows.append(np.concatenate([H.ravel(), b, [s, f.compute_cost(x.astype(np.float32))]]).astype(np.float64))
+pts, pix = ds.synthetic_camera(30_000, seed=5)
+cams = [mo.ReprojectionCost(pts[:12_000], pix[:12_000]), mo.ReprojectionCost(pts[12_000:], pix[12_000:])]
+for k in cams: k.set_loss(mo.LOSS_GEMAN_MCCLURE, 100.0)
+mo.capi.link_costs(cams)
+for it in range(3):
+    xc = np.full(6, 1e-3 * it)
+    for k in cams:
+        H, b, s = k.linearize(xc, mo.JAC_NUMERIC)
+        rows.append(np.concatenate([H.ravel(), b, [s, k.compute_cost(xc)]]))
+mo.capi.link_costs([])
+# many costs over the two queues, interleaved
+many = [mo.Point2PointCost(src[k * 1000:(k + 1) * 1000 + 37], tgt[k * 1000:(k + 1) * 1000 + 37]) for k in range(12)]
+for rnd in range(3):
+    for k, m in enumerate(many):
+        H, b, s = m.linearize(x + 1e-3 * rnd, mo.JAC_ANALYTIC)
+        rows.append(np.concatenate([H.ravel(), b, [s, float(k)]]))
+out["rows"] = np.array(rows).tolist()
+out["direct"] = [c.direct_dispatches(), f.direct_dispatches(), cams[0].direct_dispatches(), many[0].direct_dispatches()]
+out["direct_before"] = direct_before
+out["sweeps"] = c.stats()[0]
+print("RESULT " + json.dumps(out))
+"""
+
+
+def _run(aql):
+    env = dict(os.environ, MOPT_AQL=aql)
+    out = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ds.ROOT}], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    line = [ln for ln in out.stdout.decode().splitlines() if ln.startswith("RESULT ")][-1]
+    return json.loads(line[len("RESULT "):])
+
+
+def test_direct_dispatch_gives_the_same_bits_as_the_hip_stream(hip_lib):
+    direct, stream = _run("1"), _run("0")
+    assert stream["direct"] == [0, 0, 0, 0] and stream["direct_before"] == 0
+    # the direct path was taken: by the point2point cost for (nearly) every blocking sweep, by the
+    # float cost, the reprojection costs and the small costs sharing the queues
+    assert direct["direct_before"] >= 0.9 * 40 and direct["direct"][0] > direct["direct_before"]
+    assert all(n > 0 for n in direct["direct"][1:])
+    a, b = np.array(direct["rows"]), np.array(stream["rows"])
+    assert a.shape == b.shape and a.shape[0] > 60
+    assert np.array_equal(a, b), np.abs(a - b).max()
+    # a profiled sweep is timed on the path it takes, with a plausible duration either way
+    for run in (direct, stream):
+        assert run["profiled_launches"] == 1 and 1e-3 < run["profiled_ms"] < 1.0, run["profiled_ms"]
