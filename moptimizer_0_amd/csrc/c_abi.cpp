@@ -662,6 +662,18 @@ void boundCommandBatch(mopt_cost *c) {
   (void)hipStreamQuery(c->stream);
 }
 
+// A profiled sweep that went through the direct path: once its results have arrived, the packet
+// processor's own start and end of that dispatch (aql.hpp) go into the cost's sweep statistics.
+void collectDirectTiming(mopt_cost *c, int rc) {
+  if (!c->aql_timed) return;
+  c->aql_timed = false;
+  const double ns = rc == MOPT_OK ? mopt_detail::aqlDispatchNanoseconds(c->aql_queue, c) : -1.0;
+  if (ns >= 0.0) {
+    c->sweep_ms_total += ns * 1e-6;
+    c->sweep_launches += 1;
+  }
+}
+
 // Where the blocking sweep about to be launched goes: the cost's own queue (aql.hpp) when nothing
 // about the call needs the HIP stream — no combine that launches on it (RCCL), no profiled launches, a
 // model whose sweeps the direct path knows (point2point, reprojection) — else the stream.  A switch
@@ -825,14 +837,7 @@ int blockingSweep(mopt_cost *c, bool cost_only, int jac_mode, const void *x) {
       if (rc != MOPT_OK) return rc;
       boundCommandBatch(c);
       rc = waitPublished(c, pub.sequence);
-      if (c->aql_timed) {  // a profiled sweep on the direct path: its dispatch's own timestamps
-        c->aql_timed = false;
-        const double ns = rc == MOPT_OK ? mopt_detail::aqlDispatchNanoseconds(c->aql_queue, c) : -1.0;
-        if (ns >= 0.0) {
-          c->sweep_ms_total += ns * 1e-6;
-          c->sweep_launches += 1;
-        }
-      }
+      collectDirectTiming(c, rc);
       return rc;
     }
   }
@@ -1287,6 +1292,7 @@ int launchPublishedSweep(mopt_cost *c, bool cost_only, int jac_mode, const void 
   c->stat_sweeps += 1;
   *sequence_out = pub.sequence;
   chooseDispatchPath(c);
+  c->aql_timed = false;
   const int rc = cost_only ? costAsyncImpl(c, x, c->d_result + offset, c->stream, pub)
                            : linearizeAsyncImpl(c, jac_mode, x, c->d_result, c->stream, pub);
   c->aql_now = mopt_detail::AqlSite();
@@ -1294,7 +1300,9 @@ int launchPublishedSweep(mopt_cost *c, bool cost_only, int jac_mode, const void 
   return rc;
 }
 int waitPublishedSweep(mopt_cost *c, unsigned long long sequence) {
-  return waitPublished(c, sequence);
+  const int rc = waitPublished(c, sequence);
+  collectDirectTiming(c, rc);
+  return rc;
 }
 
 mopt::HostPublish nextHostPublish(mopt_cost *c, int offset) { return nextPublish(c, offset); }

@@ -255,6 +255,9 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
   if ((unsigned long long)snap.peer_status == mopt::kStatusPeerTimeout)
     return fail(MOPT_ERR_PEER_TIMEOUT,
                 "a rank did not deliver its sums to this device in time (MOPT_PEER_TIMEOUT_MS)");
+  // the loop has stopped: what the window left queued on the stream are launches that find
+  // control->done set and leave without touching anything — nothing a direct sweep has to wait for
+  for (int k = 0; k < num_costs; ++k) costs[k]->hip_pending = false;
   return MOPT_OK;
 }
 
