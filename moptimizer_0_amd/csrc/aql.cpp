@@ -254,6 +254,16 @@ AqlQueue *aqlAcquireQueue(int device) {
   return q.queue ? &q : nullptr;
 }
 
+void aqlWarm(int device) {
+  const char *shared = std::getenv("MOPT_AQL_SHARDED");
+  if (shared && shared[0] == '0') return;
+  DeviceState *d = deviceState(device);
+  if (!d) return;
+  std::lock_guard<std::mutex> lock(d->mutex);
+  for (AqlQueue &q : d->queues)
+    if (!q.queue && !q.faulted.load() && !createQueue(*d, q)) q.faulted.store(true);
+}
+
 const AqlKernel *aqlLookup(int device, const void *host_function) {
   DeviceState *d = deviceState(device);
   if (!d) return nullptr;

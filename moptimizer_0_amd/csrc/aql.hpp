@@ -54,6 +54,10 @@ struct AqlKernel {
 
 // A queue of `device`'s pool (round robin), or nullptr when the direct path is unavailable.
 AqlQueue *aqlAcquireQueue(int device);
+// Creates the device's queues now (a few milliseconds, once per process and device) instead of
+// inside the first blocking sweep; a no-op where the direct path is off or MOPT_AQL_SHARDED=0 says
+// that processes share the GPU.
+void aqlWarm(int device);
 // The loaded kernel behind a __global__ function of this library, or nullptr.
 const AqlKernel *aqlLookup(int device, const void *host_function);
 // One dispatch: `grid` workgroups of `block` threads; `args` are the explicit arguments as the

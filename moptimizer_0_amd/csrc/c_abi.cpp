@@ -1372,6 +1372,8 @@ int commonCreate(mopt_cost *c, int device) {
   c->h_flag = reinterpret_cast<unsigned long long *>(c->h_result + kResultSlots);
   MOPT_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->h_result_dev), c->h_result, 0));
   c->h_flag_dev = reinterpret_cast<unsigned long long *>(c->h_result_dev + kResultSlots);
+  // the device's direct-dispatch queues (aql.hpp), here rather than inside the first blocking sweep
+  mopt_detail::aqlWarm(device);
   return MOPT_OK;
 }
 
