@@ -14,14 +14,14 @@ SAN="-fsanitize=undefined -fno-sanitize-recover=undefined"
 if [ "$1" = "build" ]; then
   make >/dev/null
   mkdir -p $OUT
-  for f in c_abi lm combine group icp jit_model device_pool; do
+  for f in c_abi lm combine group icp jit_model device_pool aql; do
     $HIPCC -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -Imoptimizer_0_amd/csrc -x hip \
       -Xarch_host -fsanitize=undefined -Xarch_host -fno-sanitize-recover=undefined \
       -c moptimizer_0_amd/csrc/$f.cpp -o $OUT/$f.o
   done
   $HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT/libmoptimizer_hip.so $OUT/*.o \
     build/obj/sweep_kernels.o build/obj/fd_kernels.o build/obj/icp_grid.o build/obj/lm_kernels.o \
-    -L/opt/rocm/lib -lrccl -lhiprtc -lpthread -lrt -Wl,-rpath,/opt/rocm/lib
+    -L/opt/rocm/lib -lrccl -lhiprtc -lhsa-runtime64 -lpthread -lrt -Wl,-rpath,/opt/rocm/lib
   for t in dropin_point2point dropin_models dropin_device_lm; do
     $CLANG -O1 -g -std=c++17 $SAN -Iinclude -Ioracle -Itests/support -o $OUT/$t tests/cpp/$t.cpp \
       -L$OUT -lmoptimizer_hip -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib -lpthread
