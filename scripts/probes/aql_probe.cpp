@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
+#include <immintrin.h>
 
 #include <algorithm>
 #include <chrono>
@@ -203,6 +204,54 @@ int main(int argc, char **argv) {
           dispatch(q, idx + 1, kp, 256, pa, 1);
           hsa_signal_store_screlease(q->doorbell_signal, idx + 1);
         });
+  }
+  // ---- one kernel, rows straight to the host, the host adds them -----------------------------------
+  {
+    Kernel kh;
+    if (lookup(exe, f.gpu, "probeWriterToHost.kd", &kh)) return 1;
+    double *host_rows = nullptr;
+    HIPCHECK(hipHostMalloc(&host_rows, 256 * 24 * sizeof(double), hipHostMallocMapped));
+    std::memset(host_rows, 0, 256 * 24 * sizeof(double));
+    double *host_rows_dev = nullptr;
+    HIPCHECK(hipHostGetDevicePointer(reinterpret_cast<void **>(&host_rows_dev), host_rows, 0));
+    char *arena = nullptr;
+    const size_t slot = 256, slots = 256;
+    if (pools.have_local &&
+        hsa_amd_memory_pool_allocate(pools.local, slot * slots, 0, reinterpret_cast<void **>(&arena)) == HSA_STATUS_SUCCESS &&
+        hsa_amd_agents_allow_access(1, &f.cpu, nullptr, arena) == HSA_STATUS_SUCCESS) {
+      struct ToHostArgs { double *rows; double seed; unsigned long long sequence; };
+      for (int scope = 1; scope >= 0; --scope) {
+        g_acquire[0] = 1; g_release[0] = scope;
+        std::vector<double> us;
+        long wrong = 0;
+        uint64_t n = 0;
+        for (int i = 0; i < iters + 200; ++i) {
+          const auto t0 = std::chrono::steady_clock::now();
+          ++sequence;
+          auto *a = reinterpret_cast<ToHostArgs *>(arena + (n++ % slots) * slot);
+          a->rows = host_rows_dev; a->seed = double(i); a->sequence = sequence;
+          _mm_sfence();
+          const uint64_t idx = hsa_queue_add_write_index_relaxed(q, 1);
+          dispatch(q, idx, kh, 256 * 256, a, 0);
+          hsa_signal_store_screlease(q->doorbell_signal, idx);
+          // the host's finalize: wait for every row's tag, add the rows in row order
+          double sum = 0.0;
+          for (int r = 0; r < 256; ++r) {
+            volatile unsigned long long *tag = reinterpret_cast<volatile unsigned long long *>(host_rows + r * 24 + 23);
+            while (*tag != sequence) __builtin_ia32_pause();
+            const double *row = host_rows + r * 24;
+            for (int k = 0; k < 23; ++k) sum += row[k];
+          }
+          const auto t1 = std::chrono::steady_clock::now();
+          if (i >= 200) us.push_back(std::chrono::duration<double, std::micro>(t1 - t0).count());
+          if (sum != 5888.0 * double(i) + 815488.0) ++wrong;
+        }
+        std::sort(us.begin(), us.end());
+        std::printf("aql: ONE kernel, rows to host, host adds (release %d)  median %6.2f us  p10 %6.2f  p90 %6.2f  (wrong sums: %ld of %d)\n",
+                    scope, us[us.size() / 2], us[us.size() / 10], us[us.size() * 9 / 10], wrong, iters + 200);
+        std::fflush(stdout);
+      }
+    }
   }
   // ---- kernels queued back to back (the device-resident loop's situation): 64 pairs per wait -------
   {

@@ -38,3 +38,18 @@ extern "C" __global__ __launch_bounds__(256) void probeWriterThrough(double *row
     __builtin_amdgcn_s_waitcnt(0);  // every counter: the stores have been acknowledged
   }
 }
+
+// No second kernel: every workgroup hands its row straight to the host — 23 values written through to
+// mapped host memory, drained, then the row's tag (the sequence number) — and the host adds the rows.
+extern "C" __global__ __launch_bounds__(256) void probeWriterToHost(double *host_rows, double seed,
+                                                                    unsigned long long sequence) {
+  double *row = host_rows + blockIdx.x * 24;  // 23 values + tag, 192 bytes = 3 cache lines
+  if (threadIdx.x < 23) {
+    __hip_atomic_store(row + threadIdx.x, seed + blockIdx.x + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_s_waitcnt(0);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(row + 23), sequence, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
