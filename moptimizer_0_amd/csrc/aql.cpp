@@ -301,7 +301,14 @@ bool aqlDrain(AqlQueue *q) {
   std::lock_guard<std::mutex> lock(q->mutex);
   if (q->faulted.load(std::memory_order_acquire)) return false;
   hsa_queue_t *hq = q->queue;
-  while (q->dispatched - hsa_queue_load_read_index_scacquire(hq) >= hq->size) _mm_pause();
+  {
+    const auto started = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (q->dispatched - hsa_queue_load_read_index_scacquire(hq) >= hq->size) {
+      _mm_pause();
+      if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - started > std::chrono::seconds(10)) return false;
+    }
+  }
   hsa_signal_store_relaxed(q->drained, 1);
   const uint64_t index = q->dispatched++;
   hsa_queue_store_write_index_relaxed(hq, index + 1);
@@ -355,8 +362,22 @@ bool aqlDispatch(AqlQueue *q, const AqlKernel *kernel, uint32_t grid, uint32_t b
     return false;
   std::lock_guard<std::mutex> lock(q->mutex);
   hsa_queue_t *hq = q->queue;
-  // room in the ring: the packet processor has taken everything up to the read index
-  while (q->dispatched - hsa_queue_load_read_index_scacquire(hq) >= hq->size) _mm_pause();
+  // Room in both rings.  Packets: the packet processor has taken everything up to the read index.
+  // Argument blocks: every packet carries the barrier bit, so once the packet processor has taken
+  // packet d + 2, packet d has completed and its block may be written again — with fewer than
+  // kArgSlots - 2 packets beyond the read index the block about to be reused belongs to such a one.
+  // (The blocking sweeps never get near either limit; a wedged queue must not wedge the caller.)
+  {
+    const uint64_t most = hq->size < uint64_t(kArgSlots - 2) ? hq->size : uint64_t(kArgSlots - 2);
+    const auto started = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (q->dispatched - hsa_queue_load_read_index_scacquire(hq) >= most) {
+      _mm_pause();
+      if ((++spins & 0xfff) == 0 && (q->faulted.load(std::memory_order_acquire) ||
+                                     std::chrono::steady_clock::now() - started > std::chrono::seconds(10)))
+        return false;
+    }
+  }
   unsigned char *slot = q->arg_ring + size_t(q->dispatched % kArgSlots) * kArgSlotBytes;
   // kernel arguments: explicit, then the implicit block where the kernel has one
   std::memcpy(slot, args, args_bytes);
