@@ -303,7 +303,7 @@ MOPT_API int mopt_cost_set_speculation(mopt_cost *cost, int enabled);
 MOPT_API int mopt_cost_stats(const mopt_cost *cost, int64_t *sweeps, int64_t *cache_hits);
 /* How many of those sweeps the library dispatched itself — AQL packets with agent-scope fences written
  * into an HSA queue of its own instead of a launch on the cost's HIP stream (blocking sweeps of
- * point2point and reprojection costs; csrc/aql.hpp says why: 2-3 us per call).  Same kernels, same
+ * point2point, reprojection and built-in scalar-model costs; csrc/aql.hpp says why: 1-3 us per call).  Same kernels, same
  * numbers.  MOPT_AQL=0 in the environment keeps everything on HIP streams. */
 MOPT_API int mopt_cost_direct_dispatches(const mopt_cost *cost, int64_t *sweeps);
 

@@ -25,10 +25,10 @@
 // before it wrote, on whichever XCD it ran), no completion signal (the finalize kernel publishes
 // into mapped host memory itself).
 //
-// Scope.  Only the blocking sweeps with no combine, the host-slot combine or the peer combine, with
-// profiling off and nothing pending on the cost's HIP stream; everything else (asynchronous calls,
-// the device-resident loop, RCCL, profiled launches, run-time compiled models) stays on the HIP
-// stream.  MOPT_AQL=0 switches the direct path off; it is off by itself under a profiler that collects
+// Scope.  The blocking sweeps of point2point, reprojection and built-in scalar-model costs, with no
+// combine, the host-slot combine or the peer combine, and nothing pending on the cost's HIP stream;
+// everything else (asynchronous calls, the device-resident loop, RCCL, costs with a correspondence
+// search, run-time compiled models — their kernels live in hipRTC modules) stays on the HIP stream.  MOPT_AQL=0 switches the direct path off; it is off by itself under a profiler that collects
 // hardware counters per dispatch (rocprofv3 --pmc), which hung with these packets — kernel tracing works.
 #pragma once
 

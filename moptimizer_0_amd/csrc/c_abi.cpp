@@ -462,13 +462,14 @@ int scalarSweepAsync(mopt_cost *c, bool cost_only, int jac_mode, const S *x, dou
   const int n = c->n_params;
   SweepTimer timer(c, s);
   MOPT_HIP_TRY(mopt::launchScalarModel<S>(args, c->scalar_model, cost_only, jac_mode, c->cov_mode,
-                                          grid, s));
+                                          grid, timer.site));
   timer.stop();
   if (cost_only) {
-    MOPT_HIP_TRY(mopt::launchFinalizeCost(c->d_partials, grid, d_out, pub, s, c->launch_peers));
+    MOPT_HIP_TRY(mopt::launchFinalizeCost(c->d_partials, grid, d_out, pub, s, c->launch_peers, timer.aql()));
   } else {
     const int nacc = c->cov_mode == mopt::kCovGeneral ? n * n + n + 1 : n * (n + 1) / 2 + n + 1;
-    MOPT_HIP_TRY(mopt::launchFinalizeDense(c->d_partials, grid, nacc, n, d_out, pub, s, c->launch_peers));
+    MOPT_HIP_TRY(mopt::launchFinalizeDense(c->d_partials, grid, nacc, n, d_out, pub, s, c->launch_peers,
+                                           timer.aql()));
   }
   return MOPT_OK;
 }
@@ -676,7 +677,8 @@ void collectDirectTiming(mopt_cost *c, int rc) {
 
 // Where the blocking sweep about to be launched goes: the cost's own queue (aql.hpp) when nothing
 // about the call needs the HIP stream — no combine that launches on it (RCCL), no profiled launches, a
-// model whose sweeps the direct path knows (point2point, reprojection) — else the stream.  A switch
+// model whose sweeps the direct path knows (point2point, reprojection, the built-in scalar models; not
+// the run-time compiled ones, whose kernels live in hipRTC modules) — else the stream.  A switch
 // of path waits once for whatever the other path still has queued for this cost.
 void chooseDispatchPath(mopt_cost *c) {
   c->aql_now = mopt_detail::AqlSite();
@@ -692,7 +694,8 @@ void chooseDispatchPath(mopt_cost *c) {
     return !(v && v[0] == '0');
   }();
   const bool sharded = c->combine.host_block != nullptr || c->combine.peer_attached || c->comm != nullptr;
-  const bool eligible = (c->model == kModelPoint2Point || c->model == kModelReprojection) &&
+  const bool eligible = (c->model == kModelPoint2Point || c->model == kModelReprojection ||
+                         c->model == kModelScalar) &&
                         (c->combine.mode == MOPT_COMBINE_NONE || c->combine.mode == MOPT_COMBINE_HOST ||
                          c->combine.mode == MOPT_COMBINE_PEER) &&
                         (!sharded || sharded_allowed) && !c->matcher;

@@ -355,7 +355,7 @@ bool aqlFinalizersLoaded(const mopt_detail::AqlSite &site);
 // (or of the cost when cost_only); finish with launchFinalizeDense(n) / launchFinalizeCost.
 template <typename S>
 hipError_t launchScalarModel(const ScalarSweepArgs<S> &args, int model, bool cost_only,
-                             int jac_mode, int cov_mode, int grid, hipStream_t stream);
+                             int jac_mode, int cov_mode, int grid, const LaunchSite &site);
 
 // For every source point i: nearest target of T p_i within max_dist -> target planes of slot i
 // (NaN marker when there is none).

@@ -1724,57 +1724,49 @@ hipError_t launchFinalizeCost(const double *partials, int grid, double *result,
 namespace {
 template <typename S, template <typename> class ModelT>
 hipError_t launchScalarFor(const ScalarSweepArgs<S> &args, bool cost_only, int jac_mode,
-                           int cov_mode, int grid, hipStream_t stream) {
-  const dim3 g(grid), b(kBlockThreads);
-  if (cost_only) {
-    hipLaunchKernelGGL((scalarModelKernel<S, ModelT, kJacNumeric, kCovIdentity, true>), g, b, 0,
-                       stream, args);
-    return hipGetLastError();
-  }
+                           int cov_mode, int grid, const LaunchSite &site) {
+  if (cost_only)
+    return launchSweep(scalarModelKernel<S, ModelT, kJacNumeric, kCovIdentity, true>, grid, site, args);
   const bool numeric = (jac_mode == kJacNumeric);
 #define MOPT_LAUNCH_SCALAR(JAC, COV) \
-  hipLaunchKernelGGL((scalarModelKernel<S, ModelT, JAC, COV, false>), g, b, 0, stream, args)
+  return launchSweep(scalarModelKernel<S, ModelT, JAC, COV, false>, grid, site, args)
   switch (cov_mode) {
     case kCovIdentity:
       if (numeric) MOPT_LAUNCH_SCALAR(kJacNumeric, kCovIdentity);
       else MOPT_LAUNCH_SCALAR(kJacAnalytic, kCovIdentity);
-      break;
     case kCovSymmetric:
       if (numeric) MOPT_LAUNCH_SCALAR(kJacNumeric, kCovSymmetric);
       else MOPT_LAUNCH_SCALAR(kJacAnalytic, kCovSymmetric);
-      break;
     default:
       if (numeric) MOPT_LAUNCH_SCALAR(kJacNumeric, kCovGeneral);
       else MOPT_LAUNCH_SCALAR(kJacAnalytic, kCovGeneral);
-      break;
   }
 #undef MOPT_LAUNCH_SCALAR
-  return hipGetLastError();
 }
 }  // namespace
 
 template <typename S>
 hipError_t launchScalarModel(const ScalarSweepArgs<S> &args, int model, bool cost_only,
-                             int jac_mode, int cov_mode, int grid, hipStream_t stream) {
+                             int jac_mode, int cov_mode, int grid, const LaunchSite &site) {
   switch (model) {
     case kScalarExpCurve:
-      return launchScalarFor<S, ExpCurve>(args, cost_only, jac_mode, cov_mode, grid, stream);
+      return launchScalarFor<S, ExpCurve>(args, cost_only, jac_mode, cov_mode, grid, site);
     case kScalarRational:
-      return launchScalarFor<S, Rational>(args, cost_only, jac_mode, cov_mode, grid, stream);
+      return launchScalarFor<S, Rational>(args, cost_only, jac_mode, cov_mode, grid, site);
     case kScalarPowell:
-      return launchScalarFor<S, Powell>(args, cost_only, jac_mode, cov_mode, grid, stream);
+      return launchScalarFor<S, Powell>(args, cost_only, jac_mode, cov_mode, grid, site);
     case kScalarExpCurveMarked:
-      return launchScalarFor<S, ExpCurveMarked>(args, cost_only, jac_mode, cov_mode, grid, stream);
+      return launchScalarFor<S, ExpCurveMarked>(args, cost_only, jac_mode, cov_mode, grid, site);
     case kScalarRationalMarked:
-      return launchScalarFor<S, RationalMarked>(args, cost_only, jac_mode, cov_mode, grid, stream);
+      return launchScalarFor<S, RationalMarked>(args, cost_only, jac_mode, cov_mode, grid, site);
     default:
       return hipErrorInvalidValue;
   }
 }
 template hipError_t launchScalarModel<float>(const ScalarSweepArgs<float> &, int, bool, int, int,
-                                             int, hipStream_t);
+                                             int, const LaunchSite &);
 template hipError_t launchScalarModel<double>(const ScalarSweepArgs<double> &, int, bool, int, int,
-                                              int, hipStream_t);
+                                              int, const LaunchSite &);
 
 // MOPT_ICP_FIRST_ROUND=0: the row-by-row search alone (measurements: scripts/icp_offsets_timing.py)
 static bool icpFirstRound() {

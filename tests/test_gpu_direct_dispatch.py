@@ -62,6 +62,16 @@ for it in range(3):
         H, b, s = k.linearize(xc, mo.JAC_NUMERIC)
         rows.append(np.concatenate([H.ravel(), b, [s, k.compute_cost(xc)]]))
 mo.capi.link_costs([])
+# a built-in scalar model (tst/test_models.h rational model, tst/curve_fitting.cpp exp curve)
+t = np.linspace(0.0, 4.95, 5003)
+curves = [mo.ScalarModelCost(mo.capi.MODEL_RATIONAL, t, 0.36 * t / (0.56 + t)),
+          mo.ScalarModelCost(mo.capi.MODEL_EXP_CURVE, t, np.exp(0.3 * t + 0.1))]
+for sc, modes in zip(curves, ((mo.JAC_ANALYTIC, mo.JAC_NUMERIC), (mo.JAC_NUMERIC,))):
+    for mode in modes:
+        xs2 = np.array([0.31, 0.52])
+        H, b, s = sc.linearize(xs2, mode)
+        row = np.zeros(44); v = np.concatenate([H.ravel(), b, [s, sc.compute_cost(xs2)]]); row[:v.size] = v
+        rows.append(row)
 # many costs over the two queues, interleaved
 many = [mo.Point2PointCost(src[k * 1000:(k + 1) * 1000 + 37], tgt[k * 1000:(k + 1) * 1000 + 37]) for k in range(12)]
 for rnd in range(3):
@@ -69,7 +79,8 @@ for rnd in range(3):
         H, b, s = m.linearize(x + 1e-3 * rnd, mo.JAC_ANALYTIC)
         rows.append(np.concatenate([H.ravel(), b, [s, float(k)]]))
 out["rows"] = np.array(rows).tolist()
-out["direct"] = [c.direct_dispatches(), f.direct_dispatches(), cams[0].direct_dispatches(), many[0].direct_dispatches()]
+out["direct"] = [c.direct_dispatches(), f.direct_dispatches(), cams[0].direct_dispatches(), many[0].direct_dispatches(),
+                 curves[0].direct_dispatches(), curves[1].direct_dispatches()]
 out["direct_before"] = direct_before
 out["sweeps"] = c.stats()[0]
 print("RESULT " + json.dumps(out))
@@ -87,9 +98,9 @@ def _run(aql):
 
 def test_direct_dispatch_gives_the_same_bits_as_the_hip_stream(hip_lib):
     direct, stream = _run("1"), _run("0")
-    assert stream["direct"] == [0, 0, 0, 0] and stream["direct_before"] == 0
+    assert stream["direct"] == [0, 0, 0, 0, 0, 0] and stream["direct_before"] == 0
     # the direct path was taken: by the point2point cost for (nearly) every blocking sweep, by the
-    # float cost, the reprojection costs and the small costs sharing the queues
+    # float cost, the reprojection costs, the small costs sharing the queues and the built-in scalar models
     assert direct["direct_before"] >= 0.9 * 40 and direct["direct"][0] > direct["direct_before"]
     assert all(n > 0 for n in direct["direct"][1:])
     a, b = np.array(direct["rows"]), np.array(stream["rows"])
