@@ -675,20 +675,19 @@ void collectDirectTiming(mopt_cost *c, int rc) {
   }
 }
 
-// Where the blocking sweep about to be launched goes: the cost's own queue (aql.hpp) when nothing
-// about the call needs the HIP stream — no combine that launches on it (RCCL), no profiled launches, a
-// model whose sweeps the direct path knows (point2point, reprojection, the built-in scalar models; not
-// the run-time compiled ones, whose kernels live in hipRTC modules) — else the stream.  A switch
-// of path waits once for whatever the other path still has queued for this cost.
+// Where the blocking sweep about to be launched goes: the cost's own queue (aql.hpp) unless the call
+// needs the HIP stream — RCCL selected (its all-reduce launches there), a cost with a correspondence
+// search (its update(x) is queued on the stream every outer iteration: a sweep on another queue would
+// have to wait for it with a synchronisation), a model whose kernels live in hipRTC modules (run-time
+// compiled).  Profiled sweeps go the same way as unprofiled ones (the queue stamps its own dispatch).
+// A switch of path waits once for whatever the other path still has queued for this cost.
 void chooseDispatchPath(mopt_cost *c) {
   c->aql_now = mopt_detail::AqlSite();
-  // (a cost with a correspondence search stays on the stream: its update(x) is queued there every
-  // outer iteration, and a sweep on another queue would have to wait for it with a synchronisation)
   // A shard of a multi-rank job (a combine transport attached) takes the direct path like any other
-  // cost — the host-slot and peer combines live inside the finalize kernel and its wait; RCCL needs
-  // the stream — unless MOPT_AQL_SHARDED=0: ranks that SHARE a GPU (rehearsals, tests) add two
-  // hardware queues per process on it, and 4 ranks + their parent oversubscribed the GPU's queues
-  // until the combines' bounded waits ran out (profiles/NOTES.md round 5).
+  // cost — the host-slot and peer combines live inside the finalize kernel and its wait — unless
+  // MOPT_AQL_SHARDED=0: ranks that SHARE a GPU (rehearsals, tests) add two hardware queues per
+  // process on it, and 4 ranks + their parent oversubscribed the GPU's queues until the combines'
+  // bounded waits ran out (profiles/NOTES.md round 5).
   static const bool sharded_allowed = [] {
     const char *v = std::getenv("MOPT_AQL_SHARDED");
     return !(v && v[0] == '0');
