@@ -1861,10 +1861,23 @@ int markForeignStream(mopt_cost *c, hipStream_t s) {
 }
 }  // namespace
 
+namespace {
+// An asynchronous sweep writes the cost's partial rows from a HIP stream: a sweep a linked cost queued
+// ahead for this one through the direct path (aql.hpp) is on another queue and must have finished.
+void settleDirectPrefetch(mopt_cost *c) {
+  if (c->prefetch.pending && c->aql_touched && c->aql_queue) {
+    (void)mopt_detail::aqlDrain(c->aql_queue);
+    c->aql_touched = false;
+    c->prefetch.pending = false;
+  }
+}
+}  // namespace
+
 int mopt_cost_linearize_async(mopt_cost *c, int jacobian_mode, const void *x, double *d_result,
                               void *hip_stream) {
   if (!c || !x || !d_result) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
   MOPT_HIP_TRY(hipSetDevice(c->device));
+  settleDirectPrefetch(c);
   // hip_stream is the hipStream_t itself; NULL is HIP's null (legacy default) stream, which is
   // also what torch's default stream is
   const hipStream_t s = static_cast<hipStream_t>(hip_stream);
@@ -1881,6 +1894,7 @@ int mopt_cost_linearize_async(mopt_cost *c, int jacobian_mode, const void *x, do
 int mopt_cost_compute_async(mopt_cost *c, const void *x, double *d_sum_sq, void *hip_stream) {
   if (!c || !x || !d_sum_sq) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
   MOPT_HIP_TRY(hipSetDevice(c->device));
+  settleDirectPrefetch(c);
   const hipStream_t s = static_cast<hipStream_t>(hip_stream);
   mopt::PeerCombine pc;
   if (c->combine.mode == MOPT_COMBINE_PEER) {

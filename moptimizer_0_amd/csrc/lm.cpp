@@ -166,7 +166,10 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
   for (int k = 0; k < num_costs; ++k) {
     mopt_cost *ck = costs[k];
     const bool other_stream = ck->stream != s;
-    if (ck->foreign_pending || (other_stream && (ck->own_async_pending || ck->prefetch.pending)))
+    // (a sweep queued ahead through the direct path — aql.hpp — is on a queue of its own whichever
+    // cost leads: stream order does not hold it back)
+    if (ck->foreign_pending || (other_stream && (ck->own_async_pending || ck->prefetch.pending)) ||
+        (ck->prefetch.pending && ck->aql_touched))
       MOPT_HIP_TRY(quiesceCost(ck));
     ck->prefetch.pending = false;  // its partial rows and result are about to be overwritten
   }
