@@ -306,6 +306,12 @@ MOPT_API int mopt_cost_stats(const mopt_cost *cost, int64_t *sweeps, int64_t *ca
  * point2point, reprojection and built-in scalar-model costs; csrc/aql.hpp says why: 1-3 us per call).  Same kernels, same
  * numbers.  MOPT_AQL=0 in the environment keeps everything on HIP streams. */
 MOPT_API int mopt_cost_direct_dispatches(const mopt_cost *cost, int64_t *sweeps);
+/* Gives back the HSA queues the direct path holds on `device` (they are created with the first cost
+ * and otherwise kept for the life of the process; the next cost creates them again, a few
+ * milliseconds).  Each is a hardware queue of the GPU, and processes that share one GPU can run out
+ * of them — a parent that has finished its own costs calls this before it starts workers on the
+ * same GPU.  MOPT_ERR_INVALID_ARGUMENT while a cost of this process lives on the device. */
+MOPT_API int mopt_device_trim(int device);
 
 /* Costs of one problem.  The optimizer asks the costs it holds one after the other at the same x:
  * `for (cost : costs_) { cost->update(x0); y0 += cost->linearize(x0, H, b); ... }` and the same for

@@ -109,6 +109,7 @@ def load():
         "mopt_costs_link": [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int],
         "mopt_cost_link_stats": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)],
         "mopt_cost_direct_dispatches": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)],
+        "mopt_device_trim": [ctypes.c_int],
         "mopt_cost_stats": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64),
                             ctypes.POINTER(ctypes.c_int64)],
         "mopt_comm_unique_id": [ctypes.c_void_p, ctypes.c_int],
@@ -167,6 +168,13 @@ def comm_unique_id():
     buf = ctypes.create_string_buffer(COMM_ID_BYTES)
     check(load().mopt_comm_unique_id(buf, COMM_ID_BYTES))
     return buf.raw
+
+
+def device_trim(device=0):
+    """Gives back the hardware queues the library's direct dispatch holds on `device`
+    (mopt_device_trim): before workers that share the GPU start.  Raises while a cost of this
+    process lives on the device."""
+    check(load().mopt_device_trim(int(device)))
 
 
 def device_count():

@@ -57,7 +57,7 @@ struct DeviceState {
   hsa_agent_t gpu{}, cpu{};
   hsa_amd_memory_pool_t local_pool{};
   AqlQueue queues[kQueuesPerDevice];
-  int created = 0;
+  int users = 0;  // live costs on this device (aqlRetain / aqlRelease)
   std::atomic<unsigned> next{0};
   std::map<const void *, AqlKernel> kernels;  // by host function; the null kernel = looked up, absent
   std::mutex mutex;
@@ -254,14 +254,49 @@ AqlQueue *aqlAcquireQueue(int device) {
   return q.queue ? &q : nullptr;
 }
 
-void aqlWarm(int device) {
+bool aqlRetain(int device) {
   const char *shared = std::getenv("MOPT_AQL_SHARDED");
-  if (shared && shared[0] == '0') return;
+  if (shared && shared[0] == '0') return false;
+  DeviceState *d = deviceState(device);
+  if (!d) return false;
+  std::lock_guard<std::mutex> lock(d->mutex);
+  ++d->users;
+  for (AqlQueue &q : d->queues)
+    if (!q.queue && !q.faulted.load() && !createQueue(*d, q)) q.faulted.store(true);
+  return true;
+}
+
+void aqlRelease(int device) {
   DeviceState *d = deviceState(device);
   if (!d) return;
   std::lock_guard<std::mutex> lock(d->mutex);
-  for (AqlQueue &q : d->queues)
-    if (!q.queue && !q.faulted.load() && !createQueue(*d, q)) q.faulted.store(true);
+  if (d->users > 0) --d->users;
+}
+
+bool aqlTrim(int device) {
+  DeviceState *d = deviceState(device);
+  if (!d) return true;  // (nothing held)
+  std::lock_guard<std::mutex> lock(d->mutex);
+  if (d->users > 0) return false;
+  // no cost of the device is alive (each drained its own sweeps in its destructor)
+  for (AqlQueue &q : d->queues) {
+    std::lock_guard<std::mutex> queue_lock(q.mutex);
+    if (q.queue) {
+      (void)hsa_queue_destroy(q.queue);
+      q.queue = nullptr;
+    }
+    if (q.arg_ring) {
+      (void)hsa_amd_memory_pool_free(q.arg_ring);
+      q.arg_ring = nullptr;
+    }
+    if (q.drained.handle) (void)hsa_signal_destroy(q.drained);
+    if (q.stamped.handle) (void)hsa_signal_destroy(q.stamped);
+    q.drained.handle = q.stamped.handle = 0;
+    q.stamp_owner = nullptr;
+    q.dispatched = 0;
+    q.faulted.store(false);
+  }
+  return true;
 }
 
 const AqlKernel *aqlLookup(int device, const void *host_function) {

@@ -54,10 +54,16 @@ struct AqlKernel {
 
 // A queue of `device`'s pool (round robin), or nullptr when the direct path is unavailable.
 AqlQueue *aqlAcquireQueue(int device);
-// Creates the device's queues now (a few milliseconds, once per process and device) instead of
-// inside the first blocking sweep; a no-op where the direct path is off or MOPT_AQL_SHARDED=0 says
-// that processes share the GPU.
-void aqlWarm(int device);
+// One more / one fewer cost lives on `device`.  The first one creates the device's queues (a few
+// milliseconds, here rather than inside the first blocking sweep); they then stay for the process
+// (a caller that builds one cost per outer iteration must not pay for queues each time) unless
+// aqlTrim gives them back.  aqlRetain returns whether it counted (false where the direct path is
+// off or MOPT_AQL_SHARDED=0): only then call aqlRelease.
+bool aqlRetain(int device);
+void aqlRelease(int device);
+// Destroys the device's queues if no cost lives on it (true), else leaves them (false): every queue
+// is a hardware queue of the GPU, and processes that share one run out of them (MOPT_AQL_SHARDED).
+bool aqlTrim(int device);
 // The loaded kernel behind a __global__ function of this library, or nullptr.
 const AqlKernel *aqlLookup(int device, const void *host_function);
 // One dispatch: `grid` workgroups of `block` threads; `args` are the explicit arguments as the

@@ -1374,8 +1374,8 @@ int commonCreate(mopt_cost *c, int device) {
   c->h_flag = reinterpret_cast<unsigned long long *>(c->h_result + kResultSlots);
   MOPT_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->h_result_dev), c->h_result, 0));
   c->h_flag_dev = reinterpret_cast<unsigned long long *>(c->h_result_dev + kResultSlots);
-  // the device's direct-dispatch queues (aql.hpp), here rather than inside the first blocking sweep
-  mopt_detail::aqlWarm(device);
+  // the device's direct-dispatch queues (aql.hpp) exist while a cost of this process lives on it
+  c->aql_retained = mopt_detail::aqlRetain(device);
   return MOPT_OK;
 }
 
@@ -1425,6 +1425,7 @@ void destroyCost(mopt_cost *c) {
   deviceRelease(c->d_result);
   mappedHostRelease(c->device, c->h_result, (kResultSlots + 16) * sizeof(double));
   releaseStream(c->device, c->stream);  // synchronised at the top of this function
+  if (c->aql_retained) mopt_detail::aqlRelease(c->device);
   delete c;
 }
 
@@ -2095,6 +2096,15 @@ int mopt_cost_set_speculation(mopt_cost *c, int enabled) {
 int mopt_cost_direct_dispatches(const mopt_cost *c, int64_t *sweeps) {
   if (!c || !sweeps) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
   *sweeps = c->stat_direct_sweeps;
+  return MOPT_OK;
+}
+
+int mopt_device_trim(int device) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count)
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "no such device");
+  if (!mopt_detail::aqlTrim(device))
+    return fail(MOPT_ERR_INVALID_ARGUMENT, "a cost of this process still lives on the device");
   return MOPT_OK;
 }
 

@@ -135,6 +135,7 @@ struct mopt_cost {
   // a direct sweep would have to wait for (a path switch synchronises once).
   mopt_detail::AqlQueue *aql_queue = nullptr;
   bool aql_tried = false;
+  bool aql_retained = false;  // counted by aqlRetain: aqlRelease when the cost goes
   mopt_detail::AqlSite aql_now;
   bool aql_touched = false;
   bool hip_pending = false;

@@ -109,3 +109,45 @@ def test_direct_dispatch_gives_the_same_bits_as_the_hip_stream(hip_lib):
     # a profiled sweep is timed on the path it takes, with a plausible duration either way
     for run in (direct, stream):
         assert run["profiled_launches"] == 1 and 1e-3 < run["profiled_ms"] < 1.0, run["profiled_ms"]
+
+
+TRIM_SCRIPT = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+import moptimizer_0_amd as mo
+from tests import datasets as ds
+
+src, tgt = ds.synthetic_pair(50_001, seed=4, noise=0.02)
+out = {"refused": False, "rows": [], "direct": []}
+mo.capi.device_trim(0)  # nothing held yet: fine
+for life in range(3):
+    c = mo.Point2PointCost(src, tgt)
+    d = mo.Point2PointCost(src[:999], tgt[:999])
+    for k in range(40):
+        H, b, s = c.linearize(ds.X_GENERIC + 1e-4 * k, mo.JAC_ANALYTIC)  # (a repeated x is answered from the kept result)
+        Hd, bd, sd = d.linearize(ds.X_GENERIC + 1e-4 * k, mo.JAC_NUMERIC)
+    out["rows"].append(np.concatenate([H.ravel(), b, [s], Hd.ravel(), bd, [sd]]).tolist())
+    out["direct"].append(c.direct_dispatches())
+    c.close()
+    try:
+        mo.capi.device_trim(0)
+    except mo.MoptError:
+        out["refused"] = True  # d is alive
+    d.close()
+    mo.capi.device_trim(0)
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_queues_given_back_and_created_again(hip_lib):
+    """mopt_device_trim: refused while a cost lives on the device; after it, the next cost creates
+    the queues again and its sweeps go the direct way with the same results."""
+    out = subprocess.run([sys.executable, "-c", TRIM_SCRIPT % {"root": ds.ROOT}], env=dict(os.environ, MOPT_AQL="1"),
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    line = [ln for ln in out.stdout.decode().splitlines() if ln.startswith("RESULT ")][-1]
+    got = json.loads(line[len("RESULT "):])
+    assert got["refused"] is True
+    assert all(n >= 36 for n in got["direct"]), got["direct"]
+    assert got["rows"][0] == got["rows"][1] == got["rows"][2]
