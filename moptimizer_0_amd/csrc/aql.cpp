@@ -255,12 +255,12 @@ AqlQueue *aqlAcquireQueue(int device) {
 }
 
 bool aqlRetain(int device) {
-  const char *shared = std::getenv("MOPT_AQL_SHARDED");
-  if (shared && shared[0] == '0') return false;
   DeviceState *d = deviceState(device);
   if (!d) return false;
   std::lock_guard<std::mutex> lock(d->mutex);
-  ++d->users;
+  ++d->users;  // (counted either way: a cost may draw a queue later, and aqlTrim must know it lives)
+  const char *shared = std::getenv("MOPT_AQL_SHARDED");
+  if (shared && shared[0] == '0') return true;  // processes share the GPU: a queue only when a cost asks
   for (AqlQueue &q : d->queues)
     if (!q.queue && !q.faulted.load() && !createQueue(*d, q)) q.faulted.store(true);
   return true;

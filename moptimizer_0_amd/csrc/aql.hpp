@@ -58,7 +58,8 @@ AqlQueue *aqlAcquireQueue(int device);
 // milliseconds, here rather than inside the first blocking sweep); they then stay for the process
 // (a caller that builds one cost per outer iteration must not pay for queues each time) unless
 // aqlTrim gives them back.  aqlRetain returns whether it counted (false where the direct path is
-// off or MOPT_AQL_SHARDED=0): only then call aqlRelease.
+// off): only then call aqlRelease.  Under MOPT_AQL_SHARDED=0 it counts but creates nothing (a
+// queue is then made when an unsharded cost first asks for one).
 bool aqlRetain(int device);
 void aqlRelease(int device);
 // Destroys the device's queues if no cost lives on it (true), else leaves them (false): every queue
