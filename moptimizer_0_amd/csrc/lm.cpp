@@ -178,7 +178,36 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
 
   mopt::LmReport *live = lead->h_lm_report;
   __atomic_store_n(&live->flag, 0ull, __ATOMIC_RELEASE);
-  if (lead->scalar_bytes == 8)
+  const long long max_points =
+      1 + (long long)opt.max_iterations *
+              ((opt.lm_max_iterations > 0 ? opt.lm_max_iterations : 1) + (problem.rematch ? 1 : 0));
+  // One small point2point cost (a few tiles: the reference's own test sizes): the whole loop in one
+  // launch of one workgroup (sweep_kernels.hip p2pSolveSmallKernel) instead of two launches per
+  // evaluated point — the same sums added in another order, so the same iterates to rounding.
+  // MOPT_LM_ONE_LAUNCH_TILES: the largest tile count that goes this way (default and maximum
+  // solveSmallMaxTiles(); a tile is 512 fp64 / 1024 fp32 correspondences; 0 = never), read per call.
+  int small_tiles = mopt::solveSmallMaxTiles();
+  if (const char *v = std::getenv("MOPT_LM_ONE_LAUNCH_TILES")) {
+    const int asked = std::atoi(v);
+    if (asked >= 0 && asked < small_tiles) small_tiles = asked;
+  }
+  const bool one_workgroup = num_costs == 1 && lead->model == kModelPoint2Point && !lead->matcher &&
+                             lead->combine.mode == MOPT_COMBINE_NONE && problem.cost[0].moments &&
+                             problem.n == kNumParams && lead->num_tiles >= 1 &&
+                             lead->num_tiles <= small_tiles &&
+                             max_points <= 4096;  // (one kernel for the whole loop: at ~8 us a point, <= 35 ms)
+  if (one_workgroup) {
+    if (lead->scalar_bytes == 8)
+      MOPT_HIP_TRY(mopt::launchP2PSolveSmall<double>(
+          static_cast<const double *>(lead->d_tiles), lead->num_tiles,
+          static_cast<const mopt::P2PSweepArgs<double> *>(lead->d_lm_args), lead->d_lm_basis,
+          lead->d_result, problem, static_cast<const double *>(x), int(max_points), s));
+    else
+      MOPT_HIP_TRY(mopt::launchP2PSolveSmall<float>(
+          static_cast<const float *>(lead->d_tiles), lead->num_tiles,
+          static_cast<const mopt::P2PSweepArgs<float> *>(lead->d_lm_args), lead->d_lm_basis,
+          lead->d_result, problem, static_cast<const float *>(x), int(max_points), s));
+  } else if (lead->scalar_bytes == 8)
     MOPT_HIP_TRY(mopt::launchLmStep<double>(problem, true, static_cast<const double *>(x), s));
   else
     MOPT_HIP_TRY(mopt::launchLmStep<float>(problem, true, static_cast<const float *>(x), s));
@@ -187,9 +216,6 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
   // points per outer iteration.  The host stays `window` points ahead of the device; whatever is
   // still queued when the step kernel stops finds control->done set and returns at once.
   // (with an ICP cost an accepted point is searched and swept again before it is linearized)
-  const long long max_points =
-      1 + (long long)opt.max_iterations *
-              ((opt.lm_max_iterations > 0 ? opt.lm_max_iterations : 1) + (problem.rematch ? 1 : 0));
   static const int default_window = envInt("MOPT_LM_WINDOW", 3);
   const int window = opt.window > 0 ? opt.window : default_window;
   long long enqueued = 0;
@@ -201,7 +227,7 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
     const long long steps = (long long)(word >> 1);
     const long long completed = steps > 0 ? steps - 1 : 0;  // the init run counts one
     bool queued = false;
-    while (enqueued < max_points && enqueued - completed < window) {
+    while (!one_workgroup && enqueued < max_points && enqueued - completed < window) {
       // per point: every cost's sweep + finalize; the last finalize also takes the LM step
       if (one_launch) {
         rc = residentSweepSet(costs, num_costs, jacobian_modes, row_offset, problem.control, s);
@@ -228,7 +254,7 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
         return fail(MOPT_ERR_HIP, std::string("device-resident LM failed: ") + hipGetErrorString(q));
       if (q == hipSuccess) {
         if (progressWord(live) & 1ull) break;
-        if (enqueued >= max_points)
+        if (one_workgroup || enqueued >= max_points)
           return fail(MOPT_ERR_HIP, "device-resident LM drained without reaching a status");
       }
       if (std::chrono::steady_clock::now() - started > std::chrono::seconds(120))

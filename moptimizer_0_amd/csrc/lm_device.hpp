@@ -413,8 +413,13 @@ __device__ void projectionFor(const LmCostDesc &d, const double (&T)[12], double
 
 // The per-x constants of every cost's next sweep, at point x (LDS).  Lane j (0..6) forms the
 // transform at x (j = 0) or at x + h_j e_j.
+// args_local / basis_local: where a kernel that sweeps in the same launch (p2pSolveSmallKernel: the
+// whole minimisation in one workgroup) keeps its one point2point cost's constants — LDS — instead of
+// the cost's blocks in HBM.
 template <typename S>
-__device__ __forceinline__ void writeSweepConstants(const LmProblem &P, const S *x) {
+__device__ __forceinline__ void writeSweepConstants(const LmProblem &P, const S *x,
+                                                    void *args_local = nullptr,
+                                                    AffineBasis *basis_local = nullptr) {
   // The transforms at x and at x + h_j e_j are the same for every SE(3) cost of the problem: formed
   // once (seven lanes, one sincos each), before the loop over the costs — a cost that does not
   // differentiate numerically takes the transform at x in all seven places and steps of zero, as when
@@ -446,7 +451,8 @@ __device__ __forceinline__ void writeSweepConstants(const LmProblem &P, const S 
       auto Tj = [&](int j) -> const S(&)[12] { return Tstep[numeric ? j : 0]; };
       auto inv_h_of = [&](int j) { return numeric ? inv_step[j] : S(0); };
       if (d.model == kLmPoint2Point) {
-        P2PSweepArgs<S> *a = static_cast<P2PSweepArgs<S> *>(d.args);
+        P2PSweepArgs<S> *a = static_cast<P2PSweepArgs<S> *>(args_local ? args_local : d.args);
+        AffineBasis *const basis = basis_local ? basis_local : d.basis;
         if (tid < (1 + kNumParams) * 12) a->T[tid / 12][tid % 12] = Tj(tid / 12)[tid % 12];
         if (tid < kNumParams) a->inv_h[tid] = inv_h_of(tid);
         if (d.moments && d.jac_mode == kJacAnalyticLeft && tid < 18) {
@@ -463,18 +469,18 @@ __device__ __forceinline__ void writeSweepConstants(const LmProblem &P, const S 
           };
           const S w0[3] = {Tj(0)[3], Tj(0)[7], Tj(0)[11]};
           const S base = pattern(w0);
-          d.basis->J[0][r * 6 + j] = double(base);
+          basis->J[0][r * 6 + j] = double(base);
           for (int k = 0; k < 3; ++k) {
             const S wk[3] = {w0[0] + Tj(0)[0 * 4 + k], w0[1] + Tj(0)[1 * 4 + k],
                              w0[2] + Tj(0)[2 * 4 + k]};
-            d.basis->J[1 + k][r * 6 + j] = double(pattern(wk)) - double(base);
+            basis->J[1 + k][r * 6 + j] = double(pattern(wk)) - double(base);
           }
         }
         if (d.moments && d.jac_mode == kJacAnalyticRight && tid < 18) {
           // J(p) = [I | -R skew(p)]: J0 = [I | 0], J_k = [0 | -R skew(e_k)] (c_abi.cpp fillBasis).
           // skew(e_k)(m, c) = -eps(m, c, k): column c != k has its one entry in row m = 3 - c - k.
           const int r = tid / 6, j = tid % 6;
-          d.basis->J[0][r * 6 + j] = (j < 3 && r == j) ? 1.0 : 0.0;
+          basis->J[0][r * 6 + j] = (j < 3 && r == j) ? 1.0 : 0.0;
           for (int k = 0; k < 3; ++k) {
             double v = 0.0;
             if (j >= 3) {
@@ -487,15 +493,15 @@ __device__ __forceinline__ void writeSweepConstants(const LmProblem &P, const S 
                 v = -double(Tj(0)[r * 4 + m]) * skew_mc;
               }
             }
-            d.basis->J[1 + k][r * 6 + j] = v;
+            basis->J[1 + k][r * 6 + j] = v;
           }
         }
         if (d.moments && numeric && tid < 18) {
           // column j of J is ((R_j - R) p + (t_j - t)) / h_j  (c_abi.cpp fillBasis)
           const int r = tid / 6, j = tid % 6;
-          d.basis->J[0][r * 6 + j] = double((Tj(1 + j)[r * 4 + 3] - Tj(0)[r * 4 + 3]) * inv_h_of(j));
+          basis->J[0][r * 6 + j] = double((Tj(1 + j)[r * 4 + 3] - Tj(0)[r * 4 + 3]) * inv_h_of(j));
           for (int k = 0; k < 3; ++k)
-            d.basis->J[1 + k][r * 6 + j] =
+            basis->J[1 + k][r * 6 + j] =
                 double((Tj(1 + j)[r * 4 + k] - Tj(0)[r * 4 + k]) * inv_h_of(j));
         }
       } else {
@@ -545,10 +551,14 @@ __device__ __forceinline__ void storeReport(double *p, double v) {
 //               false)
 // (forced inline: as a real call the by-value kernel arguments it takes by reference — 1.2 KB of
 // LmProblem — are first copied to scratch by every lane of the 1024-thread workgroup: 60 us)
-template <typename S, int NMAX>
-__device__ __forceinline__ void lmStepBodyFor(const LmProblem &P, bool init, const LmStart<S> &start,
+// Returns whether the loop has stopped (the same for every thread).
+// STATE_STAYS: the caller runs every step of the minimisation in this one launch — the state then
+// lives in this function's LDS from one run to the next and never travels to HBM and back.
+template <typename S, int NMAX, bool STATE_STAYS = false>
+__device__ __forceinline__ bool lmStepBodyFor(const LmProblem &P, bool init, const LmStart<S> &start,
                               const double *own_result, int own_index, bool prefetched,
-                              LmStateWords state_words) {
+                              LmStateWords state_words, void *args_local = nullptr,
+                              AffineBasis *basis_local = nullptr) {
 #ifdef MOPT_LM_TIMING
   __shared__ unsigned long long tick[8];
 #define MOPT_TICK(i) if (threadIdx.x == 0) tick[i] = wall_clock64()
@@ -570,7 +580,8 @@ __device__ __forceinline__ void lmStepBodyFor(const LmProblem &P, bool init, con
   const int tid = threadIdx.x;
   constexpr int kStateWords = int(sizeof(LmState<S, NMAX>) / sizeof(unsigned int));
   if (!init) {
-    if (prefetched) {
+    if constexpr (STATE_STAYS) {
+    } else if (prefetched) {
       if (tid < kStateWords) reinterpret_cast<unsigned int *>(&st)[tid] = state_words.lo;
       if (tid + int(blockDim.x) < kStateWords)
         reinterpret_cast<unsigned int *>(&st)[tid + blockDim.x] = state_words.hi;
@@ -801,8 +812,9 @@ __device__ __forceinline__ void lmStepBodyFor(const LmProblem &P, bool init, con
     __syncthreads();
   }
   MOPT_TICK(2);
-  for (int i = tid; i < kStateWords; i += blockDim.x)
-    reinterpret_cast<unsigned int *>(stored)[i] = reinterpret_cast<const unsigned int *>(&st)[i];
+  if constexpr (!STATE_STAYS)
+    for (int i = tid; i < kStateWords; i += blockDim.x)
+      reinterpret_cast<unsigned int *>(stored)[i] = reinterpret_cast<const unsigned int *>(&st)[i];
   if (tid == 0) {
     if (init) ctl->pad[0] = 0;
     ctl->trial = st.trials;
@@ -810,7 +822,7 @@ __device__ __forceinline__ void lmStepBodyFor(const LmProblem &P, bool init, con
     ctl->done = finished;
   }
   MOPT_TICK(3);
-  if (propose) writeSweepConstants<S>(P, next_x);
+  if (propose) writeSweepConstants<S>(P, next_x, args_local, basis_local);
   MOPT_TICK(4);
 
   // For the host: the progress word after every run (one write-through store: the host only needs
@@ -839,6 +851,7 @@ __device__ __forceinline__ void lmStepBodyFor(const LmProblem &P, bool init, con
                        __HIP_MEMORY_SCOPE_SYSTEM);
   }
 #undef MOPT_TICK
+  return finished != 0;  // (written before the barrier that precedes the state's write-back)
 }
 
 // Words `threadIdx.x` and `threadIdx.x + blockDim.x` of the stored state (LmStateWords), for
@@ -859,13 +872,12 @@ __device__ __forceinline__ LmStateWords lmPrefetchState(const LmProblem &P) {
 
 // The step for this problem's parameter count (see LmState).
 template <typename S>
-__device__ __forceinline__ void lmStepBody(const LmProblem &P, bool init, const LmStart<S> &start,
+__device__ __forceinline__ bool lmStepBody(const LmProblem &P, bool init, const LmStart<S> &start,
                            const double *own_result, int own_index, bool prefetched,
                            LmStateWords state_words) {
   if (P.n <= kMaxParams)
-    lmStepBodyFor<S, kMaxParams>(P, init, start, own_result, own_index, prefetched, state_words);
-  else
-    lmStepBodyFor<S, kMaxWideParams>(P, init, start, own_result, own_index, prefetched, state_words);
+    return lmStepBodyFor<S, kMaxParams>(P, init, start, own_result, own_index, prefetched, state_words);
+  return lmStepBodyFor<S, kMaxWideParams>(P, init, start, own_result, own_index, prefetched, state_words);
 }
 
 }  // namespace

@@ -259,6 +259,16 @@ hipError_t launchLmStep(const LmProblem &problem, bool init, const S *x0, hipStr
 template <typename Args>
 hipError_t launchStoreArgs(const Args &value, Args *d_dst, hipStream_t stream);
 
+// A whole minimisation of one small point2point cost (moments sweep, <= solveSmallMaxTiles() tiles,
+// 6 parameters) in one launch of one workgroup: sweep_kernels.hip p2pSolveSmallKernel.  The cost's
+// resident blocks must hold its data / loss / covariance (residentPrepare); the report goes where
+// problem.report says, as from the launch-per-point loop.
+int solveSmallMaxTiles();
+template <typename S>
+hipError_t launchP2PSolveSmall(const S *tiles, int num_tiles, const P2PSweepArgs<S> *d_args,
+                               const AffineBasis *d_basis, double *result, const LmProblem &problem,
+                               const S *x0, int max_points, hipStream_t stream);
+
 // Resident forms: per-x constants read from HBM (`d_args`, `d_basis`), early exit on control->done,
 // peer-combine sequence = peers.sequence + control->trial.
 template <typename S>

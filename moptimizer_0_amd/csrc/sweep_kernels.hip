@@ -274,68 +274,74 @@ __global__ __launch_bounds__(kBlockThreads) void p2pLinearizeLiteralResidentSetK
 // `tiles` / `num_tiles` repeat the first members of A as leading scalar arguments: gfx950 can
 // preload those into SGPRs at wave launch (-amdgpu-kernarg-preload-count), so the first tile's
 // loads go out without waiting for a kernel-argument fetch.
-template <typename S, bool STREAMING>
-__device__ __forceinline__ void p2pMomentsBody(const S *tiles, int num_tiles,
-                                               const P2PSweepArgs<S> &A) {
+// The moments of the V correspondences one lane holds of a tile, added to `acc`.
+template <typename S>
+__device__ __forceinline__ void momentsOfPack(double (&acc)[kAccMoments], const Pack<S> (&cur)[6],
+                                              long long first, const P2PSweepArgs<S> &A) {
   constexpr int V = TileShape<S>::kVec;
-  double acc[kAccMoments];
-#pragma unroll
-  for (int k = 0; k < kAccMoments; ++k) acc[k] = 0.0;
-
   // fp64: the moment updates contract into one v_fma_f64 each, straight into the accumulators.
   // fp32: the four correspondences a lane holds per tile are first summed in fp32 (fp32 FMAs),
   // then promoted once — 23 conversions + fp64 adds per tile instead of 92, which otherwise makes
   // the fp32 sweep VALU-bound.
   using Local = typename std::conditional<sizeof(S) == 8, double, S>::type;
+  Local loc[kAccMoments];
+  if constexpr (sizeof(S) == 4) {
+#pragma unroll
+    for (int k = 0; k < kAccMoments; ++k) loc[k] = Local(0);
+  }
+  auto add = [&](int k, S v) {
+    if constexpr (sizeof(S) == 8)
+      acc[k] += double(v);
+    else
+      loc[k] += v;
+  };
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    const S p[3] = {cur[0].v[e], cur[1].v[e], cur[2].v[e]};
+    const bool valid = isCorrespondence(first + e, A.count, cur[3].v[e]);
+    const S q[3] = {valid ? cur[3].v[e] : S(0), valid ? cur[4].v[e] : S(0),
+                    valid ? cur[5].v[e] : S(0)};
+    S r[3];
+    p2pResidual<S>(A.T[0], p, q, r);
+    S rr = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+    S w = lossWeight<S>(A.loss_kind, A.loss_param, rr);
+    w = valid ? w : S(0);
+    rr = valid ? rr : S(0);
+    const S wp[3] = {w * p[0], w * p[1], w * p[2]};
+    const S wr[3] = {w * r[0], w * r[1], w * r[2]};
+    add(0, w);
+    add(1, wp[0]);
+    add(2, wp[1]);
+    add(3, wp[2]);
+    add(4, wp[0] * p[0]);
+    add(5, wp[0] * p[1]);
+    add(6, wp[0] * p[2]);
+    add(7, wp[1] * p[1]);
+    add(8, wp[1] * p[2]);
+    add(9, wp[2] * p[2]);
+    add(10, wr[0]);
+    add(11, wr[1]);
+    add(12, wr[2]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) add(13 + 3 * k + c, p[k] * wr[c]);
+    add(22, rr);
+  }
+  if constexpr (sizeof(S) == 4) {
+#pragma unroll
+    for (int k = 0; k < kAccMoments; ++k) acc[k] += double(loc[k]);
+  }
+}
+
+template <typename S, bool STREAMING>
+__device__ __forceinline__ void p2pMomentsBody(const S *tiles, int num_tiles,
+                                               const P2PSweepArgs<S> &A) {
+  double acc[kAccMoments];
+#pragma unroll
+  for (int k = 0; k < kAccMoments; ++k) acc[k] = 0.0;
   sweepTiles<S, STREAMING>(tiles, num_tiles, [&](const Pack<S>(&cur)[6], long long first) {
-    Local loc[kAccMoments];
-    if constexpr (sizeof(S) == 4) {
-#pragma unroll
-      for (int k = 0; k < kAccMoments; ++k) loc[k] = Local(0);
-    }
-    auto add = [&](int k, S v) {
-      if constexpr (sizeof(S) == 8)
-        acc[k] += double(v);
-      else
-        loc[k] += v;
-    };
-#pragma unroll
-    for (int e = 0; e < V; ++e) {
-      const S p[3] = {cur[0].v[e], cur[1].v[e], cur[2].v[e]};
-      const bool valid = isCorrespondence(first + e, A.count, cur[3].v[e]);
-      const S q[3] = {valid ? cur[3].v[e] : S(0), valid ? cur[4].v[e] : S(0),
-                      valid ? cur[5].v[e] : S(0)};
-      S r[3];
-      p2pResidual<S>(A.T[0], p, q, r);
-      S rr = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
-      S w = lossWeight<S>(A.loss_kind, A.loss_param, rr);
-      w = valid ? w : S(0);
-      rr = valid ? rr : S(0);
-      const S wp[3] = {w * p[0], w * p[1], w * p[2]};
-      const S wr[3] = {w * r[0], w * r[1], w * r[2]};
-      add(0, w);
-      add(1, wp[0]);
-      add(2, wp[1]);
-      add(3, wp[2]);
-      add(4, wp[0] * p[0]);
-      add(5, wp[0] * p[1]);
-      add(6, wp[0] * p[2]);
-      add(7, wp[1] * p[1]);
-      add(8, wp[1] * p[2]);
-      add(9, wp[2] * p[2]);
-      add(10, wr[0]);
-      add(11, wr[1]);
-      add(12, wr[2]);
-#pragma unroll
-      for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) add(13 + 3 * k + c, p[k] * wr[c]);
-      add(22, rr);
-    }
-    if constexpr (sizeof(S) == 4) {
-#pragma unroll
-      for (int k = 0; k < kAccMoments; ++k) acc[k] += double(loc[k]);
-    }
+    momentsOfPack<S>(acc, cur, first, A);
   });
   blockReduceStore<kAccMoments>(acc, A.partials + size_t(blockIdx.x) * kAccMoments);
 }
@@ -1393,7 +1399,9 @@ __global__ __launch_bounds__(kStepThreads) void finalizeDenseResidentKernel(
   }
 }
 
-template <int T, typename Parked = NoHook>
+// PEERS = false: no exchange between ranks, and no PeerCombine to read (a default-constructed one
+// handed in by reference is a private array, i.e. scratch memory).
+template <int T, typename Parked = NoHook, bool PEERS = true>
 __device__ __forceinline__ unsigned long long finalizeMomentsBody(const double *partials, int grid,
                                                                   const AffineBasis &B,
                                                                   double *result,
@@ -1458,8 +1466,8 @@ __device__ __forceinline__ unsigned long long finalizeMomentsBody(const double *
       v = total[22];
     }
   }
-  unsigned long long status;
-  v = peerCombine(pc, kResultDoubles, v, &status, sequence_add);
+  unsigned long long status = 0;
+  if constexpr (PEERS) v = peerCombine(pc, kResultDoubles, v, &status, sequence_add);
   if (t < kResultDoubles) {
     result[t] = v;
     if (result_lds) result_lds[t] = v;
@@ -1516,6 +1524,89 @@ __global__ __launch_bounds__(kStepThreads) void finalizeMomentsResidentKernel(
   if constexpr (STEP != 0) {
     __syncthreads();
     lmStepBody<S>(P, false, LmStart<S>(), own, own_index, true, state_words);
+  }
+}
+
+// ---- a whole minimisation in one launch ---------------------------------------------------------
+// Small point2point problems (the reference's own test sizes: tst/point2point.cpp registers 1 k
+// correspondences): under the launch-per-point loop an evaluated point costs two launches, 11-12 us,
+// of which the sweep of a tile or two is a fraction.  Here one workgroup runs the loop of
+// levenberg_marquadt_dyn.cpp:34-119 without leaving the kernel.  The correspondences — at most
+// kSolveSmallTiles tiles — are loaded once and stay in registers for every evaluated point; per
+// point the workgroup adds up their moments (momentsOfPack, the arithmetic of the resident sweep),
+// reduces them to one row in LDS, contracts it as finalizeMomentsResidentKernel does and takes the
+// LM step, whose state stays in LDS; the per-x constants and the Jacobian basis the step leaves for
+// the next sweep stay in LDS too (through HBM they would come back through the scalar cache, which
+// does not see this kernel's own stores).  The sums are those of the launch-per-point loop added in
+// another order (one row instead of one per tile): the same iterates to rounding
+// (tests/test_gpu_device_lm.py).  At most `max_points` evaluated points: the loop's own bound, which
+// every thread reaches.
+constexpr int kSolveSmallTiles = 4;
+
+template <typename S>
+__global__ __launch_bounds__(kBlockThreads) void p2pSolveSmallKernel(
+    const S *tiles, int num_tiles, const P2PSweepArgs<S> *__restrict__ d_args,
+    const AffineBasis *__restrict__ d_basis, double *result, const LmProblem problem,
+    const LmStart<S> start, int max_points) {
+  __shared__ P2PSweepArgs<S> A;
+  __shared__ AffineBasis B;
+  // the problem's description, read from LDS inside the loop: as kernel arguments its 1.2 KB are
+  // loop invariants the compiler loads up front into scalar registers, of which there are 104 —
+  // some 400 spills to vector lanes, read back one by one in every step
+  static_assert(sizeof(LmProblem) % 4 == 0, "copied by words");
+  __shared__ alignas(16) unsigned int problem_words[sizeof(LmProblem) / 4];
+  for (int i = threadIdx.x; i < int(sizeof(LmProblem) / 4); i += kBlockThreads)
+    problem_words[i] = reinterpret_cast<const unsigned int *>(&problem)[i];
+  const LmProblem &P = *reinterpret_cast<const LmProblem *>(problem_words);
+  __shared__ double row[kAccMoments];
+  __shared__ double own[kSlotData];
+  constexpr int V = TileShape<S>::kVec, TP = TileShape<S>::kPoints;
+  Pack<S> held[kSolveSmallTiles][6];
+#pragma unroll
+  for (int t = 0; t < kSolveSmallTiles; ++t) {
+    // (past the last tile: that tile again — an unconditional load; its values are never used)
+    const S *base = tiles + size_t(t < num_tiles ? t : num_tiles - 1) * TileShape<S>::kP2PScalars +
+                    threadIdx.x * V;
+#pragma unroll
+    for (int pl = 0; pl < 6; ++pl) held[t][pl] = loadPack<S>(base + pl * TP);
+  }
+  static_assert(sizeof(P2PSweepArgs<S>) % 4 == 0 && sizeof(AffineBasis) % 4 == 0, "copied by words");
+  constexpr int kArgWords = int(sizeof(P2PSweepArgs<S>) / 4), kBasisWords = int(sizeof(AffineBasis) / 4);
+  for (int i = threadIdx.x; i < kArgWords; i += kBlockThreads)
+    reinterpret_cast<unsigned int *>(&A)[i] = reinterpret_cast<const unsigned int *>(d_args)[i];
+  for (int i = threadIdx.x; i < kBasisWords; i += kBlockThreads)
+    reinterpret_cast<unsigned int *>(&B)[i] = reinterpret_cast<const unsigned int *>(d_basis)[i];
+  __syncthreads();
+  // (one inlined copy of the step: its first run starts the minimisation, like lmStepKernel's `init`)
+  for (int point = 0;; ++point) {
+#ifdef MOPT_LM_TIMING
+    const unsigned long long tick_step = wall_clock64();
+#endif
+    const bool finished = lmStepBodyFor<S, kMaxParams, true>(P, point == 0, start, own, 0, false,
+                                                             LmStateWords(), &A, &B);
+    if (finished || point >= max_points) break;
+#ifdef MOPT_LM_TIMING
+    const unsigned long long tick_sweep = wall_clock64();
+#endif
+    double acc[kAccMoments];
+#pragma unroll
+    for (int k = 0; k < kAccMoments; ++k) acc[k] = 0.0;
+#pragma unroll
+    for (int t = 0; t < kSolveSmallTiles; ++t)
+      if (t < num_tiles) momentsOfPack<S>(acc, held[t], (long long)t * TP + threadIdx.x * V, A);
+    blockReduceStore<kAccMoments>(acc, row);
+    __syncthreads();
+#ifdef MOPT_LM_TIMING
+    const unsigned long long tick_finalize = wall_clock64();
+#endif
+    finalizeMomentsBody<kBlockThreads, NoHook, false>(row, 1, B, result, HostPublish(), PeerCombine(),
+                                                      own);
+    __syncthreads();
+#ifdef MOPT_LM_TIMING
+    if (threadIdx.x == 0)
+      printf("one launch, point %d: step %llu sweep of %d tiles %llu contraction %llu (x10 ns)\n", point,
+             tick_sweep - tick_step, num_tiles, tick_finalize - tick_sweep, wall_clock64() - tick_finalize);
+#endif
   }
 }
 
@@ -1873,6 +1964,28 @@ hipError_t launchPublish(const double *d_values, int count, const HostPublish &p
 }
 
 // ---- resident forms (device-resident LM) ---------------------------------------------------------
+int solveSmallMaxTiles() { return kSolveSmallTiles; }
+
+template <typename S>
+hipError_t launchP2PSolveSmall(const S *tiles, int num_tiles, const P2PSweepArgs<S> *d_args,
+                               const AffineBasis *d_basis, double *result, const LmProblem &problem,
+                               const S *x0, int max_points, hipStream_t stream) {
+  if (num_tiles < 1 || num_tiles > kSolveSmallTiles || problem.num_costs != 1 ||
+      problem.n != kNumParams || max_points < 1)
+    return hipErrorInvalidValue;
+  LmStart<S> start;
+  for (int i = 0; i < kMaxWideParams; ++i) start.x[i] = i < problem.n ? x0[i] : S(0);
+  hipLaunchKernelGGL((p2pSolveSmallKernel<S>), dim3(1), dim3(kBlockThreads), 0, stream, tiles,
+                     num_tiles, d_args, d_basis, result, problem, start, max_points);
+  return hipGetLastError();
+}
+template hipError_t launchP2PSolveSmall<float>(const float *, int, const P2PSweepArgs<float> *,
+                                               const AffineBasis *, double *, const LmProblem &,
+                                               const float *, int, hipStream_t);
+template hipError_t launchP2PSolveSmall<double>(const double *, int, const P2PSweepArgs<double> *,
+                                                const AffineBasis *, double *, const LmProblem &,
+                                                const double *, int, hipStream_t);
+
 template <typename S>
 hipError_t launchP2PMomentsResident(const S *tiles, int num_tiles, const P2PSweepArgs<S> *d_args,
                                     const LmControl *control, int grid, const LaunchSite &site) {

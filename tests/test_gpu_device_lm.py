@@ -600,3 +600,68 @@ def test_four_wide_costs_each_with_full_rows(hip_lib):
         assert np.isfinite(Hc).all() and sc > 0
         c.close()
 
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_small_problems_in_one_launch_take_the_same_iterates(hip_lib, oracle, dtype, monkeypatch):
+    """One point2point cost of at most four tiles (the reference's own sizes) is minimised by ONE
+    launch of one workgroup (sweep_kernels.hip p2pSolveSmallKernel: correspondences held in registers;
+    sweep, contraction and LM step without leaving the kernel).  Against the launch-per-point loop
+    (MOPT_LM_ONE_LAUNCH_TILES=0), whose sums it adds in another order: truncated after k outer
+    iterations the same status, iteration count, sweeps and — to rounding — x and cost, for every
+    Jacobian mode, covariance form, the robust loss and both manifold updates; run out, the same pose
+    and cost (the noise-level stopping tests may fire an iteration apart, as between any two
+    summation orders).  And the CPU loop's iterates as for any size."""
+    mo = hip_lib
+    per_tile = 512 if dtype == np.float64 else 1024
+    eps = np.finfo(dtype).eps
+    cov = np.array([[2.0, 0.3, -0.1], [0.3, 0.5, 0.2], [-0.1, 0.2, 1.5]])
+    cases = [(mo.JAC_ANALYTIC, 0, None, 0), (mo.JAC_NUMERIC, 0, None, 0), (mo.JAC_ANALYTIC_TST_LAYOUT, 0, None, 0),
+             (mo.JAC_ANALYTIC_LEFT, 1, None, 0), (mo.JAC_ANALYTIC_RIGHT, 2, None, 0),
+             (mo.JAC_ANALYTIC, 0, cov, 1), (mo.JAC_NUMERIC, 0, np.diag([0.5, 2.0, 3.0]), 1)]
+    compared = 0
+    for n in (1, 7, 1000, 4 * per_tile, 4 * per_tile + 1):
+        src, tgt = ds.synthetic_pair(n, seed=40 + n % 7, noise=0.01)
+        cost = mo.Point2PointCost(src.astype(dtype), tgt.astype(dtype), dtype=dtype)
+        for jac, manifold, cv, loss in cases:
+            numeric = jac == mo.JAC_NUMERIC
+            cost.set_covariance(cv)
+            cost.set_loss(loss, 100.0)
+            for k in (1, 3, 15):
+                got = {}
+                for tiles in ("4", "0"):
+                    monkeypatch.setenv("MOPT_LM_ONE_LAUNCH_TILES", tiles)
+                    got[tiles] = mo.capi.lm_minimize([cost], [jac], np.zeros(6, dtype=dtype), max_iterations=k,
+                                                     manifold=manifold)
+                (xa, ra), (xb, rb) = got["4"], got["0"]
+                what = (n, jac, k, ra, rb, xa, xb)
+                if n > 4 * per_tile:  # five tiles: both runs took the launch-per-point loop
+                    assert ra == rb and np.array_equal(xa, xb), what
+                elif n < 3 or np.isnan(ra["cost"]) or np.isnan(rb["cost"]):
+                    # fewer correspondences than constrain a pose: singular normal equations, where
+                    # rounding decides the direction — both must end the same way
+                    assert ra["status"] == rb["status"], what
+                elif k < 15 and dtype == np.float64:
+                    assert (ra["status"], ra["iterations"], ra["sweeps"]) == (rb["status"], rb["iterations"], rb["sweeps"]), what
+                    tol = 1e-7 if numeric else 1e-10
+                    assert np.abs(xa - xb).max() <= tol * max(1.0, np.abs(xb).max()), what
+                    assert abs(ra["cost"] - rb["cost"]) <= tol * max(rb["cost"], 1e-12), what
+                else:
+                    tol = 1e-6 if dtype == np.float64 else 2e-3
+                    assert np.abs(xa - xb).max() <= tol * max(1.0, np.abs(xb).max()), what
+                    assert abs(ra["cost"] - rb["cost"]) <= 64 * eps * n + 1e-6 * rb["cost"], what
+                compared += 1
+        cost.close()
+    assert compared == 5 * 7 * 3
+    monkeypatch.delenv("MOPT_LM_ONE_LAUNCH_TILES")
+    # and against the CPU loop (fp64, analytic: every iterate to 1e-9, same status and count)
+    if dtype == np.float64:
+        src, tgt = ds.synthetic_pair(1000, seed=5, noise=0.01)
+        cost = mo.Point2PointCost(src, tgt)
+        for k in (1, 2, 3, 5, 15):
+            x, rep = mo.capi.lm_minimize([cost], [0], np.zeros(6), max_iterations=k)
+            xr, status, iters = oracle.p2p_minimize(src, tgt, np.zeros(6), cost_class=ob.ANALYTIC_DYN,
+                                                    layout=ob.LAYOUT_ROW_MAJOR, max_iter=k)
+            assert (rep["status"], rep["iterations"]) == (status, iters), (k, rep, status, iters)
+            assert np.abs(x - xr).max() < 1e-9 * max(1.0, np.abs(xr).max()), (k, x, xr)
+        cost.close()
