@@ -659,10 +659,35 @@ def main():
         return ms / max(launches, 1), launches
 
     def baseline_configs():
-        """BASELINE.json configs 2, 3 and 5, measured as the headline is (same timed_pass /
+        """BASELINE.json configs 1, 2, 3 and 5, measured as the headline is (same timed_pass /
         kernel_pass): 1 M correspondences fit the Infinity Cache, 100 k reprojection elements are
         pure latency — step times, with the kernel's share beside them."""
         out = {}
+        # configs[0]: tst/point2point.cpp's size.  One blocking linearization per step as everywhere
+        # else, and — what a 1 k problem is for — the whole registration (forward differences, from
+        # x = 0) under mopt_lm_minimize: one launch of one workgroup at this size (DESIGN.md §3)
+        n0 = 1000
+        c0, s0, t0 = make_cost(n0)
+        del s0, t0
+        el, _, ssq, st = timed_pass(c0, None, args.steps, args.warmup, 200, mode=mo.JAC_ANALYTIC)
+        ms = el / args.steps * 1e3
+        x0 = np.zeros(6, dtype=np_dtype)
+        for _ in range(5):
+            mo.capi.lm_minimize([c0], [mo.JAC_NUMERIC], x0)
+        solves = []
+        for _ in range(20):
+            t_solve = time.perf_counter()
+            xs0, rep0 = mo.capi.lm_minimize([c0], [mo.JAC_NUMERIC], x0)
+            solves.append(time.perf_counter() - t_solve)
+        out["cfg1"] = {"ms_per_step": ms, "value": n0 / (ms * 1e-3), "median_step_us": step_times(st)["median"],
+                       "check_sum_sq": ssq, "solve_ms": float(np.median(solves)) * 1e3,
+                       "solve_iterations": rep0["iterations"], "solve_sweeps": rep0["sweeps"],
+                       "solve_status": rep0["status"], "solve_x": [float(v) for v in xs0],
+                       "workload": "point2point, 1k synthetic correspondences (tst/point2point.cpp's size): "
+                                   "a blocking analytic linearization per step; solve_ms = the whole "
+                                   "forward-difference registration from x = 0 under mopt_lm_minimize "
+                                   "(median of 20)"}
+        c0.close()
         n1 = 1_000_000
         c1, s1, t1 = make_cost(n1)
         del s1, t1
