@@ -554,7 +554,9 @@ __device__ __forceinline__ void storeReport(double *p, double v) {
 // Returns whether the loop has stopped (the same for every thread).
 // STATE_STAYS: the caller runs every step of the minimisation in this one launch — the state then
 // lives in this function's LDS from one run to the next and never travels to HBM and back.
-template <typename S, int NMAX, bool STATE_STAYS = false>
+// FIXED_N: the parameter count when the caller knows it at compile time (0: P.n) — the solve's
+// dispatch on n and every `i < n` predicate then fold away.
+template <typename S, int NMAX, bool STATE_STAYS = false, int FIXED_N = 0>
 __device__ __forceinline__ bool lmStepBodyFor(const LmProblem &P, bool init, const LmStart<S> &start,
                               const double *own_result, int own_index, bool prefetched,
                               LmStateWords state_words, void *args_local = nullptr,
@@ -575,7 +577,7 @@ __device__ __forceinline__ bool lmStepBodyFor(const LmProblem &P, bool init, con
   __shared__ int propose, finished;
   __shared__ SolveScratch<S, NMAX> solve_scratch;
   LmState<S, NMAX> *stored = static_cast<LmState<S, NMAX> *>(P.state);
-  const int n = P.n;
+  const int n = FIXED_N > 0 ? FIXED_N : P.n;
   const int nn = n * n;
   const int tid = threadIdx.x;
   constexpr int kStateWords = int(sizeof(LmState<S, NMAX>) / sizeof(unsigned int));
@@ -871,10 +873,13 @@ __device__ __forceinline__ LmStateWords lmPrefetchState(const LmProblem &P) {
 }
 
 // The step for this problem's parameter count (see LmState).
-template <typename S>
+template <typename S, int FIXED_N = 0>
 __device__ __forceinline__ bool lmStepBody(const LmProblem &P, bool init, const LmStart<S> &start,
                            const double *own_result, int own_index, bool prefetched,
                            LmStateWords state_words) {
+  if constexpr (FIXED_N > 0 && FIXED_N <= kMaxParams)  // (the caller's costs fix the parameter count)
+    return lmStepBodyFor<S, kMaxParams, false, FIXED_N>(P, init, start, own_result, own_index, prefetched,
+                                                        state_words);
   if (P.n <= kMaxParams)
     return lmStepBodyFor<S, kMaxParams>(P, init, start, own_result, own_index, prefetched, state_words);
   return lmStepBodyFor<S, kMaxWideParams>(P, init, start, own_result, own_index, prefetched, state_words);

@@ -1523,7 +1523,8 @@ __global__ __launch_bounds__(kStepThreads) void finalizeMomentsResidentKernel(
 #endif
   if constexpr (STEP != 0) {
     __syncthreads();
-    lmStepBody<S>(P, false, LmStart<S>(), own, own_index, true, state_words);
+    // (rows of moments are a point2point cost's: the problem has its six parameters)
+    lmStepBody<S, kNumParams>(P, false, LmStart<S>(), own, own_index, true, state_words);
   }
 }
 
@@ -1582,8 +1583,8 @@ __global__ __launch_bounds__(kBlockThreads) void p2pSolveSmallKernel(
 #ifdef MOPT_LM_TIMING
     const unsigned long long tick_step = wall_clock64();
 #endif
-    const bool finished = lmStepBodyFor<S, kMaxParams, true>(P, point == 0, start, own, 0, false,
-                                                             LmStateWords(), &A, &B);
+    const bool finished = lmStepBodyFor<S, kMaxParams, true, kNumParams>(
+        P, point == 0, start, own, 0, false, LmStateWords(), &A, &B);
     if (finished || point >= max_points) break;
 #ifdef MOPT_LM_TIMING
     const unsigned long long tick_sweep = wall_clock64();

@@ -36,17 +36,17 @@ ACCEPTED_SGPR_SPILLS = (
     ("mopt::p2pForwardDiffResidentArgsKernel<float,", 20, "parked outside the tile loop"),
     ("mopt::p2pForwardDiffResidentSetKernel<float,", 20, "parked outside the tile loop"),
     # one workgroup of 256 threads running a whole small minimisation (512 registers a lane): the LM
-    # step inside a loop, where the compiler hoists the fp64 constants of sincos / acos / sqrt into
-    # scalar registers as loop invariants (the same step in the one-shot kernels: 0-18) — parked in
-    # vector lanes, read back per step: measured 4.7 us a step against 3.4 us in the fused
-    # finalize-and-step kernel, inside a point that costs 7 us instead of 11 (profiles/r5_small_solve.txt)
-    ("mopt::p2pSolveSmallKernel<", 420, "LM step inside a loop: hoisted constants"),
+    # step inside a loop keeps more lane masks and invariants alive than the one-shot kernels do
+    # (the same step there: 0-18) — parked in vector lanes.  330 with the parameter count read at run
+    # time, 92 with n = 6 fixed at compile time (the solve's dispatch on n and every `i < n` predicate
+    # fold away); a point costs 7-8 us instead of 10-11 (profiles/r5_small_solve.txt)
+    ("mopt::p2pSolveSmallKernel<", 100, "LM step inside a loop"),
 )
 # Vector registers the allocator moved to the accumulation registers of the same lane (vgpr spills
 # with NO scratch memory): for the kernel that holds its correspondences in registers across a whole
 # minimisation that is where idle values belong.
 ACCEPTED_AGPR_RESIDENT = (
-    ("mopt::p2pSolveSmallKernel<", 64),
+    ("mopt::p2pSolveSmallKernel<", 32),  # (0 since n is fixed at compile time; 20-28 before)
 )
 FIELDS = ("sgpr_count", "sgpr_spill_count", "vgpr_count", "vgpr_spill_count", "private_segment_fixed_size")
 
