@@ -429,6 +429,11 @@ MOPT_API int mopt_cost_get_combine(const mopt_cost *cost, int *combine_mode, int
  * forward-difference constants of the next sweep into HBM; sweeps are queued ahead and read their
  * constants from there.  The host takes no decision and sees only the final x.  Each point is
  * evaluated once, with the linearization sweep (it also yields sum r^T r).
+ * A single point2point cost of at most four tiles (2048 fp64 / 4096 fp32 correspondences — the
+ * reference's own test sizes) with fixed correspondences is minimised by ONE launch of one workgroup
+ * that keeps the correspondences in registers and never leaves the kernel between points (same sums,
+ * added in another order; MOPT_LM_ONE_LAUNCH_TILES=0 in the environment keeps the launch-per-point
+ * form; `window` does not apply).
  *
  * costs / jacobian_modes: the costs of Optimizer::addCost (optimizer.h:58) with the Jacobian mode
  * of each (the cost class the caller would have used), at most 4, same device / scalar type / n;
