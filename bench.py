@@ -851,8 +851,12 @@ def main():
     # ---- the other BASELINE configs that fit one GPU, driver-timed in the same line ------------
     if (world == 1 and not args.no_configs and args.dtype == "f64" and args.cov == "identity"
             and args.loss == "none"):
-        progress["stage"] = "configs 2, 3, 5"
-        line["configs"] = baseline_configs()
+        progress["stage"] = "configs 1, 2, 3, 5"
+        try:
+            line["configs"] = baseline_configs()
+        except Exception as e:  # noqa: BLE001 - an extra must not cost the headline its line
+            line["configs"] = {"error": repr(e)}
+            log("configs block failed: %r" % (e,))
 
     # ---- CPU baseline: rank 0's host cores, every world size -----------------------------------
     progress["stage"] = "cpu baseline"
