@@ -24,11 +24,15 @@ Prints ONE JSON line on rank 0 (contract in the task statement) including
   timing       — the K individual step times of rank 0 (per_step_us, median, min, first)
   check.vs_oracle — one GPU linearize over rank 0's shard against the CPU restatement's H, b, cost
                  on the same correspondences (the sums the cpu_baseline sweeps compute anyway), bar 1e-6
-  configs      — N = 1: BASELINE configs 2, 3 (default and literal evaluation) and 5, timed the same way
-  timing       — the K individual step times of rank 0 (per_step_us, median, min, first)
-  check.vs_oracle — one GPU linearize over rank 0's shard against the CPU restatement's H, b, cost
-                 on the same correspondences (the sums the cpu_baseline sweeps compute anyway), bar 1e-6
-  configs      — N = 1: BASELINE configs 2, 3 (default and literal evaluation) and 5, timed the same way
+  check.timed_region — what the library counted between t0 and t1 (mopt_cost_stats /
+                 mopt_cost_direct_dispatches deltas): K sweeps, 0 calls answered from a kept result,
+                 K direct dispatches (0 on HIP streams) — K steps were K sweeps over HBM
+  configs      — N = 1: BASELINE configs 1, 2, 3 (default and literal evaluation) and 5, timed the same
+                 way, plus the two figures the 256 MiB Infinity Cache cannot have helped:
+                 hbm_check (the same analytic sweep over 100 M correspondences = 4.8 GB, 19 x the
+                 cache) and rotating (several distinct costs of the headline's size swept round-robin:
+                 every line a sweep reads was last touched >= 3 x 480 MB ago); roofline.frac_rotating
+                 and roofline.hbm_check_frac repeat their fractions beside roofline.frac
   roofline     — achieved algorithmic GB/s of the dominant (sweep) kernel from HIP events that
                  carry the dispatch's own timestamps, taken in a pass of their own AFTER the K
                  timed wall-clock steps (which run uninstrumented), vs the 8 TB/s HBM3E peak
@@ -107,6 +111,14 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true",
                     help="N=1: skip the configs block (BASELINE configs 2, 3 and 5 timed after the headline)")
+    ap.add_argument("--hbm-check-n", type=int, default=100_000_000,
+                    help="N=1: correspondences of configs.hbm_check, the sweep whose input (48 B each) is "
+                         "many times the 256 MiB Infinity Cache (0 = skip)")
+    ap.add_argument("--rotating-costs", type=int, default=4,
+                    help="N=1: distinct costs of the headline's size swept round-robin for "
+                         "roofline.frac_rotating (0 = skip)")
+    ap.add_argument("--rotating-launches", type=int, default=0,
+                    help="timed kernel launches per rotating cost (0 = min(kernel steps, 30))")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--deadline-s", type=float,
@@ -507,7 +519,19 @@ def main():
         est_step_s = 20e-6 + n_per_rank * BYTES_PER_CORRESPONDENCE[scalar_bytes] / 6.0e12
         return min(20000, max(50, int(ms * 1e-3 / est_step_s)))
 
-    def timed_pass(the_cost, combine, steps, warmup, settle, via_torch=None, mode=None, step_fn=None):
+    def counters(costs):
+        """(sweeps launched, calls answered from the kept result, sweeps dispatched through the
+        library's own AQL packets) summed over `costs`, as the library counts them."""
+        sw = hits = direct = 0
+        for c in costs:
+            a, h = c.stats()
+            sw, hits, direct = sw + a, hits + h, direct + c.direct_dispatches()
+        return sw, hits, direct
+
+    region = {}  # the library's counters over the most recent timed region (timed_pass fills it)
+
+    def timed_pass(the_cost, combine, steps, warmup, settle, via_torch=None, mode=None, step_fn=None,
+                   counted=None):
         """barrier | K blocking steps | barrier, wall clock, max over ranks.  Profiling is off.
         Returns (elapsed, H, sum, stamps): stamps[k] is this rank's clock after step k - 1
         (stamps[0] = t0), read between the steps — one clock read each, ~50 ns.
@@ -543,6 +567,8 @@ def main():
                 err = e
         stamps = [0.0] * (steps + 1)
         clock = time.perf_counter
+        counted = ([the_cost] if the_cost is not None else []) if counted is None else counted
+        before = counters(counted)  # nothing is launched between this reading and t0
         barrier()
         # The synchronisation that has to precede t0 is not free for the steps that follow it: it hands
         # the HIP runtime a marker, and when that completes a thread of the runtime releases every command
@@ -565,6 +591,10 @@ def main():
                 err = e
         barrier()
         elapsed = time.perf_counter() - t0
+        after = counters(counted)
+        region.clear()
+        region.update({"steps": steps, "costs": len(counted), "sweeps": after[0] - before[0],
+                       "cache_hits": after[1] - before[1], "direct_dispatches": after[2] - before[2]})
         if world > 1:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=ctl)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -642,6 +672,10 @@ def main():
         if res is None:
             raise SystemExit("rank %d: no way of adding the ranks' sums worked" % rank)
         elapsed, H, s, stamps = res
+    headline_region = dict(region, what="mopt_cost_stats / mopt_cost_direct_dispatches deltas of the "
+                           "headline's cost between t0 and t1 of the timed region: K steps are K sweeps "
+                           "launched, none answered from the kept result; direct_dispatches = K when the "
+                           "library's own AQL queue carried them, 0 on HIP streams")
 
     # ---- kernel time: a pass of its own, every launch carrying its dispatch timestamps ---------
     def kernel_pass(the_cost, steps, mode=None):
@@ -699,6 +733,7 @@ def main():
             k_ms, _ = kernel_pass(c1, min(ksteps, 30), mode=mode)
             ms = el / args.steps * 1e3
             return {"ms_per_step": ms, "value": n1 / (ms * 1e-3), "kernel_ms": k_ms,
+                    "timed_region": dict(region),
                     "frac": n1 * bpc / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "step_frac": n1 * bpc / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "median_step_us": step_times(st)["median"], "check_sum_sq": ssq}
@@ -714,13 +749,14 @@ def main():
         c1.close()
         n5, costs5, step5, kernel5 = camera_problem(mo, ds)
         mo.capi.link_costs(costs5)
-        el, _, y5, st = timed_pass(None, None, args.steps, args.warmup, 500, step_fn=step5)
+        el, _, y5, st = timed_pass(None, None, args.steps, args.warmup, 500, step_fn=step5, counted=costs5)
+        region5 = dict(region)
         mo.capi.link_costs([])
         k_ms = kernel5(min(ksteps, 30))
         ms = el / args.steps * 1e3
         out["cfg5"] = {"ms_per_step": ms, "value": n5 / (ms * 1e-3), "unit": "residual-blocks/s",
                        "kernel_ms": k_ms, "median_step_us": step_times(st)["median"],
-                       "check_sum_sq": y5,
+                       "check_sum_sq": y5, "timed_region": region5,
                        "workload": "camera-calibration reprojection cost: 100000 elements as two "
                                    "linked costs (40k + 60k), Geman-McClure(100), forward differences, "
                                    "both linearized and summed per step; kernel_ms = both sweeps"}
@@ -728,6 +764,85 @@ def main():
             c.close()
         out["note"] = ("1 GPU, f64, each timed as the headline: settle | %d warm-up | barrier | %d "
                        "blocking steps | barrier; kernel_ms from a pass of its own" % (args.warmup, args.steps))
+        return out
+
+    def cache_proof_configs():
+        """Two measurements of the headline's sweep that the 256 MiB Infinity Cache (MALL) cannot have
+        served (SURVEY.md §7 "Cache vs HBM"; MI355X_MICROARCH.md: FETCH_SIZE counts MALL hits, so the
+        PMC traffic figure cannot tell HBM from the cache).  rotating: R distinct costs of the headline's
+        size swept round-robin, so that every line a sweep reads was last touched (R - 1) x its input
+        ago; hbm_check: one cost whose input is many times the cache.  Neither involves the other
+        ranks (combine off, no barrier inside the kernel passes): at N > 1 every rank runs the rotating
+        kernel pass on its own GPU and rank 0's figure is reported."""
+        out = {}
+        if args.rotating_costs >= 2:
+            progress["stage"] = "rotating costs"
+            ring = [cost]
+            for k in range(1, args.rotating_costs):
+                extra, s_k, t_k = make_cost(args.n)
+                del s_k, t_k
+                ring.append(extra)
+            torch.cuda.empty_cache()
+            for c in ring:
+                c.set_combine(mo.COMBINE_NONE)
+            bound = [c.bound_linearize(jac_mode) for c in ring]
+
+            def rot_step(k):
+                call, x_in, H_out, b_out, s_out = bound[k % len(ring)]
+                x_in[:] = xs[k % 16]
+                call()
+                return H_out, b_out, s_out[0]
+
+            entry = {"costs": len(ring), "n": args.n, "bytes_between_reuse": (len(ring) - 1) * args.n * bpc,
+                     "workload": "the headline's sweep over %d distinct costs of %d correspondences each, "
+                                 "round-robin: a sweep's input was last read %d MB of other input ago"
+                                 % (len(ring), args.n, (len(ring) - 1) * args.n * bpc // 1_000_000)}
+            if world == 1:
+                rsteps = max(args.steps, 3 * len(ring))
+                el, _, _, st = timed_pass(None, None, rsteps, 2 * len(ring), 4 * len(ring), step_fn=rot_step,
+                                          counted=ring)
+                ms = el / rsteps * 1e3
+                entry.update({"ms_per_step": ms, "value": args.n / (ms * 1e-3),
+                              "step_frac": args.n * bpc / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "median_step_us": step_times(st)["median"], "timed_region": dict(region)})
+            for k in range(2 * len(ring)):
+                rot_step(k)
+            for c in ring:
+                c.set_profiling(1)
+            per_cost = args.rotating_launches if args.rotating_launches > 0 else max(min(ksteps, 30), 3)
+            for k in range(per_cost * len(ring)):
+                rot_step(k)
+            prof = [c.profile() for c in ring]
+            for c in ring:
+                c.set_profiling(False)
+            k_ms = sum(p[0] for p in prof) / max(sum(p[1] for p in prof), 1)
+            entry.update({"kernel_ms": k_ms, "kernel_launches_timed": sum(p[1] for p in prof),
+                          "frac": args.n * bpc / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "per_cost_kernel_ms": [p[0] / max(p[1], 1) for p in prof]})
+            out["rotating"] = entry
+            for c in ring[1:]:
+                c.close()
+        if args.hbm_check_n > 0 and world == 1:
+            progress["stage"] = "hbm_check"
+            nb = args.hbm_check_n
+            big, s_b, t_b = make_cost(nb)
+            del s_b, t_b
+            torch.cuda.empty_cache()
+            launches_b = min(ksteps, 30)
+            el, _, ssq, st = timed_pass(big, None, launches_b, 3, 3)
+            reg = dict(region)
+            k_ms, got = kernel_pass(big, launches_b)
+            ms = el / launches_b * 1e3
+            out["hbm_check"] = {
+                "n": nb, "input_bytes": nb * bpc, "kernel_ms": k_ms, "kernel_launches_timed": got,
+                "frac": nb * bpc / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "ms_per_step": ms, "value": nb / (ms * 1e-3),
+                "step_frac": nb * bpc / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "check_sum_sq": ssq, "timed_region": reg,
+                "workload": "the headline's sweep over one cost of %d correspondences: %.1f GB of input, "
+                            "%.0f x the 256 MiB Infinity Cache" % (nb, nb * bpc / 1e9, nb * bpc / 2 ** 28)}
+            big.close()
+        torch.cuda.empty_cache()
         return out
 
     progress["stage"] = "kernel-time pass"
@@ -817,7 +932,7 @@ def main():
             "algorithmic_bytes_per_launch": args.n * bpc,
         },
         "pct_hbm_peak": 100.0 * achieved / HBM_PEAK_GBS,
-        "check": {"sum_sq": float(s), "H00": float(H[0, 0])},
+        "check": {"sum_sq": float(s), "H00": float(H[0, 0]), "timed_region": headline_region},
         "timing": step_times(stamps, elapsed if world == 1 else None),
     })
     if world > 1:
@@ -848,16 +963,49 @@ def main():
         line["roofline"]["literal_kernel_ms"] = literal_ms
         line["roofline"]["literal_frac"] = args.n * bpc / (literal_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
 
+    # ---- the HBM figure proper: the same kernel where no cache can hold a sweep's input -----------
+    # roofline.frac is a statement about HBM.  The headline's own cost is swept back to back (that is what
+    # an LM loop does, and what `value` measures), and a part of its 480 MB survives in the 32 MiB of L2
+    # and the 256 MiB Infinity Cache from one sweep to the next: measured, the same kernel on the same
+    # cost takes ~70 us back to back and ~74 us with three other costs swept in between.  So the roofline
+    # figures are taken over the rotating costs; the back-to-back figure stays beside them.
+    same_cost = {"kernel_ms": kernel_ms, "kernel_launches_timed": launches, "achieved": achieved,
+                 "frac": achieved / HBM_PEAK_GBS,
+                 "what": "the headline's own cost swept back to back, as the timed steps run it: includes "
+                         "what L2 and the Infinity Cache keep of its input from one sweep to the next"}
+    line["roofline"]["measured_over"] = "one cost, back to back"
+    try:
+        proof = cache_proof_configs()
+    except Exception as e:  # noqa: BLE001 - an extra must not cost the headline its line
+        proof = {"cache_proof_error": repr(e)}
+        log("cache-proof block failed: %r" % (e,))
+    if "rotating" in proof:
+        rot = proof["rotating"]
+        roof = line["roofline"]
+        roof["same_cost"] = same_cost
+        roof["kernel_ms"], roof["kernel_launches_timed"] = rot["kernel_ms"], rot["kernel_launches_timed"]
+        roof["achieved"] = args.n * bpc / (rot["kernel_ms"] * 1e-3) / 1e9
+        roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+        roof["frac_rotating"] = roof["frac"]
+        roof["frac_same_cost"] = same_cost["frac"]
+        roof["measured_over"] = ("%d distinct costs of %d correspondences swept round-robin (%d MB of other "
+                                 "input between two sweeps of the same bytes): HBM only"
+                                 % (rot["costs"], args.n, rot["bytes_between_reuse"] // 1_000_000))
+        line["pct_hbm_peak"] = 100.0 * roof["frac"]
+    if "hbm_check" in proof:
+        line["roofline"]["hbm_check_frac"] = proof["hbm_check"]["frac"]
+    if proof:
+        line.setdefault("configs", {}).update(proof)
+
     # ---- the other BASELINE configs that fit one GPU, driver-timed in the same line ------------
     if (world == 1 and not args.no_configs and args.dtype == "f64" and args.cov == "identity"
             and args.loss == "none"):
         progress["stage"] = "configs 1, 2, 3, 5"
         try:
-            line["configs"] = baseline_configs()
+            line.setdefault("configs", {}).update(baseline_configs())
         except Exception as e:  # noqa: BLE001 - an extra must not cost the headline its line
-            line["configs"] = {"error": repr(e)}
+            line.setdefault("configs", {})["error"] = repr(e)
             log("configs block failed: %r" % (e,))
-
     # ---- CPU baseline: rank 0's host cores, every world size -----------------------------------
     progress["stage"] = "cpu baseline"
     if rank == 0:

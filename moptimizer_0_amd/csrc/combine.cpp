@@ -14,6 +14,8 @@
 
 #include <cerrno>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 using namespace mopt_detail;
 
@@ -35,6 +37,37 @@ int checkRanks(const mopt_cost *c, int rank, int num_ranks, int limit) {
   return MOPT_OK;
 }
 
+// Slot blocks exported by THIS process.  hipIpcOpenMemHandle refuses a handle of the opening process's
+// own allocation, and ranks need not be processes: one process may hold several ranks' costs (a thread
+// per GPU, as mopt_group_* does; 8 ranks rehearsed on a box that admits fewer processes).  A handle
+// found here is attached through the pointer it was made from.
+struct OwnExport {
+  hipIpcMemHandle_t handle;
+  double *block;
+  int device;
+};
+std::mutex g_own_exports_mutex;
+std::vector<OwnExport> g_own_exports;
+
+double *ownExport(const hipIpcMemHandle_t &handle, int *device) {
+  std::lock_guard<std::mutex> lock(g_own_exports_mutex);
+  for (const OwnExport &e : g_own_exports)
+    if (std::memcmp(&e.handle, &handle, sizeof handle) == 0) {
+      *device = e.device;
+      return e.block;
+    }
+  return nullptr;
+}
+
+void forgetOwnExport(const double *block) {
+  std::lock_guard<std::mutex> lock(g_own_exports_mutex);
+  for (size_t k = 0; k < g_own_exports.size(); ++k)
+    if (g_own_exports[k].block == block) {
+      g_own_exports.erase(g_own_exports.begin() + long(k));
+      return;
+    }
+}
+
 unsigned long long peerTimeoutTicks(int device) {
   int khz = 0;
   if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) != hipSuccess || khz <= 0)
@@ -53,7 +86,10 @@ void releaseCombine(mopt_cost *c) {
     sc.peer_opened[k] = false;
     sc.peer_blocks[k] = nullptr;
   }
-  if (sc.peer_own) (void)hipFree(sc.peer_own);
+  if (sc.peer_own) {
+    forgetOwnExport(sc.peer_own);
+    (void)hipFree(sc.peer_own);
+  }
   sc.peer_own = nullptr;
   sc.peer_attached = false;
   if (sc.host_registered) (void)hipHostUnregister(sc.host_block);
@@ -173,6 +209,10 @@ int mopt_cost_peer_export(mopt_cost *c, int num_ranks, void *handle_out) {
     return fail(MOPT_ERR_HIP, std::string("exporting the slot block (hipIpcGetMemHandle): ") +
                                   hipGetErrorString(e));
   }
+  {
+    std::lock_guard<std::mutex> lock(g_own_exports_mutex);
+    g_own_exports.push_back({handle, sc.peer_own, c->device});
+  }
   std::memcpy(handle_out, &handle, sizeof handle);
   return MOPT_OK;
 }
@@ -186,6 +226,17 @@ int mopt_cost_peer_attach(mopt_cost *c, const void *handles, int rank, int num_r
   if (sc.peer_attached) return fail(MOPT_ERR_INVALID_ARGUMENT, "peers are already attached");
   MOPT_HIP_TRY(hipSetDevice(c->device));
   const char *bytes = static_cast<const char *>(handles);
+  // a failure at rank k undoes the mappings made for the ranks before it.  The own block stays
+  // allocated: other ranks may have opened its exported handle already (it is released with the
+  // cost); mopt_cost_peer_attach may be called again with new handles
+  auto undo = [&](int k) {
+    for (int q = 0; q < k; ++q) {
+      if (sc.peer_opened[q]) (void)hipIpcCloseMemHandle(sc.peer_blocks[q]);
+      sc.peer_opened[q] = false;
+      sc.peer_blocks[q] = nullptr;
+    }
+    sc.peer_blocks[rank] = nullptr;
+  };
   for (int k = 0; k < num_ranks; ++k) {
     if (k == rank) {
       sc.peer_blocks[k] = sc.peer_own;
@@ -193,17 +244,27 @@ int mopt_cost_peer_attach(mopt_cost *c, const void *handles, int rank, int num_r
     }
     hipIpcMemHandle_t handle;
     std::memcpy(&handle, bytes + size_t(k) * sizeof handle, sizeof handle);
+    int owner_device = c->device;
+    if (double *same_process = ownExport(handle, &owner_device)) {
+      // a rank of this very process: no IPC mapping; another GPU's block needs peer access switched
+      // on for this device (what hipIpcMemLazyEnablePeerAccess does for an opened handle)
+      if (owner_device != c->device) {
+        const hipError_t pe = hipDeviceEnablePeerAccess(owner_device, 0);
+        if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) {
+          (void)hipGetLastError();
+          undo(k);
+          return fail(MOPT_ERR_HIP, "peer access to the slot block of rank " + std::to_string(k) +
+                                        " (hipDeviceEnablePeerAccess): " + hipGetErrorString(pe));
+        }
+        (void)hipGetLastError();
+      }
+      sc.peer_blocks[k] = same_process;
+      continue;
+    }
     void *p = nullptr;
     const hipError_t e = hipIpcOpenMemHandle(&p, handle, hipIpcMemLazyEnablePeerAccess);
     if (e != hipSuccess) {
-      for (int q = 0; q < k; ++q) {
-        if (sc.peer_opened[q]) (void)hipIpcCloseMemHandle(sc.peer_blocks[q]);
-        sc.peer_opened[q] = false;
-        sc.peer_blocks[q] = nullptr;
-      }
-      // the own block stays allocated: other ranks may have opened its exported handle already
-      // (it is released with the cost); mopt_cost_peer_attach may be called again with new handles
-      sc.peer_blocks[rank] = nullptr;
+      undo(k);
       return fail(MOPT_ERR_HIP, "opening the slot block of rank " + std::to_string(k) +
                                     " (hipIpcOpenMemHandle): " + hipGetErrorString(e));
     }

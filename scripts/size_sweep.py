@@ -35,7 +35,7 @@ def measure(cost, x, mode, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tag", default="r1")
-    ap.add_argument("--max-n", type=int, default=100_000_000)
+    ap.add_argument("--max-n", type=int, default=300_000_000)
     args = ap.parse_args()
     import torch
     import moptimizer_0_amd as mo
@@ -47,7 +47,7 @@ def main():
     rows = []
     for dtype, tdt, ndt, bpp in (("f64", torch.float64, np.float64, 48), ("f32", torch.float32, np.float32, 24)):
         x = ds.X_GENERIC.astype(ndt)
-        for n in (1_000, 10_000, 100_000, 1_000_000, 10_000_000, 100_000_000):
+        for n in (1_000, 10_000, 100_000, 1_000_000, 3_000_000, 10_000_000, 30_000_000, 100_000_000, 300_000_000):
             if n > args.max_n:
                 continue
             src, tgt = make_shard_on_gpu(torch, n, 0, tdt)

@@ -16,7 +16,8 @@ pytestmark = pytest.mark.gpu
 
 def test_single_gpu_line_carries_every_object(hip_lib):
     out = subprocess.run([sys.executable, os.path.join(ds.ROOT, "bench.py"), "--gpus", "1", "--steps", "20",
-                          "--warmup", "5", "--n", "1000000", "--cpu-seconds", "1"],
+                          "--warmup", "5", "--n", "1000000", "--cpu-seconds", "1", "--hbm-check-n", "3000000",
+                          "--rotating-costs", "3"],
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert out.returncode == 0, out.stderr.decode()[-3000:]
     lines = [ln for ln in out.stdout.decode().splitlines() if ln.strip()]
@@ -44,3 +45,23 @@ def test_single_gpu_line_carries_every_object(hip_lib):
     assert 0 < c1["solve_ms"] < 5.0 and c1["solve_sweeps"] >= c1["solve_iterations"] >= 2
     x = np.array(c1["solve_x"])
     assert np.abs(x[:3] - ds.FIXTURE_T).max() < 0.05, x
+    # the timed region as the library counted it: K steps were K sweeps over the data, none answered from
+    # a kept result, every one through the library's own packets (or none: MOPT_AQL=0 / a profiler)
+    reg = line["check"]["timed_region"]
+    assert reg["sweeps"] == 20 and reg["cache_hits"] == 0 and reg["direct_dispatches"] in (0, 20), reg
+    if os.environ.get("MOPT_AQL", "1") != "0":
+        assert reg["direct_dispatches"] == 20, reg
+    for name in ("cfg2", "cfg3", "cfg3_literal"):
+        r = cfgs[name]["timed_region"]
+        assert r["sweeps"] == 20 and r["cache_hits"] == 0, (name, r)
+    r5 = cfgs["cfg5"]["timed_region"]
+    assert r5["sweeps"] == 40 and r5["cache_hits"] == 0 and r5["costs"] == 2, r5
+    # the two measurements no cache can have served (at the bench's real sizes: 100 M and 4 x 10 M)
+    rot, big = cfgs["rotating"], cfgs["hbm_check"]
+    assert rot["costs"] == 3 and rot["timed_region"]["sweeps"] == rot["timed_region"]["steps"] >= 20
+    assert rot["timed_region"]["cache_hits"] == 0 and 0 < rot["frac"] < 1.2 and rot["kernel_ms"] > 0
+    assert big["n"] == 3000000 and big["timed_region"]["sweeps"] == big["timed_region"]["steps"] > 0
+    assert big["timed_region"]["cache_hits"] == 0 and 0 < big["frac"] < 1.2
+    assert line["roofline"]["frac_rotating"] == rot["frac"] and line["roofline"]["hbm_check_frac"] == big["frac"]
+    # the sum of squares is additive over correspondences: 3 M of the same distribution ~ 3 x the 1 M shard's
+    assert 2.5 < big["check_sum_sq"] / line["check"]["sum_sq"] < 3.5

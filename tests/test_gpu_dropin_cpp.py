@@ -45,3 +45,16 @@ def test_cpp_device_resident_optimizer(hip_lib):
     print(out.stdout[-8000:])
     assert out.returncode == 0, out.stdout[-8000:] + out.stderr[-2000:]
     assert ", 0 failures" in out.stdout
+
+
+def test_cpp_binding_every_class_on_the_device(hip_lib):
+    """tests/cpp/reference_headers_binding.cpp over host_api.hpp: every cost class and device model of
+    the binding, float and double, built on the GPU and linearized with GemmanMCClure + a covariance
+    set through the base class's setters.  (The CPU suite compiles the same source against the
+    reference's own headers, where every construction must end in the NO_DEVICE exception.)"""
+    exe = os.path.join(ds.ROOT, "tests", "cpp", "_build", "binding_all_classes")
+    assert os.path.exists(exe), "build it with `make cpptests`"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    print(out.stdout[-8000:])
+    assert out.returncode == 0, out.stdout[-8000:] + out.stderr[-2000:]
+    assert ", 0 failures; 28 costs built on a device, 0 refused" in out.stdout

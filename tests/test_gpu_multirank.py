@@ -57,6 +57,84 @@ def run_ranks(tmp_path, world, n_total, extra_env=None, timeout=420):
     return [np.load(os.path.join(tmp_path, "rank%d.npz" % r)) for r in range(world)]
 
 
+def run_thread_ranks(tmp_path, world, processes, n_total, extra_env=None, timeout=420):
+    """`world` ranks as `processes` processes of world / processes rank threads each
+    (tests/multirank_threads_worker.py): how this pool — at most 6 processes on a GPU at once, the
+    test runner being one — reaches world size 8."""
+    assert world % processes == 0
+    here = world // processes
+    shm = "/mopt-test-%d-%x" % (os.getpid(), int.from_bytes(os.urandom(4), "little"))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MOPT_TEST_SHM=shm)
+    env.update(extra_env or {})
+    procs = [subprocess.Popen([sys.executable, os.path.join(ds.ROOT, "tests", "multirank_threads_worker.py"),
+                               str(tmp_path), str(n_total), str(world), str(k * here), str(here)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for k in range(processes)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out.decode())
+    for k, p in enumerate(procs):
+        assert p.returncode == 0, "process %d (ranks %d..%d) failed:\n%s" % (k, k * here, k * here + here - 1,
+                                                                             outs[k][-4000:])
+    return [np.load(os.path.join(tmp_path, "rank%d.npz" % r)) for r in range(world)]
+
+
+@pytest.mark.parametrize("world,processes", [(8, 4), (8, 2), (4, 4)])
+def test_eight_ranks_combine_through_the_library(hip_lib, tmp_path, world, processes):
+    """BASELINE config 4's world size, G = kMaxPeers = 8 (csrc/sweep.hpp) — every one of the eight
+    slots of both fused transports in use — on the one GPU there is: the 43 sums of every sweep on every
+    rank are, word for word, the per-shard sums added in shard order (levenberg_marquadt_dyn.cpp:57-59
+    across shards); 300 linearizations back to back per transport; the device-resident loop over the
+    peer slots takes identical iterates on all eight ranks and lands on the unsharded solution.
+    (8, 4): 4 processes x 2 rank threads - IPC handles between processes and same-process pointers
+    mixed; (8, 2): 4 rank threads per process; (4, 4): the threaded worker with one rank per process,
+    IPC only."""
+    res = run_thread_ranks(tmp_path, world, processes, 400_009)
+    for name in ("host", "peer"):
+        for jm in (0, 2):
+            for xi in range(3):
+                want = res[0]["expected_%d_%d" % (jm, xi)]
+                for r in range(world):
+                    got = res[r]["%s_%d_%d" % (name, jm, xi)]
+                    # bit-equal: same shards, same kernels, the G additions in shard order
+                    assert got[:43].tobytes() == want[:43].tobytes(), (name, jm, xi, r)
+                    assert got[43] == want[43], (name, jm, xi, r)
+        want = res[0]["expected_linchain"]
+        for r in range(world):
+            bad = np.argwhere(res[r][name + "_linchain"] != want)
+            assert bad.size == 0, (name, r, bad[:5])
+    for r in range(1, world):
+        assert list(res[r]["lm_rep"]) == list(res[0]["lm_rep"])
+        assert res[r]["lm_x"].tobytes() == res[0]["lm_x"].tobytes()
+        assert res[r]["after_lm"].tobytes() == res[0]["after_lm"].tobytes()
+    assert res[0]["lm_rep"][0] == res[0]["lm_whole_rep"][0]
+    assert abs(int(res[0]["lm_rep"][1]) - int(res[0]["lm_whole_rep"][1])) <= 1
+    assert np.abs(res[0]["lm_x"] - res[0]["lm_whole_x"]).max() < 1e-9 * 11
+    assert np.abs(res[0]["lm_x"] - ds.FIXTURE_X).max() < 1e-3
+
+
+def test_a_ninth_rank_is_refused_by_name(hip_lib):
+    """One past kMaxPeers: the device-side combine says so when asked (MOPT_ERR_INVALID_ARGUMENT, the
+    limit in the message); the host slots, which have no such limit, attach."""
+    src, tgt = ds.synthetic_pair(5000, seed=3)
+    cost = hip_lib.Point2PointCost(src, tgt)
+    with pytest.raises(hip_lib.MoptError, match="at most 8 ranks"):
+        cost.peer_export(9)
+    handle = cost.peer_export(8)
+    with pytest.raises(hip_lib.MoptError, match="bad rank / num_ranks"):
+        cost.peer_attach([handle] * 9, 0, 9)
+    name = "/mopt-test-nine-%d" % os.getpid()
+    cost.hostcomm_attach(name, 8, 9)
+    assert cost.get_combine()[1:] == (8, 9)
+    cost.close()
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_ranks_combine_through_the_library(hip_lib, tmp_path, world):
     res = run_ranks(tmp_path, world, 200_003)
