@@ -306,9 +306,10 @@ MOPT_API int mopt_cost_stats(const mopt_cost *cost, int64_t *sweeps, int64_t *ca
  * point2point, reprojection and built-in scalar-model costs; csrc/aql.hpp says why: 1-3 us per call).  Same kernels, same
  * numbers.  MOPT_AQL=0 in the environment keeps everything on HIP streams. */
 MOPT_API int mopt_cost_direct_dispatches(const mopt_cost *cost, int64_t *sweeps);
-/* Gives back the HSA queues the direct path holds on `device` (they are created with the first cost
- * and otherwise kept for the life of the process; the next cost creates them again, a few
- * milliseconds).  Each is a hardware queue of the GPU, and processes that share one GPU can run out
+/* Gives back the HSA queues the direct path holds on `device` (each is created when a cost first
+ * takes that path — costs with a correspondence search, run-time compiled models and RCCL-combined
+ * shards never do — and otherwise kept for the life of the process; the next such cost creates one
+ * again, a few milliseconds).  Each is a hardware queue of the GPU, and processes that share one GPU can run out
  * of them — a parent that has finished its own costs calls this before it starts workers on the
  * same GPU.  MOPT_ERR_INVALID_ARGUMENT while a cost of this process lives on the device. */
 MOPT_API int mopt_device_trim(int device);
@@ -398,7 +399,11 @@ MOPT_API int mopt_cost_comm_info(const mopt_cost *cost, int *num_ranks, int *ran
  *   mopt_cost_peer_export       allocates this rank's slot block and returns its IPC handle
  *                               (MOPT_PEER_HANDLE_BYTES); the caller gathers the handles of all
  *                               ranks, in rank order, by any means
- *   mopt_cost_peer_attach       opens them (handles: num_ranks * MOPT_PEER_HANDLE_BYTES)
+ *   mopt_cost_peer_attach       opens them (handles: num_ranks * MOPT_PEER_HANDLE_BYTES); at most
+ *                               8 ranks (one node).  Ranks need not be processes: a handle that
+ *                               was exported by the calling process itself (several ranks' costs
+ *                               in one process, a thread each) is attached through the block's own
+ *                               pointer, with peer access enabled when it lives on another GPU
  *
  * A peer that never arrives ends the device-side wait after MOPT_PEER_TIMEOUT_MS (default 5000)
  * and the call returns MOPT_ERR_PEER_TIMEOUT; the host-side wait is bounded the same way. */

@@ -82,7 +82,17 @@ bool enabled() {
     const char *cc = std::getenv("ROCPROF_COUNTER_COLLECTION");
     const char *counters = std::getenv("ROCPROF_COUNTERS");
     const char *v1 = std::getenv("ROCP_INPUT");
-    if ((cc && cc[0] == '1') || (counters && *counters) || (v1 && *v1)) return v && v[0] == '2';  // MOPT_AQL=2 forces it
+    if ((cc && cc[0] == '1') || (counters && *counters) || (v1 && *v1)) {
+      if (v && v[0] == '2') return true;  // MOPT_AQL=2 forces it
+      // said once, on stderr: an evidence run states its dispatch path itself (these variable names are a
+      // guess at what the profiler exports; should a later ROCm rename them, the blocking wait's bound is
+      // what is left — this line missing from a --pmc run's log is the sign)
+      std::fprintf(stderr,
+                   "libmoptimizer_hip: a per-dispatch counter profiler is attached (%s): blocking sweeps stay on "
+                   "HIP streams, the direct AQL path is off (MOPT_AQL=2 forces it on)\n",
+                   (cc && cc[0] == '1') ? "ROCPROF_COUNTER_COLLECTION" : (counters && *counters) ? "ROCPROF_COUNTERS" : "ROCP_INPUT");
+      return false;
+    }
     return true;
   }();
   return on;
@@ -258,11 +268,11 @@ bool aqlRetain(int device) {
   DeviceState *d = deviceState(device);
   if (!d) return false;
   std::lock_guard<std::mutex> lock(d->mutex);
-  ++d->users;  // (counted either way: a cost may draw a queue later, and aqlTrim must know it lives)
-  const char *shared = std::getenv("MOPT_AQL_SHARDED");
-  if (shared && shared[0] == '0') return true;  // processes share the GPU: a queue only when a cost asks
-  for (AqlQueue &q : d->queues)
-    if (!q.queue && !q.faulted.load() && !createQueue(*d, q)) q.faulted.store(true);
+  // Counted only: a hardware queue (and its 1 MiB argument ring) is created when a cost that can use
+  // the direct path first asks for one (aqlAcquireQueue) — costs with a correspondence search,
+  // run-time compiled models and RCCL-combined shards never do, and processes that share a GPU must
+  // not pin queues they will not use.  aqlTrim must still know that a cost lives here.
+  ++d->users;
   return true;
 }
 
@@ -327,6 +337,12 @@ const AqlKernel *aqlLookup(int device, const void *host_function) {
     it = d->kernels.emplace(host_function, kernel).first;
   }
   return it->second.object ? &it->second : nullptr;
+}
+
+void aqlForgetStamp(AqlQueue *q, const void *owner) {
+  if (!q || !owner) return;
+  std::lock_guard<std::mutex> lock(q->mutex);
+  if (q->stamp_owner == owner) q->stamp_owner = nullptr;  // (after a drain: its dispatch has completed)
 }
 
 bool aqlFaulted(const AqlQueue *queue) { return queue && queue->faulted.load(std::memory_order_acquire); }
@@ -454,7 +470,13 @@ bool aqlDispatch(AqlQueue *q, const AqlKernel *kernel, uint32_t grid, uint32_t b
   packet->kernarg_address = slot;
   packet->reserved2 = 0;
   packet->completion_signal.handle = 0;
-  if (timed_for && q->stamped.handle && (!q->stamp_owner || q->stamp_owner == timed_for)) {
+  // One timed dispatch outstanding per queue.  The signal is armed for this one only when nothing is
+  // outstanding: no owner, or an owner whose dispatch has completed (signal below 1) and was never read —
+  // a cost that was destroyed, or a call that did not collect.  While an earlier timed dispatch is still in
+  // flight — the same cost's superseded prefetch, say — this one goes untimed: re-arming would let the
+  // earlier packet's completion release the wait and hand out the wrong timestamps.
+  if (timed_for && q->stamped.handle &&
+      (!q->stamp_owner || hsa_signal_load_relaxed(q->stamped) < 1)) {
     hsa_signal_store_relaxed(q->stamped, 1);
     packet->completion_signal = q->stamped;
     q->stamp_owner = timed_for;

@@ -54,14 +54,17 @@ struct AqlKernel {
 
 // A queue of `device`'s pool (round robin), or nullptr when the direct path is unavailable.
 AqlQueue *aqlAcquireQueue(int device);
-// One more / one fewer cost lives on `device`.  The first one creates the device's queues (a few
-// milliseconds, here rather than inside the first blocking sweep); they then stay for the process
-// (a caller that builds one cost per outer iteration must not pay for queues each time) unless
-// aqlTrim gives them back.  aqlRetain returns whether it counted (false where the direct path is
-// off): only then call aqlRelease.  Under MOPT_AQL_SHARDED=0 it counts but creates nothing (a
-// queue is then made when an unsharded cost first asks for one).
+// One more / one fewer cost lives on `device`.  Counting only: a queue is created when a cost that can
+// use the direct path first asks for one (aqlAcquireQueue, a few milliseconds inside that cost's first
+// blocking sweep) — costs that never take the path (a correspondence search, run-time compiled models,
+// RCCL) pin no hardware queue.  Queues then stay for the process (a caller that builds one cost per
+// outer iteration must not pay for them each time) unless aqlTrim gives them back.  aqlRetain returns
+// whether it counted (false where the direct path is off): only then call aqlRelease.
 bool aqlRetain(int device);
 void aqlRelease(int device);
+// `owner` is going away (after a drain): a timed dispatch of its that nobody read no longer holds the
+// queue's profiling signal.
+void aqlForgetStamp(AqlQueue *queue, const void *owner);
 // Destroys the device's queues if no cost lives on it (true), else leaves them (false): every queue
 // is a hardware queue of the GPU, and processes that share one run out of them (MOPT_AQL_SHARDED).
 bool aqlTrim(int device);

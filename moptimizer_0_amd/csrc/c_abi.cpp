@@ -86,6 +86,7 @@ struct SweepTimer {
   const mopt_detail::AqlSite *aql() {
     if (!aql_used) return nullptr;
     c->stat_direct_sweeps += 1;
+    c->sweep_went_direct = true;
     finalize_site = site.aql;
     finalize_site.timed_for = nullptr;
     return &finalize_site;
@@ -715,8 +716,8 @@ void chooseDispatchPath(mopt_cost *c) {
     }
     c->aql_now.queue = c->aql_queue;
     c->aql_now.device = c->device;
-    c->aql_touched = true;
-    c->waiting_direct = true;
+    c->sweep_went_direct = false;
+    c->waiting_direct = true;  // provisional: settleDispatchPath corrects it once the launch has happened
     return;
   }
   if (c->aql_touched && c->aql_queue) {  // (a superseded prefetch may still be queued there)
@@ -725,6 +726,25 @@ void chooseDispatchPath(mopt_cost *c) {
   }
   c->hip_pending = true;
   c->waiting_direct = false;
+  c->sweep_went_direct = false;
+}
+
+// After the launch: where the sweep really went.  chooseDispatchPath only OFFERS the direct path; the
+// launch itself can still end up on the HIP stream — a profiled sweep of a model that is timed with a
+// recorded event pair (scalar models), a kernel the loader lookup did not find.  Then the whole call is
+// a HIP-stream call: the wait queries the stream (a faulted kernel is an error at once, not a 60 s
+// time-out), command batches are bounded, and the next direct sweep first waits for the stream.
+void settleDispatchPath(mopt_cost *c) {
+  c->aql_now = mopt_detail::AqlSite();
+  if (c->sweep_went_direct) {
+    c->aql_touched = true;
+    return;
+  }
+  if (c->waiting_direct) {
+    c->waiting_direct = false;
+    c->hip_pending = true;
+    c->aql_timed = false;
+  }
 }
 
 mopt::HostPublish nextPublish(mopt_cost *c, int offset) {
@@ -748,9 +768,15 @@ int waitAndSumHostSlots(mopt_cost *c, unsigned long long sequence, int offset, i
         reinterpret_cast<const unsigned long long *>(slot + mopt::kSlotFlag);
     while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) < sequence) {
       if ((++spins & 0x3fff) == 0) {
-        const hipError_t q = hipStreamQuery(c->stream);
-        if (q != hipSuccess && q != hipErrorNotReady)
-          return fail(MOPT_ERR_HIP, std::string("sweep failed: ") + hipGetErrorString(q));
+        // this rank's own sweep first: a local fault must not be reported as a peer that stays away
+        if (c->waiting_direct) {
+          if (mopt_detail::aqlFaulted(c->aql_queue))
+            return fail(MOPT_ERR_HIP, "sweep failed: the direct-dispatch queue reported an error");
+        } else {
+          const hipError_t q = hipStreamQuery(c->stream);
+          if (q != hipSuccess && q != hipErrorNotReady)
+            return fail(MOPT_ERR_HIP, std::string("sweep failed: ") + hipGetErrorString(q));
+        }
         if (std::chrono::steady_clock::now() - started > limit)
           return fail(MOPT_ERR_PEER_TIMEOUT, "rank " + std::to_string(k) +
                                                  " did not publish its sums (MOPT_PEER_TIMEOUT_MS)");
@@ -789,7 +815,7 @@ int blockingSweep(mopt_cost *c, bool cost_only, int jac_mode, const void *x) {
   auto launch = [&](const mopt::HostPublish &pub) {
     const int rc = cost_only ? costAsyncImpl(c, x, c->d_result + offset, c->stream, pub)
                              : linearizeAsyncImpl(c, jac_mode, x, c->d_result, c->stream, pub);
-    c->aql_now = mopt_detail::AqlSite();
+    settleDispatchPath(c);
     return rc;
   };
   switch (c->combine.mode) {
@@ -811,21 +837,26 @@ int blockingSweep(mopt_cost *c, bool cost_only, int jac_mode, const void *x) {
       pub.host_result = slot + offset;
       pub.host_flag = reinterpret_cast<unsigned long long *>(slot + mopt::kSlotFlag);
       pub.sequence = seq;
+      c->aql_timed = false;
       int rc = launch(pub);
       if (rc != MOPT_OK) return rc;
       boundCommandBatch(c);
-      return waitAndSumHostSlots(c, seq, offset, count);
+      rc = waitAndSumHostSlots(c, seq, offset, count);
+      collectDirectTiming(c, rc);
+      return rc;
     }
     case MOPT_COMBINE_PEER: {
       const mopt::PeerCombine pc = nextPeerCombine(c, offset);
       mopt::HostPublish pub = nextPublish(c, offset);
       pub.host_status = c->h_flag_dev + 1;
       c->launch_peers = &pc;
+      c->aql_timed = false;
       int rc = launch(pub);
       c->launch_peers = nullptr;
       if (rc != MOPT_OK) return rc;
       boundCommandBatch(c);
       rc = waitPublished(c, pub.sequence);
+      collectDirectTiming(c, rc);
       if (rc != MOPT_OK) return rc;
       if (__atomic_load_n(c->h_flag + 1, __ATOMIC_ACQUIRE) == mopt::kStatusPeerTimeout)
         return fail(MOPT_ERR_PEER_TIMEOUT,
@@ -1297,7 +1328,7 @@ int launchPublishedSweep(mopt_cost *c, bool cost_only, int jac_mode, const void 
   c->aql_timed = false;
   const int rc = cost_only ? costAsyncImpl(c, x, c->d_result + offset, c->stream, pub)
                            : linearizeAsyncImpl(c, jac_mode, x, c->d_result, c->stream, pub);
-  c->aql_now = mopt_detail::AqlSite();
+  settleDispatchPath(c);
   if (rc == MOPT_OK) boundCommandBatch(c);
   return rc;
 }
@@ -1374,7 +1405,7 @@ int commonCreate(mopt_cost *c, int device) {
   c->h_flag = reinterpret_cast<unsigned long long *>(c->h_result + kResultSlots);
   MOPT_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&c->h_result_dev), c->h_result, 0));
   c->h_flag_dev = reinterpret_cast<unsigned long long *>(c->h_result_dev + kResultSlots);
-  // the device's direct-dispatch queues (aql.hpp) exist while a cost of this process lives on it
+  // counted as a user of the device's direct-dispatch queues (aql.hpp; created when a cost first takes that path)
   c->aql_retained = mopt_detail::aqlRetain(device);
   return MOPT_OK;
 }
@@ -1385,6 +1416,8 @@ hipError_t quiesceCost(mopt_cost *c) {
     (void)mopt_detail::aqlDrain(c->aql_queue);
     c->aql_touched = false;
   }
+  if (c->aql_queue) mopt_detail::aqlForgetStamp(c->aql_queue, c);  // (a timed dispatch nobody collected)
+  c->aql_timed = false;
   if (c->stream) first = hipStreamSynchronize(c->stream);
   c->hip_pending = false;
   c->own_async_pending = false;

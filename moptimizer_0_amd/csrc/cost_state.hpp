@@ -140,6 +140,7 @@ struct mopt_cost {
   bool aql_touched = false;
   bool hip_pending = false;
   bool waiting_direct = false;  // the sweep being waited for went through the direct path
+  bool sweep_went_direct = false;  // set by the launch itself (SweepTimer::aql) when it did
   bool aql_timed = false;       // ... and its dispatch is being timed (profiling)
 
   double cov[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};  // row-major, stride 3 (m <= 3), as double

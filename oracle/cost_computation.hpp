@@ -55,26 +55,36 @@ class CostComputation {
   // linearization.h:49-63.  The reference hands every TBB worker the same residual scratch
   // (a data race, :56); here each worker owns its scratch and the partials are joined with
   // plus<Scalar> in worker order.  Identity is the float literal 0.0f as at :53.
+  // TBB keeps a pool of workers and splits the range by grain; this restatement starts
+  // std::threads per call, so the worker count is capped at one per kParallelGrain elements and a
+  // single worker runs on the calling thread: otherwise a small problem times pthread_create (256
+  // launches per call on a 256-core host: 50 ms for 1 k points), not the reference's loop.
+  static constexpr int kParallelGrain = 4096;
   Scalar parallelComputeCost(const Scalar *x, ModelPtr model, int num_elements,
                              int num_threads = 0) {
     model->setup(x);
     int workers = num_threads > 0 ? num_threads : int(std::thread::hardware_concurrency());
+    const int by_grain = (num_elements + kParallelGrain - 1) / kParallelGrain;
+    if (num_threads <= 0 && workers > by_grain) workers = by_grain;
+    if (workers > num_elements) workers = num_elements;
     if (workers < 1) workers = 1;
-    if (workers > num_elements) workers = num_elements > 0 ? num_elements : 1;
     std::vector<Scalar> partial(workers, Scalar(0.0f));
     std::vector<std::thread> pool;
     const int m = m_;
-    for (int t = 0; t < workers; ++t) {
-      pool.emplace_back([&, t]() {
-        const long long lo = (long long)num_elements * t / workers;
-        const long long hi = (long long)num_elements * (t + 1) / workers;
-        std::vector<Scalar> r(m);
-        Scalar init = Scalar(0.0f);
-        for (long long it = lo; it < hi; ++it) {
-          if (model->f(x, r.data(), (unsigned int)it)) init += dot(r.data(), r.data(), m);
-        }
-        partial[t] = init;
-      });
+    auto work = [&](int t) {
+      const long long lo = (long long)num_elements * t / workers;
+      const long long hi = (long long)num_elements * (t + 1) / workers;
+      std::vector<Scalar> r(m);
+      Scalar init = Scalar(0.0f);
+      for (long long it = lo; it < hi; ++it) {
+        if (model->f(x, r.data(), (unsigned int)it)) init += dot(r.data(), r.data(), m);
+      }
+      partial[t] = init;
+    };
+    if (workers == 1) {
+      work(0);
+    } else {
+      for (int t = 0; t < workers; ++t) pool.emplace_back(work, t);
     }
     for (auto &th : pool) th.join();
     Scalar total = Scalar(0.0f);

@@ -17,8 +17,16 @@ for dtype, name in ((np.float64, "f64"), (np.float32, "f32")):
         cost = mo.Point2PointCost(src.astype(dtype), tgt.astype(dtype), dtype=dtype)
         for jac, jname in ((0, "analytic"), (2, "numeric")):
             row = []
-            for tiles in ("4", "0"):
-                os.environ["MOPT_LM_ONE_LAUNCH_TILES"] = tiles
+            # "4": one launch wherever the kernel can (the gate by mode is lifted with MOPT_LM_ONE_LAUNCH_FORCE);
+            # "0": never; "default": what the library chooses
+            for tiles in ("4", "0", "default"):
+                os.environ.pop("MOPT_LM_ONE_LAUNCH_FORCE", None)
+                if tiles == "default":
+                    os.environ.pop("MOPT_LM_ONE_LAUNCH_TILES", None)
+                else:
+                    os.environ["MOPT_LM_ONE_LAUNCH_TILES"] = tiles
+                    if tiles == "4":
+                        os.environ["MOPT_LM_ONE_LAUNCH_FORCE"] = "1"
                 x0 = np.zeros(6, dtype=dtype)
                 for _ in range(20):
                     mo.capi.lm_minimize([cost], [jac], x0)
@@ -28,7 +36,9 @@ for dtype, name in ((np.float64, "f64"), (np.float32, "f32")):
                     x, rep = mo.capi.lm_minimize([cost], [jac], x0)
                     ts.append(time.perf_counter() - t0)
                 row.append((np.median(ts) * 1e6, rep["iterations"], rep["sweeps"]))
-            (a, it, sw), (b, _, _) = row
-            print("%s n=%5d %-8s: one launch %6.1f us, launch per point %6.1f us (%d iterations, %d sweeps): %.1f / %.1f us per point"
-                  % (name, n, jname, a, b, it, sw, a / sw, b / sw), flush=True)
+            (a, it, sw), (b, it_b, sw_b), (d, it_d, sw_d) = row
+            print("%s n=%5d %-8s: one launch %6.1f us (%2d iterations, %2d sweeps), launch per point %6.1f us "
+                  "(%2d, %2d): %.1f / %.1f us per point; default %6.1f us (%2d, %2d)%s"
+                  % (name, n, jname, a, it, sw, b, it_b, sw_b, a / sw, b / sw_b, d, it_d, sw_d,
+                     "" if d <= 1.03 * min(a, b) else "   <-- default is not the faster form"), flush=True)
         cost.close()

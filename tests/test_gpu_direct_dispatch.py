@@ -72,6 +72,33 @@ for sc, modes in zip(curves, ((mo.JAC_ANALYTIC, mo.JAC_NUMERIC), (mo.JAC_NUMERIC
         H, b, s = sc.linearize(xs2, mode)
         row = np.zeros(44); v = np.concatenate([H.ravel(), b, [s, sc.compute_cost(xs2)]]); row[:v.size] = v
         rows.append(row)
+# A profiled sweep of a built-in scalar model is timed with a recorded event pair, so its launch leaves the
+# direct path it was offered for the HIP stream; the call must then BE a stream call (wait, fault check,
+# ordering of the next direct sweep): same numbers, counted launches, and direct again afterwards
+sc = curves[0]
+d0 = sc.direct_dispatches()
+sc.set_profiling(1)
+for k in range(3):
+    H, b, s = sc.linearize(np.array([0.31, 0.52]) + 1e-3 * k, mo.JAC_ANALYTIC)
+    row = np.zeros(44); v = np.concatenate([H.ravel(), b, [s, 0.0]]); row[:v.size] = v; rows.append(row)
+ms_sc, n_sc = sc.profile(); sc.set_profiling(0)
+out["scalar_profiled"] = [int(n_sc), float(ms_sc), sc.direct_dispatches() - d0]
+for k in range(2):
+    H, b, s = sc.linearize(np.array([0.4, 0.5]) + 1e-3 * k, mo.JAC_ANALYTIC)
+    row = np.zeros(44); v = np.concatenate([H.ravel(), b, [s, 0.0]]); row[:v.size] = v; rows.append(row)
+out["scalar_direct_after"] = sc.direct_dispatches() - d0
+# profiling a sharded cost (host-slot combine, one rank): the direct path's own dispatch stamps are collected
+h = mo.Point2PointCost(src[:50_000], tgt[:50_000])
+h.set_speculation(False)
+h.hostcomm_attach("/mopt-test-prof-%%d" %% os.getpid(), 0, 1)
+h.set_combine(mo.COMBINE_HOST)
+h.set_profiling(1)
+for k in range(4):
+    H, b, s = h.linearize(x + 1e-3 * k, mo.JAC_ANALYTIC)
+    rows.append(np.concatenate([H.ravel(), b, [s, 0.0]]))
+ms_h, n_h = h.profile(); h.set_profiling(0)
+out["host_profiled"] = [int(n_h), float(ms_h), h.direct_dispatches()]
+h.close()
 # many costs over the two queues, interleaved
 many = [mo.Point2PointCost(src[k * 1000:(k + 1) * 1000 + 37], tgt[k * 1000:(k + 1) * 1000 + 37]) for k in range(12)]
 for rnd in range(3):
@@ -109,6 +136,13 @@ def test_direct_dispatch_gives_the_same_bits_as_the_hip_stream(hip_lib):
     # a profiled sweep is timed on the path it takes, with a plausible duration either way
     for run in (direct, stream):
         assert run["profiled_launches"] == 1 and 1e-3 < run["profiled_ms"] < 1.0, run["profiled_ms"]
+        # the scalar model's profiled sweeps: three launches timed, none of them direct
+        n_sc, ms_sc, went_direct = run["scalar_profiled"]
+        assert n_sc == 3 and 1e-3 < ms_sc < 1.0 and went_direct == 0, run["scalar_profiled"]
+        n_h, ms_h, _ = run["host_profiled"]
+        assert n_h == 4 and 1e-3 < ms_h < 1.0, run["host_profiled"]
+    assert direct["scalar_direct_after"] == 2 and stream["scalar_direct_after"] == 0
+    assert direct["host_profiled"][2] == 4 and stream["host_profiled"][2] == 0
 
 
 TRIM_SCRIPT = r"""
