@@ -699,28 +699,42 @@ def main():
         out = {}
         # configs[0]: tst/point2point.cpp's size.  One blocking linearization per step as everywhere
         # else, and — what a 1 k problem is for — the whole registration (forward differences, from
-        # x = 0) under mopt_lm_minimize: one launch of one workgroup at this size
+        # x = 0) under mopt_lm_minimize
         n0 = 1000
         c0, s0, t0 = make_cost(n0)
         del s0, t0
         el, _, ssq, st = timed_pass(c0, None, args.steps, args.warmup, 200, mode=mo.JAC_ANALYTIC)
         ms = el / args.steps * 1e3
         x0 = np.zeros(6, dtype=np_dtype)
-        for _ in range(5):
-            mo.capi.lm_minimize([c0], [mo.JAC_NUMERIC], x0)
-        solves = []
-        for _ in range(20):
-            t_solve = time.perf_counter()
-            xs0, rep0 = mo.capi.lm_minimize([c0], [mo.JAC_NUMERIC], x0)
-            solves.append(time.perf_counter() - t_solve)
+
+        def solve_median(jac):
+            for _ in range(5):
+                mo.capi.lm_minimize([c0], [jac], x0)
+            solves = []
+            for _ in range(20):
+                t_solve = time.perf_counter()
+                xs0, rep0 = mo.capi.lm_minimize([c0], [jac], x0)
+                solves.append(time.perf_counter() - t_solve)
+            return float(np.median(solves)) * 1e3, xs0, rep0
+
+        solve_ms, xs0, rep0 = solve_median(mo.JAC_NUMERIC)
+        choice = c0.lm_choice_stats()
+        c0.set_kernel_variant(mo.KERNEL_MOMENTS_ALWAYS)
+        one_launch_ms, _, rep1 = solve_median(mo.JAC_NUMERIC)
+        c0.set_kernel_variant(variant)
         out["cfg1"] = {"ms_per_step": ms, "value": n0 / (ms * 1e-3), "median_step_us": step_times(st)["median"],
-                       "check_sum_sq": ssq, "solve_ms": float(np.median(solves)) * 1e3,
+                       "check_sum_sq": ssq, "solve_ms": solve_ms,
                        "solve_iterations": rep0["iterations"], "solve_sweeps": rep0["sweeps"],
                        "solve_status": rep0["status"], "solve_x": [float(v) for v in xs0],
+                       "solve_points_chosen": choice[0], "solve_points_literal": choice[1],
+                       "solve_ms_moments_always": one_launch_ms, "solve_sweeps_moments_always": rep1["sweeps"],
                        "workload": "point2point, 1k synthetic correspondences (tst/point2point.cpp's size): "
                                    "a blocking analytic linearization per step; solve_ms = the whole "
                                    "forward-difference registration from x = 0 under mopt_lm_minimize "
-                                   "(median of 20)"}
+                                   "(median of 20), the sweep of every point chosen as the blocking call "
+                                   "chooses it (solve_points_literal of solve_points_chosen took the literal "
+                                   "one, over all 25 solves); solve_ms_moments_always = the same with "
+                                   "MOPT_KERNEL_MOMENTS_ALWAYS: one launch of one workgroup"}
         c0.close()
         n1 = 1_000_000
         c1, s1, t1 = make_cost(n1)

@@ -104,18 +104,15 @@ enum mopt_create_flags {
 /* How a sweep evaluates the reference's per-residual arithmetic. */
 enum mopt_kernel_variant {
   MOPT_KERNEL_AUTO = 0,    /* fastest variant that meets the parity bar (1e-6 on H, b, cost) for
-                              the mode — in the blocking and asynchronous calls: moments, except
-                              forward differences at an x with some 0 < |x_j| < 0.08 (literal).
-                              NOT in the device-resident loop (mopt_lm_minimize), which picks its
-                              sweep once per minimisation and not per iterate: there AUTO takes
-                              the moments at every iterate, so at an iterate with a small |x_j|
-                              its forward-difference Jacobian differs from mopt_cost_linearize's
-                              (and the reference's) by the amount given under _ALWAYS — the
-                              reference's own cancellation noise, which the moments lack; same
-                              fixed point, iterates within 1e-8 (first iterate at |x_j| ~ 0.005:
-                              5e-9 against 5e-14 under _LITERAL).  Ask for MOPT_KERNEL_LITERAL
-                              where the device loop must reproduce the reference's arithmetic
-                              at every iterate (18-20 % slower per sweep at 1-10 M)            */
+                              the mode: moments, except forward differences at an x with some
+                              0 < |x_j| < 0.08 (literal) — in the blocking and asynchronous
+                              calls AND, since round 6, at every point the device-resident loop
+                              (mopt_lm_minimize) evaluates: both forward-difference sweeps are
+                              queued per point and the step kernel names the one the rule asks
+                              for at that x (mopt_cost_lm_choice_stats counts them; one launch
+                              that returns at once per point is the price).  The one-launch
+                              solve of small problems holds one sweep and is therefore not
+                              taken by such costs (MOPT_KERNEL_MOMENTS_ALWAYS takes it)          */
   MOPT_KERNEL_LITERAL = 1, /* every residual and Jacobian entry formed per point, then
                               w * J^T * S * J accumulated entry by entry, as the reference does */
   MOPT_KERNEL_MOMENTS = 2, /* Jacobians that are affine in the source point (all point2point
@@ -474,6 +471,11 @@ typedef struct mopt_lm_report {
 MOPT_API int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian_modes,
                               void *x, const mopt_lm_options *options /* NULL = defaults */,
                               mopt_lm_report *report /* may be NULL */);
+/* A point2point cost that differentiates numerically under MOPT_KERNEL_AUTO / _MOMENTS has the sweep of
+ * every point mopt_lm_minimize evaluates chosen on the device as mopt_cost_linearize would choose it at
+ * that x (literal forward differences where some 0 < |x_j| < 0.08, the moments elsewhere).  Since the
+ * cost was created: the points so evaluated, and how many of them took the literal sweep. */
+MOPT_API int mopt_cost_lm_choice_stats(const mopt_cost *cost, int64_t *points, int64_t *literal_points);
 
 /* ---- measurement -------------------------------------------------------------------------- */
 

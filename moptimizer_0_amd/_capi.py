@@ -109,6 +109,8 @@ def load():
         "mopt_costs_link": [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int],
         "mopt_cost_link_stats": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)],
         "mopt_cost_direct_dispatches": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)],
+        "mopt_cost_lm_choice_stats": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64),
+                                      ctypes.POINTER(ctypes.c_int64)],
         "mopt_device_trim": [ctypes.c_int],
         "mopt_cost_stats": [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64),
                             ctypes.POINTER(ctypes.c_int64)],
@@ -288,6 +290,13 @@ class _CostBase:
         n = ctypes.c_int64(0)
         check(load().mopt_cost_direct_dispatches(self._h, ctypes.byref(n)))
         return n.value
+
+    def lm_choice_stats(self):
+        """(points of device-resident solves whose forward-difference sweep was chosen per point, how many
+        of them took the literal sweep) since creation."""
+        points, literal = ctypes.c_int64(0), ctypes.c_int64(0)
+        check(load().mopt_cost_lm_choice_stats(self._h, ctypes.byref(points), ctypes.byref(literal)))
+        return points.value, literal.value
 
     def stats(self):
         sweeps, hits = ctypes.c_int64(0), ctypes.c_int64(0)

@@ -913,19 +913,24 @@ int residentPrepareP2P(mopt_cost *c, int jac_mode, bool moments, double *partial
   return MOPT_OK;
 }
 
-// The device-resident loop chooses its sweep once per minimisation, not per iterate, so the rule of
-// the blocking calls (forward differences literally where some 0 < |x_j| < 0.08) cannot be applied
-// point by point.  Under AUTO and MOMENTS it takes the moments: literal forward differences at every
-// iterate were measured (round 5) at 21.5 against 17.9 us per evaluated point at 1 M, 101.6 against
-// 84.4 at 10 M, and — their cancellation noise delaying the small-delta stop — 10 against 7 outer
-// iterations on the reference's registration problem (0.258 against 0.161 ms to the same pose).  The
-// header states the deviation under MOPT_KERNEL_AUTO; MOPT_KERNEL_LITERAL is the reference's
-// arithmetic at every iterate (tests/test_gpu_device_lm.py test_forward_differences_at_small_parameters).
+// Rows of moments, except under MOPT_KERNEL_LITERAL.  Forward differences under AUTO / MOMENTS are the
+// one case where that is not the whole answer: where some 0 < |x_j| < 0.08 the blocking calls evaluate
+// literally (hasSmallForwardStep), and so does the device-resident loop, point by point — both sweeps are
+// queued for every evaluated point and the step kernel names the one that runs (residentPerIterate,
+// sweep.hpp kLmGateMoments / kLmGateLiteral).  Literal forward differences at EVERY iterate were measured
+// in round 5 at 21.5 against 17.9 us per evaluated point at 1 M, 101.6 against 84.4 at 10 M; the choice per
+// point pays that only at the points that need it, plus one launch that returns at once.
 bool usesMoments(const mopt_cost *c, int jac_mode) {
   (void)jac_mode;
   return c->variant != MOPT_KERNEL_LITERAL;
 }
 }  // namespace
+
+bool residentPerIterate(const mopt_cost *c, int jac_mode) {
+  static const bool enabled = envInt("MOPT_LM_PER_ITERATE", 1) != 0;  // 0: moments at every point (round 5)
+  return enabled && c->model == kModelPoint2Point && jac_mode == MOPT_JAC_NUMERIC &&
+         (c->variant == MOPT_KERNEL_AUTO || c->variant == MOPT_KERNEL_MOMENTS);
+}
 
 int residentGrid(const mopt_cost *c, int jac_mode) {
   switch (c->model) {
@@ -1222,6 +1227,33 @@ int residentSweep(mopt_cost *c, int jac_mode, mopt::LmControl *control, hipStrea
   }
   switch (c->model) {
     case kModelPoint2Point: {
+      if (residentPerIterate(c, jac_mode)) {
+        // both forward-difference sweeps, each behind its gate (sweep.hpp): the one the step kernel named
+        // for this point runs, the other finds its `done` set; one finalize kernel reads which it was
+        const int grid_m = residentGrid(c, jac_mode);
+        const int grid_l = gridFor(c, blocksPerCu(2));
+        const int nacc = c->cov_mode == mopt::kCovGeneral ? mopt::kAccFull : mopt::kAccSym;
+        if (c->scalar_bytes == 8) {
+          const auto *a = static_cast<const mopt::P2PSweepArgs<double> *>(c->d_lm_args);
+          MOPT_HIP_TRY(mopt::launchP2PMomentsResident<double>(static_cast<const double *>(c->d_tiles),
+                                                              c->num_tiles, a, control + mopt::kLmGateMoments,
+                                                              grid_m, site));
+          MOPT_HIP_TRY(mopt::launchP2PLiteralResident<double>(a, control + mopt::kLmGateLiteral, jac_mode,
+                                                              c->cov_mode, grid_l, site));
+        } else {
+          const auto *a = static_cast<const mopt::P2PSweepArgs<float> *>(c->d_lm_args);
+          MOPT_HIP_TRY(mopt::launchP2PMomentsResident<float>(static_cast<const float *>(c->d_tiles),
+                                                             c->num_tiles, a, control + mopt::kLmGateMoments,
+                                                             grid_m, site));
+          MOPT_HIP_TRY(mopt::launchP2PLiteralResident<float>(a, control + mopt::kLmGateLiteral, jac_mode,
+                                                             c->cov_mode, grid_l, site));
+        }
+        if (finalize)
+          MOPT_HIP_TRY(mopt::launchFinalizeEitherResident(c->d_partials, grid_m, grid_l, nacc, c->d_lm_basis,
+                                                          c->d_result, control, s, peers, step, own_index,
+                                                          c->scalar_bytes));
+        return MOPT_OK;
+      }
       if (usesMoments(c, jac_mode)) {
         const int grid = residentGrid(c, jac_mode);
         if (c->scalar_bytes == 8)
@@ -2129,6 +2161,13 @@ int mopt_cost_set_speculation(mopt_cost *c, int enabled) {
 int mopt_cost_direct_dispatches(const mopt_cost *c, int64_t *sweeps) {
   if (!c || !sweeps) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
   *sweeps = c->stat_direct_sweeps;
+  return MOPT_OK;
+}
+
+int mopt_cost_lm_choice_stats(const mopt_cost *c, int64_t *points, int64_t *literal_points) {
+  if (!c || !points || !literal_points) return fail(MOPT_ERR_INVALID_ARGUMENT, "NULL argument");
+  *points = c->stat_lm_choice_points;
+  *literal_points = c->stat_lm_literal_points;
   return MOPT_OK;
 }
 

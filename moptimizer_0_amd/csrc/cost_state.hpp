@@ -179,6 +179,8 @@ struct mopt_cost {
   } cache;
   long long stat_sweeps = 0;
   long long stat_direct_sweeps = 0;  // of them: dispatched by the library itself (aql.hpp)
+  long long stat_lm_choice_points = 0;   // points of device-resident solves whose forward-difference sweep
+  long long stat_lm_literal_points = 0;  // was chosen per point, and how many of them took the literal one
   // blocking sweeps launched on `stream` since the runtime was last handed a marker (boundCommandBatch)
   int launches_since_marker = 0;
   long long stat_cache_hits = 0;
@@ -258,6 +260,8 @@ int residentPrepare(mopt_cost *c, int jac_mode, hipStream_t s, mopt::LmCostDesc 
                     double *partials_override = nullptr);
 int residentGrid(const mopt_cost *c, int jac_mode);      // workgroups (= partial rows) of a resident sweep
 int residentDenseRow(const mopt_cost *c, int jac_mode);  // values per partial row; 0: rows of moments
+// point2point forward differences under AUTO / MOMENTS: moments or literal, chosen per evaluated point
+bool residentPerIterate(const mopt_cost *c, int jac_mode);
 // one finalize (+ LM step) over `rows` rows of `row_length` values in last->d_partials
 int residentFinalizeMerged(mopt_cost *last, int rows, int row_length, mopt::LmControl *control,
                            hipStream_t s, const mopt::LmProblem *step, int own_index);

@@ -14,7 +14,8 @@ namespace {
 
 int ensureWorkspace(mopt_cost *c) {
   if (!c->d_lm_control)
-    MOPT_HIP_TRY(deviceAlloc(reinterpret_cast<void **>(&c->d_lm_control), sizeof(mopt::LmControl)));
+    MOPT_HIP_TRY(deviceAlloc(reinterpret_cast<void **>(&c->d_lm_control),
+                             mopt::kLmControlBlocks * sizeof(mopt::LmControl)));
   if (!c->d_lm_state) MOPT_HIP_TRY(deviceAlloc(&c->d_lm_state, 4096));  // >= LmState<double>
   if (!c->h_lm_report) {
     MOPT_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->h_lm_report), sizeof(mopt::LmReport),
@@ -152,6 +153,7 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
                          merged ? last->d_partials + size_t(row_offset[k]) * row_length : nullptr);
     if (rc != MOPT_OK) return rc;
     costs[k]->cache.valid = false;
+    if (residentPerIterate(costs[k], jacobian_modes[k])) problem.fd_per_iterate = 1;
     if (costs[k]->matcher) {
       problem.rematch = 1;               // its update(x) runs on the device, inside the loop
       costs[k]->state_version += 1;      // the correspondences will have changed
@@ -193,6 +195,7 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
   }
   const bool one_workgroup = num_costs == 1 && lead->model == kModelPoint2Point && !lead->matcher &&
                              lead->combine.mode == MOPT_COMBINE_NONE && problem.cost[0].moments &&
+                             !problem.fd_per_iterate &&  // (its sweep is chosen point by point: two kernels)
                              problem.n == kNumParams && lead->num_tiles >= 1 &&
                              lead->num_tiles <= small_tiles &&
                              max_points <= 4096;  // (one kernel for the whole loop: at ~8 us a point, <= 35 ms)
@@ -270,6 +273,10 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
     mopt_cost *c = costs[k];
     c->stat_sweeps += trials;
     if (c->combine.mode == MOPT_COMBINE_PEER) c->combine.sequence += (unsigned long long)trials;
+    if (problem.fd_per_iterate && residentPerIterate(c, jacobian_modes[k])) {
+      c->stat_lm_choice_points += trials;
+      c->stat_lm_literal_points += (long long)snap.pad[0];
+    }
   }
   if (lead->scalar_bytes == 8)
     for (int i = 0; i < problem.n; ++i) static_cast<double *>(x)[i] = snap.x[i];

@@ -30,6 +30,8 @@ struct LmState {
   int awaiting_x0;  // the sweep in flight is the linearization at x0, not a trial
   int status;       // LmStatus
   int trials;
+  int literal_points;  // of the evaluated points, how many took the literal forward-difference sweep
+                       // (LmProblem::fd_per_iterate; reported in LmReport::pad[0])
   unsigned long long steps;  // step-kernel runs: the host's progress word
 };
 
@@ -574,7 +576,7 @@ __device__ __forceinline__ bool lmStepBodyFor(const LmProblem &P, bool init, con
   __shared__ LmState<S, NMAX> st;
   __shared__ S sums[NMAX * NMAX + NMAX + 1];  // H | b | sum_sq over the costs
   __shared__ S next_x[NMAX];
-  __shared__ int propose, finished;
+  __shared__ int propose, finished, literal_next;
   __shared__ SolveScratch<S, NMAX> solve_scratch;
   LmState<S, NMAX> *stored = static_cast<LmState<S, NMAX> *>(P.state);
   const int n = FIXED_N > 0 ? FIXED_N : P.n;
@@ -802,6 +804,21 @@ __device__ __forceinline__ bool lmStepBodyFor(const LmProblem &P, bool init, con
     st.it = it;
     st.status = status;
     st.steps += 1;
+    // Which forward-difference sweep the next point takes (costs of LmProblem::fd_per_iterate): the rule
+    // of the blocking call (c_abi.cpp hasSmallForwardStep) at the very x that sweep is evaluated at.
+    // (Not in the one-launch solve, whose one sweep is compiled in: lm.cpp keeps such problems out of it.)
+    literal_next = 0;
+    if constexpr (!STATE_STAYS) {
+      if (P.fd_per_iterate) {
+        if (init) st.literal_points = 0;
+        if (propose)
+          for (int i = 0; i < kNumParams; ++i) {
+            const double a = fabs(double(next_x[i]));
+            if (a > 0.0 && a < 0.08) literal_next = 1;
+          }
+        st.literal_points += literal_next;
+      }
+    }
   }
   __syncthreads();
   if (init) {
@@ -822,6 +839,12 @@ __device__ __forceinline__ bool lmStepBodyFor(const LmProblem &P, bool init, con
     ctl->trial = st.trials;
     ctl->pad[1] = rematch_next;
     ctl->done = finished;
+    if constexpr (!STATE_STAYS) {
+      if (P.fd_per_iterate) {  // the gates of the two forward-difference sweeps (sweep.hpp)
+        ctl[kLmGateMoments].done = finished | literal_next;
+        ctl[kLmGateLiteral].done = finished | (literal_next ^ 1);
+      }
+    }
   }
   MOPT_TICK(3);
   if (propose) writeSweepConstants<S>(P, next_x, args_local, basis_local);
@@ -840,6 +863,7 @@ __device__ __forceinline__ bool lmStepBodyFor(const LmProblem &P, bool init, con
       storeReport(&rep->iterations, double(st.it));
       storeReport(&rep->trials, double(st.trials));
       storeReport(&rep->peer_status, double(ctl->pad[0]));
+      if constexpr (!STATE_STAYS) storeReport(&rep->pad[0], P.fd_per_iterate ? double(st.literal_points) : 0.0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 #ifdef MOPT_LM_TIMING

@@ -207,6 +207,15 @@ struct LmControl {  // device memory; written by the step kernel only
   int pad[2];       // [0]: a peer-combine status (kStatusPeerTimeout) seen by a finalize kernel
 };                  // [1]: the next point is a linearization point whose correspondences are to
                     //      be re-searched first (ICP costs: the model's update(x))
+// The control block of a minimisation is kLmControlBlocks of these.  [0] is the one above.  [1] and [2]
+// are gates for a point2point cost that differentiates numerically under MOPT_KERNEL_AUTO / _MOMENTS
+// (LmProblem::fd_per_iterate): per evaluated point the host queues the moments sweep AND the literal
+// forward-difference sweep; the moments sweep is handed &control[1], the literal one &control[2], and the
+// step sets [1].done = stopped || (the next point has some 0 < |x_j| < 0.08: the reference's own
+// cancellation noise is part of its answer there, linearization.h:85-105), [2].done = stopped || not so —
+// so exactly the sweep the blocking call would choose at that x runs, the other returns at once.
+constexpr int kLmControlBlocks = 3;
+constexpr int kLmGateMoments = 1, kLmGateLiteral = 2;
 
 struct LmCostDesc {
   int model = 0;     // LmModel
@@ -245,7 +254,8 @@ struct LmProblem {
                               //    point is re-linearized after the search instead of adopted
   int merged = 0;             // 1: the partial rows of all costs lie behind one another and the last
                               //    cost's finalize reduces them all: its result is the sum over the costs
-  int pad = 0;
+  int fd_per_iterate = 0;     // 1: some point2point cost takes its forward differences by moments or
+                              //    literally as each evaluated point asks (control[1], control[2])
   LmCostDesc cost[kLmMaxCosts];
   LmControl *control = nullptr;  // device
   void *state = nullptr;         // device, LmState<S> (lm_kernels.hip)
@@ -308,6 +318,14 @@ hipError_t launchFinalizeDenseResident(const double *partials, int grid, int nac
                                        double *result, LmControl *control, hipStream_t stream,
                                        const PeerCombine *peers, const LmProblem *step = nullptr,
                                        int own_index = 0, int scalar_bytes = 8);
+// A cost whose sweep kind is chosen per evaluated point (control[kLmGateMoments].done != 0: the literal
+// sweep ran): rows of moments over `grid_moments` workgroups, or dense rows of `nacc` values over
+// `grid_literal`; n = 6.
+hipError_t launchFinalizeEitherResident(const double *partials, int grid_moments, int grid_literal,
+                                        int nacc, const AffineBasis *d_basis, double *result,
+                                        LmControl *control, hipStream_t stream,
+                                        const PeerCombine *peers, const LmProblem *step,
+                                        int own_index, int scalar_bytes);
 hipError_t launchFinalizeMomentsResident(const double *partials, int grid,
                                          const AffineBasis *d_basis, double *result,
                                          LmControl *control, hipStream_t stream,

@@ -1528,6 +1528,42 @@ __global__ __launch_bounds__(kStepThreads) void finalizeMomentsResidentKernel(
   }
 }
 
+// A cost whose forward-difference sweep is chosen per evaluated point (sweep.hpp kLmGateMoments /
+// kLmGateLiteral): the sweep that ran left rows of moments (its gate open) or dense rows (the other
+// one); the gates are rewritten only by the step at the end of this kernel, so they still say which.
+template <int STEP>
+__global__ __launch_bounds__(kStepThreads) void finalizeEitherResidentKernel(
+    const double *partials, int grid_moments, int grid_literal, int nacc,
+    const AffineBasis *__restrict__ d_basis, double *result, LmControl *control, const PeerCombine pc,
+    const LmProblem P, int own_index) {
+  if (control->done) return;
+  const bool literal = control[kLmGateMoments].done != 0;  // (uniform: a kernel argument's memory)
+  using S = typename StepScalar<STEP>::type;
+  LmStateWords state_words = {0u, 0u};
+  if constexpr (STEP != 0) state_words = lmPrefetchState<S>(P);
+  __shared__ double own[kSlotData];
+  unsigned long long status;
+  if (literal) {
+    status = finalizeDenseBody<kStepThreads>(partials, grid_literal, nacc, kNumParams, result, HostPublish(),
+                                             pc, own, NoHook(), (unsigned long long)control->trial);
+  } else {
+    constexpr int kBasisDoubles = int(sizeof(AffineBasis) / sizeof(double));
+    const double basis_value = reinterpret_cast<const double *>(
+        d_basis)[int(threadIdx.x) < kBasisDoubles ? int(threadIdx.x) : 0];
+    __shared__ AffineBasis B;
+    const auto park_basis = [&]() {
+      if (int(threadIdx.x) < kBasisDoubles) reinterpret_cast<double *>(&B)[threadIdx.x] = basis_value;
+    };
+    status = finalizeMomentsBody<kStepThreads>(partials, grid_moments, B, result, HostPublish(), pc, own,
+                                               park_basis, (unsigned long long)control->trial);
+  }
+  if (status && threadIdx.x == 0) control->pad[0] = int(status);
+  if constexpr (STEP != 0) {
+    __syncthreads();
+    lmStepBody<S, kNumParams>(P, false, LmStart<S>(), own, own_index, true, state_words);
+  }
+}
+
 // ---- a whole minimisation in one launch ---------------------------------------------------------
 // Small point2point problems (the reference's own test sizes: tst/point2point.cpp registers 1 k
 // correspondences): under the launch-per-point loop an evaluated point costs two launches, 11-12 us,
@@ -2253,6 +2289,26 @@ hipError_t launchFinalizeDenseResident(const double *partials, int grid, int nac
   else
     hipLaunchKernelGGL(finalizeDenseResidentKernel<4>, g, b, 0, stream, partials, grid, nacc, n,
                        result, control, pc, *step, own_index);
+  return hipGetLastError();
+}
+
+hipError_t launchFinalizeEitherResident(const double *partials, int grid_moments, int grid_literal,
+                                        int nacc, const AffineBasis *d_basis, double *result,
+                                        LmControl *control, hipStream_t stream,
+                                        const PeerCombine *peers, const LmProblem *step,
+                                        int own_index, int scalar_bytes) {
+  if (nacc != kAccSym && nacc != kAccFull) return hipErrorInvalidValue;
+  const PeerCombine pc = peers ? *peers : PeerCombine();
+  const dim3 g(1), b(kStepThreads);
+  if (!step)
+    hipLaunchKernelGGL(finalizeEitherResidentKernel<0>, g, b, 0, stream, partials, grid_moments,
+                       grid_literal, nacc, d_basis, result, control, pc, LmProblem(), 0);
+  else if (scalar_bytes == 8)
+    hipLaunchKernelGGL(finalizeEitherResidentKernel<8>, g, b, 0, stream, partials, grid_moments,
+                       grid_literal, nacc, d_basis, result, control, pc, *step, own_index);
+  else
+    hipLaunchKernelGGL(finalizeEitherResidentKernel<4>, g, b, 0, stream, partials, grid_moments,
+                       grid_literal, nacc, d_basis, result, control, pc, *step, own_index);
   return hipGetLastError();
 }
 

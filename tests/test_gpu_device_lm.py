@@ -113,12 +113,12 @@ def test_iterates_match_the_cpu_loop(hip_lib, oracle, n, jac):
 def test_forward_differences_at_small_parameters(hip_lib, oracle):
     """A registration between nearly aligned clouds: every iterate has 0 < |x_j| < 0.08, where the
     moments form of the forward differences lacks the reference's own per-point cancellation noise
-    (eps |R p + t| / h_j, part of what linearization.h:101-105 computes).  The device loop chooses
-    its sweep per minimisation, not per iterate (moptimizer_hip.h, MOPT_KERNEL_AUTO): under
-    MOPT_KERNEL_LITERAL its first iterate — H, b at x0 from transforms the host formed, one damped
-    solve — is the CPU loop's to rounding; under AUTO (moments) it is within the deviation the header
-    documents, 1e5 times further away and still 1e-8.  Later iterates carry the device's own sincos
-    (module docstring) and agree to FD_ITERATE_TOL under either; same pose at the end."""
+    (eps |R p + t| / h_j, part of what linearization.h:101-105 computes).  Since round 6 the device
+    loop applies the blocking call's rule at every point it evaluates (moptimizer_hip.h,
+    MOPT_KERNEL_AUTO): under AUTO, as under MOPT_KERNEL_LITERAL, its first iterate — H, b at x0 from
+    transforms the host formed, one damped solve — is the CPU loop's to rounding; MOMENTS_ALWAYS
+    keeps the moments and is 1e5 times further away, still 1e-8.  Later iterates carry the device's
+    own sincos (module docstring) and agree to FD_ITERATE_TOL under either; same pose at the end."""
     mo = hip_lib
     rng = np.random.default_rng(3)
     n = 100_000
@@ -130,12 +130,13 @@ def test_forward_differences_at_small_parameters(hip_lib, oracle):
     cost = mo.Point2PointCost(src, tgt)
     xr1, _, _ = oracle.p2p_minimize(src, tgt, x0, cost_class=ob.NUMERIC_DYN, layout=ob.LAYOUT_ROW_MAJOR,
                                     max_iter=1)
-    for variant, first_iterate_tol in ((mo.KERNEL_LITERAL, 1e-12), (mo.KERNEL_AUTO, 1e-7),
-                                       (mo.KERNEL_MOMENTS_ALWAYS, 1e-7)):
+    kept = {}
+    for variant, first_iterate_tol in ((mo.KERNEL_LITERAL, 1e-12), (mo.KERNEL_AUTO, 1e-12),
+                                       (mo.KERNEL_MOMENTS, 1e-12), (mo.KERNEL_MOMENTS_ALWAYS, 1e-7)):
         cost.set_kernel_variant(variant)
         x1, rep = mo.capi.lm_minimize([cost], [mo.JAC_NUMERIC], x0, max_iterations=1)
         assert rep["iterations"] == 1 and np.abs(x1 - xr1).max() < first_iterate_tol, (variant, x1 - xr1)
-        if variant != mo.KERNEL_LITERAL:
+        if variant == mo.KERNEL_MOMENTS_ALWAYS:
             assert np.abs(x1 - xr1).max() > 1e-10   # (the deviation is there: the header does not overstate)
         for k in (2, 3, 15):
             x, rep = mo.capi.lm_minimize([cost], [mo.JAC_NUMERIC], x0, max_iterations=k)
@@ -143,11 +144,71 @@ def test_forward_differences_at_small_parameters(hip_lib, oracle):
                                                     layout=ob.LAYOUT_ROW_MAJOR, max_iter=k)
             assert abs(rep["iterations"] - iters) <= 2, (k, rep, iters)
             assert np.abs(x - xr).max() < FD_ITERATE_TOL, (k, x - xr)
+            kept[(variant, k)] = (x, rep)
+    # every point of the AUTO solves was small: each took the literal sweep, and the solves are the
+    # LITERAL variant's bit for bit (the same two kernels ran)
+    points, literal = cost.lm_choice_stats()
+    assert points > 20 and literal == points, (points, literal)
+    for k in (2, 3, 15):
+        for variant in (mo.KERNEL_AUTO, mo.KERNEL_MOMENTS):
+            assert np.array_equal(kept[(variant, k)][0], kept[(mo.KERNEL_LITERAL, k)][0]), (variant, k)
+            assert kept[(variant, k)][1] == kept[(mo.KERNEL_LITERAL, k)][1], (variant, k)
     # the blocking call applies the rule per x: AUTO at this x0 is the reference's H, b to rounding
     cost.set_kernel_variant(mo.KERNEL_AUTO)
     H, b, s = cost.linearize(x0, mo.JAC_NUMERIC)
     Hr, br, sr = oracle.p2p_linearize(src, tgt, x0, cost_class=ob.NUMERIC_DYN)
     assert np.abs(H - Hr).max() <= 1e-12 * np.abs(Hr).max() and np.abs(b - br).max() <= 1e-12 * np.abs(br).max()
+    cost.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_forward_difference_sweep_is_chosen_point_by_point(hip_lib, oracle, dtype):
+    """Under AUTO the device-resident loop queues both forward-difference sweeps for every point and the
+    step kernel names one (sweep.hpp kLmGateMoments / kLmGateLiteral; linearization.h:78-105).  Where no
+    evaluated point has a small parameter the solve is MOMENTS_ALWAYS's bit for bit, where every point
+    has one it is LITERAL's (previous test), and on a registration that starts at x = 0 (fixed step:
+    moments) and ends at a pose with one small component both kinds run in one solve — which still
+    lands on the CPU loop's pose."""
+    mo = hip_lib
+    rng = np.random.default_rng(12)
+    n = 60_000
+    src = rng.random((n, 3)) * 10.0
+    fp64 = dtype == np.float64
+
+    def problem(x_true):
+        T = oracle.se3_from_x(np.asarray(x_true, dtype=np.float64))
+        tgt = src @ T[:3, :3].T + T[:3, 3] + rng.normal(0, 0.01, (n, 3))
+        return mo.Point2PointCost(src.astype(dtype), tgt.astype(dtype), dtype=dtype), tgt
+
+    # (a) every parameter stays large: no literal point, the moments solve exactly
+    x_true = np.array([1.5, -1.3, 1.2, 0.4, -0.5, 0.3])
+    cost, _ = problem(x_true)
+    x0 = (x_true + np.array([0.2, -0.2, 0.2, 0.05, 0.05, -0.05])).astype(dtype)
+    got = {}
+    for variant in (mo.KERNEL_AUTO, mo.KERNEL_MOMENTS_ALWAYS):
+        cost.set_kernel_variant(variant)
+        got[variant] = [mo.capi.lm_minimize([cost], [mo.JAC_NUMERIC], x0, max_iterations=k) for k in (1, 3, 15)]
+    points, literal = cost.lm_choice_stats()
+    assert points == sum(r["sweeps"] for _, r in got[mo.KERNEL_AUTO]) and literal == 0, (points, literal)
+    for (xa, ra), (xm, rm) in zip(got[mo.KERNEL_AUTO], got[mo.KERNEL_MOMENTS_ALWAYS]):
+        assert ra == rm and np.array_equal(xa, xm), (ra, rm, xa - xm)
+    assert np.abs(got[mo.KERNEL_AUTO][2][0] - x_true).max() < (1e-3 if fp64 else 5e-3)
+    cost.close()
+
+    # (b) from x = 0 to a pose with one small component: moments first, literal near the end
+    x_true = np.array([0.5, -0.3, 0.2, 0.01, -0.2, 0.3])
+    cost, tgt = problem(x_true)
+    x, rep = mo.capi.lm_minimize([cost], [mo.JAC_NUMERIC], np.zeros(6, dtype=dtype))
+    points, literal = cost.lm_choice_stats()
+    assert points == rep["sweeps"] and 0 < literal < points, (points, literal, rep)
+    if fp64:
+        xr, status, iters = oracle.p2p_minimize(src, tgt, np.zeros(6), cost_class=ob.NUMERIC_DYN,
+                                                layout=ob.LAYOUT_ROW_MAJOR)
+        assert abs(rep["iterations"] - iters) <= 2 and np.abs(x - xr).max() < FD_ITERATE_TOL, (rep, iters, x - xr)
+    else:
+        assert np.abs(x - x_true).max() < 5e-3, x - x_true
+    # the switch keeps the loop's other paths: MOPT_LM_PER_ITERATE is read once per process, so the
+    # moments-at-every-point form is exercised through MOMENTS_ALWAYS above
     cost.close()
 
 
@@ -627,6 +688,9 @@ def test_small_problems_in_one_launch_take_the_same_iterates(hip_lib, oracle, dt
             numeric = jac == mo.JAC_NUMERIC
             cost.set_covariance(cv)
             cost.set_loss(loss, 100.0)
+            # forward differences under AUTO choose their sweep point by point and stay out of the one-launch
+            # solve (moptimizer_hip.h); MOMENTS_ALWAYS is the variant that takes it
+            cost.set_kernel_variant(mo.KERNEL_MOMENTS_ALWAYS if numeric else mo.KERNEL_AUTO)
             for k in (1, 3, 15):
                 got = {}
                 for tiles in ("4", "0"):
