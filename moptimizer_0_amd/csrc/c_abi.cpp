@@ -1228,26 +1228,21 @@ int residentSweep(mopt_cost *c, int jac_mode, mopt::LmControl *control, hipStrea
   switch (c->model) {
     case kModelPoint2Point: {
       if (residentPerIterate(c, jac_mode)) {
-        // both forward-difference sweeps, each behind its gate (sweep.hpp): the one the step kernel named
-        // for this point runs, the other finds its `done` set; one finalize kernel reads which it was
+        // one sweep launch that holds both forward-difference forms and runs the one the step kernel named
+        // for this point (sweep.hpp kLmGateMoments), and one finalize kernel that reads which it was
         const int grid_m = residentGrid(c, jac_mode);
         const int grid_l = gridFor(c, blocksPerCu(2));
         const int nacc = c->cov_mode == mopt::kCovGeneral ? mopt::kAccFull : mopt::kAccSym;
-        if (c->scalar_bytes == 8) {
-          const auto *a = static_cast<const mopt::P2PSweepArgs<double> *>(c->d_lm_args);
-          MOPT_HIP_TRY(mopt::launchP2PMomentsResident<double>(static_cast<const double *>(c->d_tiles),
-                                                              c->num_tiles, a, control + mopt::kLmGateMoments,
-                                                              grid_m, site));
-          MOPT_HIP_TRY(mopt::launchP2PLiteralResident<double>(a, control + mopt::kLmGateLiteral, jac_mode,
-                                                              c->cov_mode, grid_l, site));
-        } else {
-          const auto *a = static_cast<const mopt::P2PSweepArgs<float> *>(c->d_lm_args);
-          MOPT_HIP_TRY(mopt::launchP2PMomentsResident<float>(static_cast<const float *>(c->d_tiles),
-                                                             c->num_tiles, a, control + mopt::kLmGateMoments,
-                                                             grid_m, site));
-          MOPT_HIP_TRY(mopt::launchP2PLiteralResident<float>(a, control + mopt::kLmGateLiteral, jac_mode,
-                                                             c->cov_mode, grid_l, site));
-        }
+        if (c->scalar_bytes == 8)
+          MOPT_HIP_TRY(mopt::launchForwardDiffEitherResident<double>(
+              static_cast<const double *>(c->d_tiles), c->num_tiles,
+              static_cast<const mopt::P2PSweepArgs<double> *>(c->d_lm_args), control, c->cov_mode, grid_l,
+              grid_m, site));
+        else
+          MOPT_HIP_TRY(mopt::launchForwardDiffEitherResident<float>(
+              static_cast<const float *>(c->d_tiles), c->num_tiles,
+              static_cast<const mopt::P2PSweepArgs<float> *>(c->d_lm_args), control, c->cov_mode, grid_l,
+              grid_m, site));
         if (finalize)
           MOPT_HIP_TRY(mopt::launchFinalizeEitherResident(c->d_partials, grid_m, grid_l, nacc, c->d_lm_basis,
                                                           c->d_result, control, s, peers, step, own_index,

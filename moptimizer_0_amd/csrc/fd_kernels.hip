@@ -349,6 +349,35 @@ __global__ __launch_bounds__(kBlockThreads) void p2pForwardDiffResidentArgsKerne
                                                             gridDim.x, *d_args);
 }
 
+// The sweep of a cost whose forward differences are taken by moments or literally as each evaluated
+// point asks (sweep.hpp kLmGateMoments; lm_device.hpp writes the gates): ONE launch per point, the choice
+// read from the control block — uniform over the grid.  The literal form runs over the whole grid (two
+// workgroups per CU: it is VALU-heavy); the moments form over its first `moments_grid` workgroups (one
+// per CU, rows of kAccMoments), the others leave at once.  Either way the arithmetic is the body the
+// single-purpose kernels run.
+template <typename S, bool STREAMING, int COV>
+__global__ __launch_bounds__(kBlockThreads) void p2pForwardDiffEitherResidentKernel(
+    const S *tiles, int num_tiles, const P2PSweepArgs<S> *__restrict__ d_args,
+    const LmControl *__restrict__ control, int moments_grid) {
+  if (control->done) return;
+  const bool literal = control[kLmGateMoments].done != 0;
+  if (!literal && int(blockIdx.x) >= moments_grid) return;
+  const P2PSweepArgs<S> A = *d_args;
+  if (literal) {
+    p2pForwardDiffBody<S, STREAMING, COV, kFdHomeFor<S, COV>>(tiles, num_tiles, A, blockIdx.x, gridDim.x,
+                                                              *d_args);
+  } else {
+    double acc[kAccMoments];
+#pragma unroll
+    for (int k = 0; k < kAccMoments; ++k) acc[k] = 0.0;
+    sweepTiles<S, STREAMING>(
+        tiles, num_tiles,
+        [&](const Pack<S>(&cur)[6], long long first) { momentsOfPack<S>(acc, cur, first, A); },
+        int(blockIdx.x), moments_grid);
+    blockReduceStore<kAccMoments>(acc, A.partials + size_t(blockIdx.x) * kAccMoments);
+  }
+}
+
 // several forward-difference costs of one problem in one launch (workgroups [first_block[k],
 // first_block[k + 1]) sweep cost k)
 template <typename S, bool STREAMING, int COV>
@@ -430,6 +459,39 @@ hipError_t launchForwardDiffResident(const P2PSweepArgs<S> *d_args, const LmCont
 #undef MOPT_LAUNCH_FD_RESIDENT
   return hipGetLastError();
 }
+template <typename S>
+hipError_t launchForwardDiffEitherResident(const S *tiles, int num_tiles, const P2PSweepArgs<S> *d_args,
+                                           const LmControl *control, int cov_mode, int grid,
+                                           int moments_grid, const LaunchSite &site) {
+  const dim3 g(grid), b(kBlockThreads);
+#define MOPT_LAUNCH_FD_EITHER(COV)                                                                \
+  if (site.streaming)                                                                             \
+    hipLaunchKernelGGL((p2pForwardDiffEitherResidentKernel<S, true, COV>), g, b, 0, site.stream,  \
+                       tiles, num_tiles, d_args, control, moments_grid);                          \
+  else                                                                                            \
+    hipLaunchKernelGGL((p2pForwardDiffEitherResidentKernel<S, false, COV>), g, b, 0, site.stream, \
+                       tiles, num_tiles, d_args, control, moments_grid)
+  switch (cov_mode) {
+    case kCovIdentity:
+      MOPT_LAUNCH_FD_EITHER(kCovIdentity);
+      break;
+    case kCovSymmetric:
+      MOPT_LAUNCH_FD_EITHER(kCovSymmetric);
+      break;
+    default:
+      MOPT_LAUNCH_FD_EITHER(kCovGeneral);
+      break;
+  }
+#undef MOPT_LAUNCH_FD_EITHER
+  return hipGetLastError();
+}
+template hipError_t launchForwardDiffEitherResident<float>(const float *, int, const P2PSweepArgs<float> *,
+                                                           const LmControl *, int, int, int,
+                                                           const LaunchSite &);
+template hipError_t launchForwardDiffEitherResident<double>(const double *, int,
+                                                            const P2PSweepArgs<double> *, const LmControl *,
+                                                            int, int, int, const LaunchSite &);
+
 template <typename S>
 hipError_t launchForwardDiffResidentSet(const ResidentSweepSet &set, const LmControl *control,
                                         int cov_mode, const LaunchSite &site) {

@@ -348,6 +348,11 @@ hipError_t launchP2PLinearizeLiteral(const P2PSweepArgs<S> &args, int jac_mode, 
 template <typename S>
 hipError_t launchForwardDiff(const P2PSweepArgs<S> &args, int cov_mode, int grid,
                              const LaunchSite &site);
+// one launch for a cost whose forward-difference sweep is chosen per evaluated point (kLmGateMoments)
+template <typename S>
+hipError_t launchForwardDiffEitherResident(const S *tiles, int num_tiles, const P2PSweepArgs<S> *d_args,
+                                           const LmControl *control, int cov_mode, int grid,
+                                           int moments_grid, const LaunchSite &site);
 template <typename S>
 hipError_t launchForwardDiffResident(const P2PSweepArgs<S> *d_args, const LmControl *control,
                                      int cov_mode, int grid, const LaunchSite &site);

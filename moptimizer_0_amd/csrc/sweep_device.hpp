@@ -128,6 +128,66 @@ __device__ __forceinline__ void sweepTiles(const S *tiles, int num_tiles, Body &
                            int(gridDim.x));
 }
 
+// The moments of the V correspondences one lane holds of a tile, added to `acc`.
+template <typename S>
+__device__ __forceinline__ void momentsOfPack(double (&acc)[kAccMoments], const Pack<S> (&cur)[6],
+                                              long long first, const P2PSweepArgs<S> &A) {
+  constexpr int V = TileShape<S>::kVec;
+  // fp64: the moment updates contract into one v_fma_f64 each, straight into the accumulators.
+  // fp32: the four correspondences a lane holds per tile are first summed in fp32 (fp32 FMAs),
+  // then promoted once — 23 conversions + fp64 adds per tile instead of 92, which otherwise makes
+  // the fp32 sweep VALU-bound.
+  using Local = typename std::conditional<sizeof(S) == 8, double, S>::type;
+  Local loc[kAccMoments];
+  if constexpr (sizeof(S) == 4) {
+#pragma unroll
+    for (int k = 0; k < kAccMoments; ++k) loc[k] = Local(0);
+  }
+  auto add = [&](int k, S v) {
+    if constexpr (sizeof(S) == 8)
+      acc[k] += double(v);
+    else
+      loc[k] += v;
+  };
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    const S p[3] = {cur[0].v[e], cur[1].v[e], cur[2].v[e]};
+    const bool valid = isCorrespondence(first + e, A.count, cur[3].v[e]);
+    const S q[3] = {valid ? cur[3].v[e] : S(0), valid ? cur[4].v[e] : S(0),
+                    valid ? cur[5].v[e] : S(0)};
+    S r[3];
+    p2pResidual<S>(A.T[0], p, q, r);
+    S rr = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+    S w = lossWeight<S>(A.loss_kind, A.loss_param, rr);
+    w = valid ? w : S(0);
+    rr = valid ? rr : S(0);
+    const S wp[3] = {w * p[0], w * p[1], w * p[2]};
+    const S wr[3] = {w * r[0], w * r[1], w * r[2]};
+    add(0, w);
+    add(1, wp[0]);
+    add(2, wp[1]);
+    add(3, wp[2]);
+    add(4, wp[0] * p[0]);
+    add(5, wp[0] * p[1]);
+    add(6, wp[0] * p[2]);
+    add(7, wp[1] * p[1]);
+    add(8, wp[1] * p[2]);
+    add(9, wp[2] * p[2]);
+    add(10, wr[0]);
+    add(11, wr[1]);
+    add(12, wr[2]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) add(13 + 3 * k + c, p[k] * wr[c]);
+    add(22, rr);
+  }
+  if constexpr (sizeof(S) == 4) {
+#pragma unroll
+    for (int k = 0; k < kAccMoments; ++k) acc[k] += double(loc[k]);
+  }
+}
+
 __device__ __forceinline__ double waveSum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);

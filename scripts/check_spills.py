@@ -35,6 +35,8 @@ ACCEPTED_SGPR_SPILLS = (
     # set's block bounds) parked in a VGPR's lanes once per launch, outside the tile loop
     ("mopt::p2pForwardDiffResidentArgsKernel<float,", 20, "parked outside the tile loop"),
     ("mopt::p2pForwardDiffResidentSetKernel<float,", 20, "parked outside the tile loop"),
+    # the same body behind the per-point choice of the device-resident loop (round 6): 17
+    ("mopt::p2pForwardDiffEitherResidentKernel<float,", 20, "parked outside the tile loop"),
     # one workgroup of 256 threads running a whole small minimisation (512 registers a lane): the LM
     # step inside a loop keeps more lane masks and invariants alive than the one-shot kernels do
     # (the same step there: 0-18) — parked in vector lanes.  330 with the parameter count read at run
