@@ -276,6 +276,16 @@ bool aqlRetain(int device) {
   return true;
 }
 
+void aqlWarm(int device) {
+  const char *shared = std::getenv("MOPT_AQL_SHARDED");
+  if (shared && shared[0] == '0') return;  // processes share the GPU: a queue only when a sweep asks
+  DeviceState *d = deviceState(device);
+  if (!d) return;
+  std::lock_guard<std::mutex> lock(d->mutex);
+  AqlQueue &q = d->queues[d->next.load() % kQueuesPerDevice];  // the one the next aqlAcquireQueue hands out
+  if (!q.queue && !q.faulted.load() && !createQueue(*d, q)) q.faulted.store(true);
+}
+
 void aqlRelease(int device) {
   DeviceState *d = deviceState(device);
   if (!d) return;

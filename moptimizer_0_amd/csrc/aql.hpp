@@ -62,6 +62,12 @@ AqlQueue *aqlAcquireQueue(int device);
 // whether it counted (false where the direct path is off): only then call aqlRelease.
 bool aqlRetain(int device);
 void aqlRelease(int device);
+// Called where a cost of a kind that takes the direct path is created (point2point without a
+// correspondence search, reprojection, built-in scalar models): makes sure the queue its first blocking
+// sweep is going to draw exists, so that the few milliseconds of creating it fall into the construction
+// (which copies and re-lays the data anyway) and not into the first solve.  Nothing under
+// MOPT_AQL_SHARDED=0.
+void aqlWarm(int device);
 // `owner` is going away (after a drain): a timed dispatch of its that nobody read no longer holds the
 // queue's profiling signal.
 void aqlForgetStamp(AqlQueue *queue, const void *owner);

@@ -21,6 +21,9 @@ using namespace mopt_detail;
 namespace {
 thread_local std::string g_last_error;
 }  // namespace
+namespace mopt_detail {
+thread_local bool g_creating_for_search = false;
+}
 
 int mopt_detail::fail(int code, const std::string &msg) {
   g_last_error = msg;
@@ -1631,6 +1634,7 @@ int mopt_point2point_create(mopt_cost **out, int device, int scalar_bytes, const
   c->num_tiles = int(tiles);
   int rc = commonCreate(c.get(), device);
   if (rc != MOPT_OK) return rc;
+  if (!mopt_detail::g_creating_for_search) mopt_detail::aqlWarm(device);
 
   rc = mopt_point2point_set_data(c.get(), src_xyz, tgt_xyz, count, flags);
   if (rc != MOPT_OK) return rc;
@@ -1708,6 +1712,7 @@ int mopt_reprojection_create(mopt_cost **out, int device, const double *points_x
   c->num_tiles = int(tiles);
   int rc = commonCreate(c.get(), device);
   if (rc != MOPT_OK) return rc;
+  mopt_detail::aqlWarm(device);
   MOPT_HIP_TRY(deviceAlloc(&c->d_tiles, size_t(mopt::kReprojTileBytes) * c->num_tiles));
   Staging st;
   rc = stageInputs(points_xyzw, size_t(count) * 32, pixels_uv, size_t(count) * 8, flags, c->stream,
@@ -1753,6 +1758,7 @@ int mopt_scalar_model_create(mopt_cost **out, int device, int scalar_bytes, int 
   c->data_stride = padded;
   int rc = commonCreate(c.get(), device);
   if (rc != MOPT_OK) return rc;
+  mopt_detail::aqlWarm(device);
   if (planes > 0) {
     // gather the (possibly interleaved) host arrays into contiguous planes t | y
     std::vector<unsigned char> staged(size_t(planes) * size_t(padded) * scalar_bytes, 0);

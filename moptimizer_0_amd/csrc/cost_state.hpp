@@ -262,6 +262,9 @@ int residentGrid(const mopt_cost *c, int jac_mode);      // workgroups (= partia
 int residentDenseRow(const mopt_cost *c, int jac_mode);  // values per partial row; 0: rows of moments
 // point2point forward differences under AUTO / MOMENTS: moments or literal, chosen per evaluated point
 bool residentPerIterate(const mopt_cost *c, int jac_mode);
+// set by mopt_icp_create around the point2point cost it builds on: a cost with a correspondence search
+// never takes the direct dispatch path, so its creation does not warm a queue (aql.hpp aqlWarm)
+extern thread_local bool g_creating_for_search;
 // one finalize (+ LM step) over `rows` rows of `row_length` values in last->d_partials
 int residentFinalizeMerged(mopt_cost *last, int rows, int row_length, mopt::LmControl *control,
                            hipStream_t s, const mopt::LmProblem *step, int own_index);

@@ -253,9 +253,12 @@ int mopt_icp_create_from(mopt_cost **out, int device, int scalar_bytes, const vo
   // the sources go into the resident tiles in cell order; the target planes are filled by the
   // first search
   mopt_cost *raw = nullptr;
-  if (rc == MOPT_OK)
+  if (rc == MOPT_OK) {
+    g_creating_for_search = true;  // (its update(x) is queued on the stream: never on the direct path)
     rc = mopt_point2point_create(&raw, device, scalar_bytes, d_src_sorted.p, d_src_sorted.p,
                                  int64_t(matcher->kept), MOPT_INPUT_DEVICE);
+    g_creating_for_search = false;
+  }
   if (rc != MOPT_OK) {
     freeMatcher();
     return rc;
