@@ -918,9 +918,9 @@ int residentPrepareP2P(mopt_cost *c, int jac_mode, bool moments, double *partial
 
 // Rows of moments, except under MOPT_KERNEL_LITERAL.  Forward differences under AUTO / MOMENTS are the
 // one case where that is not the whole answer: where some 0 < |x_j| < 0.08 the blocking calls evaluate
-// literally (hasSmallForwardStep), and so does the device-resident loop, point by point — both sweeps are
-// queued for every evaluated point and the step kernel names the one that runs (residentPerIterate,
-// sweep.hpp kLmGateMoments / kLmGateLiteral).  Literal forward differences at EVERY iterate were measured
+// literally (hasSmallForwardStep), and so does the device-resident loop, point by point — such a cost is
+// swept by a kernel that holds both forms and the step kernel names the one that runs (residentPerIterate,
+// sweep.hpp kLmGateMoments).  Literal forward differences at EVERY iterate were measured
 // in round 5 at 21.5 against 17.9 us per evaluated point at 1 M, 101.6 against 84.4 at 10 M; the choice per
 // point pays that only at the points that need it, plus one launch that returns at once.
 bool usesMoments(const mopt_cost *c, int jac_mode) {
@@ -1233,8 +1233,11 @@ int residentSweep(mopt_cost *c, int jac_mode, mopt::LmControl *control, hipStrea
       if (residentPerIterate(c, jac_mode)) {
         // one sweep launch that holds both forward-difference forms and runs the one the step kernel named
         // for this point (sweep.hpp kLmGateMoments), and one finalize kernel that reads which it was
-        const int grid_m = residentGrid(c, jac_mode);
         const int grid_l = gridFor(c, blocksPerCu(2));
+        // the moments form over every workgroup of the launch or over the first half (one per CU, as the
+        // single-purpose moments sweep runs): MOPT_LM_EITHER_MOMENTS_BLOCKS = 2 / 1
+        static const int moments_blocks = envInt("MOPT_LM_EITHER_MOMENTS_BLOCKS", 1);
+        const int grid_m = moments_blocks >= 2 ? grid_l : std::min(grid_l, residentGrid(c, jac_mode));
         const int nacc = c->cov_mode == mopt::kCovGeneral ? mopt::kAccFull : mopt::kAccSym;
         if (c->scalar_bytes == 8)
           MOPT_HIP_TRY(mopt::launchForwardDiffEitherResident<double>(

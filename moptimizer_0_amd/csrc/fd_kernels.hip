@@ -359,8 +359,9 @@ template <typename S, bool STREAMING, int COV>
 __global__ __launch_bounds__(kBlockThreads) void p2pForwardDiffEitherResidentKernel(
     const S *tiles, int num_tiles, const P2PSweepArgs<S> *__restrict__ d_args,
     const LmControl *__restrict__ control, int moments_grid) {
-  if (control->done) return;
-  const bool literal = control[kLmGateMoments].done != 0;
+  const int gate = control[kLmGateMoments].done;  // (the one word these kernels read of the control block)
+  if (gate == kLmGateStopped) return;
+  const bool literal = gate == kLmGateLiteralForm;
   if (!literal && int(blockIdx.x) >= moments_grid) return;
   const P2PSweepArgs<S> A = *d_args;
   if (literal) {

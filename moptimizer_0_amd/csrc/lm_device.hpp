@@ -840,10 +840,8 @@ __device__ __forceinline__ bool lmStepBodyFor(const LmProblem &P, bool init, con
     ctl->pad[1] = rematch_next;
     ctl->done = finished;
     if constexpr (!STATE_STAYS) {
-      if (P.fd_per_iterate) {  // the gates of the two forward-difference sweeps (sweep.hpp)
-        ctl[kLmGateMoments].done = finished | literal_next;
-        ctl[kLmGateLiteral].done = finished | (literal_next ^ 1);
-      }
+      if (P.fd_per_iterate)  // which forward-difference form the next point's kernels run (sweep.hpp)
+        ctl[kLmGateMoments].done = finished ? kLmGateStopped : literal_next;
     }
   }
   MOPT_TICK(3);

@@ -207,15 +207,16 @@ struct LmControl {  // device memory; written by the step kernel only
   int pad[2];       // [0]: a peer-combine status (kStatusPeerTimeout) seen by a finalize kernel
 };                  // [1]: the next point is a linearization point whose correspondences are to
                     //      be re-searched first (ICP costs: the model's update(x))
-// The control block of a minimisation is kLmControlBlocks of these.  [0] is the one above.  [1] and [2]
-// are gates for a point2point cost that differentiates numerically under MOPT_KERNEL_AUTO / _MOMENTS
-// (LmProblem::fd_per_iterate): per evaluated point the host queues the moments sweep AND the literal
-// forward-difference sweep; the moments sweep is handed &control[1], the literal one &control[2], and the
-// step sets [1].done = stopped || (the next point has some 0 < |x_j| < 0.08: the reference's own
-// cancellation noise is part of its answer there, linearization.h:85-105), [2].done = stopped || not so —
-// so exactly the sweep the blocking call would choose at that x runs, the other returns at once.
-constexpr int kLmControlBlocks = 3;
-constexpr int kLmGateMoments = 1, kLmGateLiteral = 2;
+// The control block of a minimisation is kLmControlBlocks of these.  [0] is the one above.
+// [kLmGateMoments].done is ALL the sweep and the finalize kernel of a point2point cost read that
+// differentiates numerically under MOPT_KERNEL_AUTO / _MOMENTS (LmProblem::fd_per_iterate; one word, one
+// load): such kernels hold both forward-difference forms, and the step sets the word to kLmGateStopped
+// once the loop has stopped, else to kLmGateLiteralForm where the next point has some 0 < |x_j| < 0.08
+// (the reference's own cancellation noise is part of its answer there, linearization.h:85-105), else to
+// kLmGateMomentsForm — so the sweep the blocking call would choose at that x is the one that runs.
+constexpr int kLmControlBlocks = 2;
+constexpr int kLmGateMoments = 1;
+constexpr int kLmGateMomentsForm = 0, kLmGateLiteralForm = 1, kLmGateStopped = 2;
 
 struct LmCostDesc {
   int model = 0;     // LmModel

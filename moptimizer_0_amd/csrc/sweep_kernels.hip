@@ -1470,34 +1470,39 @@ __global__ __launch_bounds__(kStepThreads) void finalizeMomentsResidentKernel(
   }
 }
 
-// A cost whose forward-difference sweep is chosen per evaluated point (sweep.hpp kLmGateMoments /
-// kLmGateLiteral): the sweep that ran left rows of moments (its gate open) or dense rows (the other
-// one); the gates are rewritten only by the step at the end of this kernel, so they still say which.
+// A cost whose forward-difference sweep is chosen per evaluated point (sweep.hpp kLmGateMoments): the
+// sweep left rows of moments (the word zero) or dense rows (non-zero); the word is rewritten only by the
+// step at the end of this kernel, so it still says which.
 template <int STEP>
 __global__ __launch_bounds__(kStepThreads) void finalizeEitherResidentKernel(
     const double *partials, int grid_moments, int grid_literal, int nacc,
     const AffineBasis *__restrict__ d_basis, double *result, LmControl *control, const PeerCombine pc,
     const LmProblem P, int own_index) {
-  if (control->done) return;
-  const bool literal = control[kLmGateMoments].done != 0;  // (uniform: a kernel argument's memory)
+  const int gate = control[kLmGateMoments].done;  // (uniform: one scalar load)
+  if (gate == kLmGateStopped) return;
+  const bool literal = gate == kLmGateLiteralForm;
   using S = typename StepScalar<STEP>::type;
   LmStateWords state_words = {0u, 0u};
   if constexpr (STEP != 0) state_words = lmPrefetchState<S>(P);
+  // the basis is requested whichever form ran (the literal one does not use it): with the state it is in
+  // flight before the branch, and the rows are requested right behind — one round trip, as in the
+  // single-purpose finalize kernels
+  constexpr int kBasisDoubles = int(sizeof(AffineBasis) / sizeof(double));
+  const double basis_value = reinterpret_cast<const double *>(
+      d_basis)[int(threadIdx.x) < kBasisDoubles ? int(threadIdx.x) : 0];
+  const unsigned long long trial = (unsigned long long)control->trial;
+  __shared__ AffineBasis B;
   __shared__ double own[kSlotData];
   unsigned long long status;
   if (literal) {
     status = finalizeDenseBody<kStepThreads>(partials, grid_literal, nacc, kNumParams, result, HostPublish(),
-                                             pc, own, NoHook(), (unsigned long long)control->trial);
+                                             pc, own, NoHook(), trial);
   } else {
-    constexpr int kBasisDoubles = int(sizeof(AffineBasis) / sizeof(double));
-    const double basis_value = reinterpret_cast<const double *>(
-        d_basis)[int(threadIdx.x) < kBasisDoubles ? int(threadIdx.x) : 0];
-    __shared__ AffineBasis B;
     const auto park_basis = [&]() {
       if (int(threadIdx.x) < kBasisDoubles) reinterpret_cast<double *>(&B)[threadIdx.x] = basis_value;
     };
     status = finalizeMomentsBody<kStepThreads>(partials, grid_moments, B, result, HostPublish(), pc, own,
-                                               park_basis, (unsigned long long)control->trial);
+                                               park_basis, trial);
   }
   if (status && threadIdx.x == 0) control->pad[0] = int(status);
   if constexpr (STEP != 0) {

@@ -163,8 +163,8 @@ def test_forward_differences_at_small_parameters(hip_lib, oracle):
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_forward_difference_sweep_is_chosen_point_by_point(hip_lib, oracle, dtype):
-    """Under AUTO the device-resident loop queues both forward-difference sweeps for every point and the
-    step kernel names one (sweep.hpp kLmGateMoments / kLmGateLiteral; linearization.h:78-105).  Where no
+    """Under AUTO the device-resident loop sweeps with a kernel that holds both forward-difference forms and
+    the step kernel names one per point (sweep.hpp kLmGateMoments; linearization.h:78-105).  Where no
     evaluated point has a small parameter the solve is MOMENTS_ALWAYS's bit for bit, where every point
     has one it is LITERAL's (previous test), and on a registration that starts at x = 0 (fixed step:
     moments) and ends at a pose with one small component both kinds run in one solve — which still
