@@ -94,6 +94,15 @@ def rank_main(rank, world, out, n_total, shm_name, clouds):
         res["lm_rep"] = np.array([rep["status"], rep["iterations"], rep["sweeps"]])
         H, b, s = cost.linearize(ds.X_GENERIC, mo.JAC_ANALYTIC)  # the sequence numbers stayed in step
         res["after_lm"] = np.concatenate([H.ravel(order="F"), b, [s]])
+        # ... and with forward differences, whose sweep the step kernel chooses per evaluated point (the
+        # kernels that hold both forms, sums exchanged over the peer slots): every rank sees the same x, so
+        # every rank makes the same choice
+        x, rep = mo.capi.lm_minimize([cost], [mo.JAC_NUMERIC], np.zeros(6))
+        res["lm_fd_x"] = x
+        res["lm_fd_rep"] = np.array([rep["status"], rep["iterations"], rep["sweeps"]])
+        res["lm_fd_choice"] = np.array(cost.lm_choice_stats())
+        H, b, s = cost.linearize(ds.X_GENERIC, mo.JAC_NUMERIC)
+        res["after_lm_fd"] = np.concatenate([H.ravel(order="F"), b, [s]])
         cost.set_loss(mo.LOSS_GEMAN_MCCLURE, 50.0)
         chan.barrier("done-lm", rank)
     if rank == 0:
@@ -127,6 +136,8 @@ def rank_main(rank, world, out, n_total, shm_name, clouds):
         x, rep = mo.capi.lm_minimize([whole], [mo.JAC_ANALYTIC], np.zeros(6))
         res["lm_whole_x"] = x
         res["lm_whole_rep"] = np.array([rep["status"], rep["iterations"], rep["sweeps"]])
+        x, rep = mo.capi.lm_minimize([whole], [mo.JAC_NUMERIC], np.zeros(6))
+        res["lm_fd_whole_x"] = x
         whole.close()
     np.savez(os.path.join(out, "rank%d.npz" % rank), **res)
     chan.barrier("closing", rank)  # nobody releases its slot blocks while a peer may still push into them

@@ -117,6 +117,14 @@ def test_eight_ranks_combine_through_the_library(hip_lib, tmp_path, world, proce
     assert abs(int(res[0]["lm_rep"][1]) - int(res[0]["lm_whole_rep"][1])) <= 1
     assert np.abs(res[0]["lm_x"] - res[0]["lm_whole_x"]).max() < 1e-9 * 11
     assert np.abs(res[0]["lm_x"] - ds.FIXTURE_X).max() < 1e-3
+    # forward differences with the sweep chosen per point, over the peer slots: the same on every rank
+    for r in range(1, world):
+        assert list(res[r]["lm_fd_rep"]) == list(res[0]["lm_fd_rep"])
+        assert res[r]["lm_fd_x"].tobytes() == res[0]["lm_fd_x"].tobytes()
+        assert list(res[r]["lm_fd_choice"]) == list(res[0]["lm_fd_choice"])
+        assert res[r]["after_lm_fd"].tobytes() == res[0]["after_lm_fd"].tobytes()
+    assert res[0]["lm_fd_choice"][0] == res[0]["lm_fd_rep"][2] > 0
+    assert np.abs(res[0]["lm_fd_x"] - res[0]["lm_fd_whole_x"]).max() < 1e-7 * 11
 
 
 def test_a_ninth_rank_is_refused_by_name(hip_lib):
