@@ -922,7 +922,8 @@ int residentPrepareP2P(mopt_cost *c, int jac_mode, bool moments, double *partial
 // swept by a kernel that holds both forms and the step kernel names the one that runs (residentPerIterate,
 // sweep.hpp kLmGateMoments).  Literal forward differences at EVERY iterate were measured
 // in round 5 at 21.5 against 17.9 us per evaluated point at 1 M, 101.6 against 84.4 at 10 M; the choice per
-// point pays that only at the points that need it, plus one launch that returns at once.
+// point pays that only at the points that need it (and 0.6-2 us per point for the kernels that hold both
+// forms: profiles/r6_device_loop_choice.txt).
 bool usesMoments(const mopt_cost *c, int jac_mode) {
   (void)jac_mode;
   return c->variant != MOPT_KERNEL_LITERAL;
@@ -1234,8 +1235,9 @@ int residentSweep(mopt_cost *c, int jac_mode, mopt::LmControl *control, hipStrea
         // one sweep launch that holds both forward-difference forms and runs the one the step kernel named
         // for this point (sweep.hpp kLmGateMoments), and one finalize kernel that reads which it was
         const int grid_l = gridFor(c, blocksPerCu(2));
-        // the moments form over every workgroup of the launch or over the first half (one per CU, as the
-        // single-purpose moments sweep runs): MOPT_LM_EITHER_MOMENTS_BLOCKS = 2 / 1
+        // the moments form over the first half of the launch's workgroups (one per CU, as the single-purpose
+        // moments sweep runs; the rest leave at once) or over all of them: MOPT_LM_EITHER_MOMENTS_BLOCKS = 1 /
+        // 2 — measured 82.8-83.5 against 84.8-85.7 us per sweep at 10 M, 18.7 against 21.2 at 1 M
         static const int moments_blocks = envInt("MOPT_LM_EITHER_MOMENTS_BLOCKS", 1);
         const int grid_m = moments_blocks >= 2 ? grid_l : std::min(grid_l, residentGrid(c, jac_mode));
         const int nacc = c->cov_mode == mopt::kCovGeneral ? mopt::kAccFull : mopt::kAccSym;
