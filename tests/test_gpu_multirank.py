@@ -364,5 +364,5 @@ def test_driver_command_rehearsed_with_four_ranks(hip_lib):
     keep = os.path.join(ds.ROOT, "gpurun_out")
     if os.path.isdir(keep):
         line["_rehearsal_wall_s"] = elapsed
-        with open(os.path.join(keep, "r5_4rank_driver_command_rehearsal.json"), "w") as f:
+        with open(os.path.join(keep, "r6_4rank_driver_command_rehearsal.json"), "w") as f:
             json.dump(line, f, indent=1)
