@@ -282,8 +282,14 @@ void aqlWarm(int device) {
   DeviceState *d = deviceState(device);
   if (!d) return;
   std::lock_guard<std::mutex> lock(d->mutex);
-  AqlQueue &q = d->queues[d->next.load() % kQueuesPerDevice];  // the one the next aqlAcquireQueue hands out
-  if (!q.queue && !q.faulted.load() && !createQueue(*d, q)) q.faulted.store(true);
+  // as many queues as costs live on the device, up to the pool's size: costs draw them round robin, so the
+  // second cost of a process finds the second queue made as well (a caller that creates its costs first
+  // and sweeps afterwards — two reprojection costs of one problem — pays for no queue inside a sweep)
+  const int want = d->users < kQueuesPerDevice ? d->users : kQueuesPerDevice;
+  for (int j = 0; j < want; ++j) {
+    AqlQueue &q = d->queues[j];
+    if (!q.queue && !q.faulted.load() && !createQueue(*d, q)) q.faulted.store(true);
+  }
 }
 
 void aqlRelease(int device) {

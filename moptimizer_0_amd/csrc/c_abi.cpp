@@ -11,6 +11,8 @@
 #include <cstring>
 #include <limits>
 #include <map>
+#include <atomic>
+#include <cstdio>
 #include <mutex>
 #include <new>
 
@@ -627,8 +629,19 @@ int waitPublished(mopt_cost *c, unsigned long long sequence) {
         // faulted kernel reaches the queue's error callback
         if (mopt_detail::aqlFaulted(c->aql_queue))
           return fail(MOPT_ERR_HIP, "sweep failed: the direct-dispatch queue reported an error");
-        if (std::chrono::steady_clock::now() - started > std::chrono::seconds(60))
+        const auto waited = std::chrono::steady_clock::now() - started;
+        if (waited > std::chrono::seconds(60))
           return fail(MOPT_ERR_HIP, "timed out waiting for the sweep result (60 s)");
+        // A sweep takes milliseconds at most.  The one known way for this wait to stall is a tool that
+        // intercepts the queue and holds packets back (a per-dispatch counter profiler: aql.cpp recognises
+        // rocprofv3's by its environment variables and stays off; one it does not recognise ends up here)
+        // — say once what to do instead of waiting out the minute in silence.
+        static std::atomic<bool> hinted{false};
+        if (waited > std::chrono::seconds(3) && !hinted.exchange(true))
+          std::fprintf(stderr,
+                       "libmoptimizer_hip: a blocking sweep dispatched through the library's own HSA queue has "
+                       "not completed after 3 s; if a tool is intercepting GPU queues (a counter-collecting "
+                       "profiler), run with MOPT_AQL=0 to keep every launch on HIP streams\n");
         __builtin_ia32_pause();
         continue;
       }
