@@ -1402,11 +1402,14 @@ def test_costs_used_concurrently_from_threads(hip_lib, oracle):
     assert not any(t.is_alive() for t in threads)
 
 
-def test_group_shards_on_one_gpu(hip_lib, oracle):
-    """mopt_group_* with a repeated device: three contiguous shards of a ragged count on GPU 0.
-    Same result as one cost over everything (shard invariance) and as the oracle."""
+@pytest.mark.parametrize("shards", [3, 8])
+def test_group_shards_on_one_gpu(hip_lib, oracle, shards):
+    """mopt_group_* with a repeated device: three — and eight, BASELINE config 4's count, what
+    `CostFunctionHip(model, n, m, N, std::vector<int>{0, …, 7})` builds — contiguous shards of a ragged
+    count on GPU 0, a host thread each.  Same result as one cost over everything (shard invariance)
+    and as the oracle."""
     src, tgt = ds.synthetic_pair(100_003, seed=51, noise=0.02)
-    grp = hip_lib.Point2PointGroup(src, tgt, devices=[0, 0, 0])
+    grp = hip_lib.Point2PointGroup(src, tgt, devices=[0] * shards)
     one = hip_lib.Point2PointCost(src, tgt)
     cov = np.diag([0.5, 2.0, 3.0])
     grp.set_covariance(cov)
