@@ -15,7 +15,7 @@ OBJDIR      = build/obj
 LIBDIR      = moptimizer_0_amd/lib
 LIB         = $(LIBDIR)/libmoptimizer_hip.so
 
-PUBLIC_HEADERS = include/moptimizer_hip.h include/moptimizer_amd/so3.hpp $(CSRC)/sweep.hpp \
+PUBLIC_HEADERS = include/moptimizer_hip.h include/moptimizer_amd/so3.hpp $(CSRC)/sweep.hpp $(CSRC)/fd_device.hpp \
                  $(CSRC)/sweep_device.hpp $(CSRC)/jit_model.hpp $(CSRC)/cost_state.hpp $(CSRC)/lm_device.hpp $(CSRC)/aql.hpp
 
 all: $(LIB)

@@ -733,8 +733,9 @@ def main():
                                    "forward-difference registration from x = 0 under mopt_lm_minimize "
                                    "(median of 20), the sweep of every point chosen as the blocking call "
                                    "chooses it (solve_points_literal of solve_points_chosen took the literal "
-                                   "one, over all 25 solves); solve_ms_moments_always = the same with "
-                                   "MOPT_KERNEL_MOMENTS_ALWAYS: one launch of one workgroup"}
+                                   "one, over all 25 solves), in one launch of one workgroup that holds both "
+                                   "forms; solve_ms_moments_always = the same with MOPT_KERNEL_MOMENTS_ALWAYS: "
+                                   "the moments-only variant of that kernel"}
         c0.close()
         n1 = 1_000_000
         c1, s1, t1 = make_cost(n1)

@@ -107,12 +107,11 @@ enum mopt_kernel_variant {
                               the mode: moments, except forward differences at an x with some
                               0 < |x_j| < 0.08 (literal) — in the blocking and asynchronous
                               calls AND, since round 6, at every point the device-resident loop
-                              (mopt_lm_minimize) evaluates: both forward-difference sweeps are
-                              queued per point and the step kernel names the one the rule asks
-                              for at that x (mopt_cost_lm_choice_stats counts them; one launch
-                              that returns at once per point is the price).  The one-launch
-                              solve of small problems holds one sweep and is therefore not
-                              taken by such costs (MOPT_KERNEL_MOMENTS_ALWAYS takes it)          */
+                              (mopt_lm_minimize) evaluates: its sweep and finalize kernels hold
+                              both forward-difference forms and the step kernel, which forms
+                              the next x, names the one the rule asks for there
+                              (mopt_cost_lm_choice_stats counts them); so does the one-launch
+                              solve of small problems                                          */
   MOPT_KERNEL_LITERAL = 1, /* every residual and Jacobian entry formed per point, then
                               w * J^T * S * J accumulated entry by entry, as the reference does */
   MOPT_KERNEL_MOMENTS = 2, /* Jacobians that are affine in the source point (all point2point

@@ -195,7 +195,6 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
   }
   const bool one_workgroup = num_costs == 1 && lead->model == kModelPoint2Point && !lead->matcher &&
                              lead->combine.mode == MOPT_COMBINE_NONE && problem.cost[0].moments &&
-                             !problem.fd_per_iterate &&  // (its sweep is chosen point by point: two kernels)
                              problem.n == kNumParams && lead->num_tiles >= 1 &&
                              lead->num_tiles <= small_tiles &&
                              max_points <= 4096;  // (one kernel for the whole loop: at ~8 us a point, <= 35 ms)
@@ -204,12 +203,12 @@ int mopt_lm_minimize(mopt_cost *const *costs, int num_costs, const int *jacobian
       MOPT_HIP_TRY(mopt::launchP2PSolveSmall<double>(
           static_cast<const double *>(lead->d_tiles), lead->num_tiles,
           static_cast<const mopt::P2PSweepArgs<double> *>(lead->d_lm_args), lead->d_lm_basis,
-          lead->d_result, problem, static_cast<const double *>(x), int(max_points), s));
+          lead->d_result, problem, static_cast<const double *>(x), int(max_points), lead->cov_mode, s));
     else
       MOPT_HIP_TRY(mopt::launchP2PSolveSmall<float>(
           static_cast<const float *>(lead->d_tiles), lead->num_tiles,
           static_cast<const mopt::P2PSweepArgs<float> *>(lead->d_lm_args), lead->d_lm_basis,
-          lead->d_result, problem, static_cast<const float *>(x), int(max_points), s));
+          lead->d_result, problem, static_cast<const float *>(x), int(max_points), lead->cov_mode, s));
   } else if (lead->scalar_bytes == 8)
     MOPT_HIP_TRY(mopt::launchLmStep<double>(problem, true, static_cast<const double *>(x), s));
   else

@@ -558,11 +558,13 @@ __device__ __forceinline__ void storeReport(double *p, double v) {
 // lives in this function's LDS from one run to the next and never travels to HBM and back.
 // FIXED_N: the parameter count when the caller knows it at compile time (0: P.n) — the solve's
 // dispatch on n and every `i < n` predicate then fold away.
-template <typename S, int NMAX, bool STATE_STAYS = false, int FIXED_N = 0>
+// CHOOSE_FD (with STATE_STAYS: the one-launch solve that holds both forward-difference forms): the step
+// also decides which form the next point takes and says so in *choice_out (LDS).
+template <typename S, int NMAX, bool STATE_STAYS = false, int FIXED_N = 0, bool CHOOSE_FD = false>
 __device__ __forceinline__ bool lmStepBodyFor(const LmProblem &P, bool init, const LmStart<S> &start,
                               const double *own_result, int own_index, bool prefetched,
                               LmStateWords state_words, void *args_local = nullptr,
-                              AffineBasis *basis_local = nullptr) {
+                              AffineBasis *basis_local = nullptr, int *choice_out = nullptr) {
 #ifdef MOPT_LM_TIMING
   __shared__ unsigned long long tick[8];
 #define MOPT_TICK(i) if (threadIdx.x == 0) tick[i] = wall_clock64()
@@ -806,9 +808,10 @@ __device__ __forceinline__ bool lmStepBodyFor(const LmProblem &P, bool init, con
     st.steps += 1;
     // Which forward-difference sweep the next point takes (costs of LmProblem::fd_per_iterate): the rule
     // of the blocking call (c_abi.cpp hasSmallForwardStep) at the very x that sweep is evaluated at.
-    // (Not in the one-launch solve, whose one sweep is compiled in: lm.cpp keeps such problems out of it.)
+    // (Compiled out of the one-launch solve that holds the moments only: lm.cpp keeps such problems out of
+    // it, and the code cost that kernel a hundred spilled scalar registers.)
     literal_next = 0;
-    if constexpr (!STATE_STAYS) {
+    if constexpr (!STATE_STAYS || CHOOSE_FD) {
       if (P.fd_per_iterate) {
         if (init) st.literal_points = 0;
         if (propose)
@@ -818,6 +821,7 @@ __device__ __forceinline__ bool lmStepBodyFor(const LmProblem &P, bool init, con
           }
         st.literal_points += literal_next;
       }
+      if constexpr (CHOOSE_FD) *choice_out = literal_next;
     }
   }
   __syncthreads();
@@ -861,7 +865,8 @@ __device__ __forceinline__ bool lmStepBodyFor(const LmProblem &P, bool init, con
       storeReport(&rep->iterations, double(st.it));
       storeReport(&rep->trials, double(st.trials));
       storeReport(&rep->peer_status, double(ctl->pad[0]));
-      if constexpr (!STATE_STAYS) storeReport(&rep->pad[0], P.fd_per_iterate ? double(st.literal_points) : 0.0);
+      if constexpr (!STATE_STAYS || CHOOSE_FD)
+        storeReport(&rep->pad[0], P.fd_per_iterate ? double(st.literal_points) : 0.0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 #ifdef MOPT_LM_TIMING

@@ -273,12 +273,14 @@ hipError_t launchStoreArgs(const Args &value, Args *d_dst, hipStream_t stream);
 // A whole minimisation of one small point2point cost (moments sweep, <= solveSmallMaxTiles() tiles,
 // 6 parameters) in one launch of one workgroup: sweep_kernels.hip p2pSolveSmallKernel.  The cost's
 // resident blocks must hold its data / loss / covariance (residentPrepare); the report goes where
-// problem.report says, as from the launch-per-point loop.
+// problem.report says, as from the launch-per-point loop.  fd_cov: the cost's covariance form (kCov*) where
+// problem.fd_per_iterate is set — the kernel then also holds the literal forward-difference form for that
+// covariance and the step chooses per point —, ignored otherwise.
 int solveSmallMaxTiles();
 template <typename S>
 hipError_t launchP2PSolveSmall(const S *tiles, int num_tiles, const P2PSweepArgs<S> *d_args,
                                const AffineBasis *d_basis, double *result, const LmProblem &problem,
-                               const S *x0, int max_points, hipStream_t stream);
+                               const S *x0, int max_points, int fd_cov, hipStream_t stream);
 
 // Resident forms: per-x constants read from HBM (`d_args`, `d_basis`), early exit on control->done,
 // peer-combine sequence = peers.sequence + control->trial.

@@ -20,6 +20,7 @@
 //   * A second tiny kernel adds the workgroup partials in a fixed order and writes
 //     H (column-major) | b | sum_sq; no atomics anywhere.
 #include "sweep_device.hpp"
+#include "fd_device.hpp"
 #include "lm_device.hpp"
 
 namespace mopt {
@@ -1527,11 +1528,18 @@ __global__ __launch_bounds__(kStepThreads) void finalizeEitherResidentKernel(
 // every thread reaches.
 constexpr int kSolveSmallTiles = 4;
 
-template <typename S>
+// FD_COV >= 0 (a covariance form): the kernel also holds the literal forward-difference form for that
+// covariance (fd_device.hpp, over the packs held in registers, rotations re-read from LDS: registers are
+// what this kernel is short of) and the step says per point which form runs — a cost that differentiates
+// numerically under MOPT_KERNEL_AUTO / _MOMENTS (LmProblem::fd_per_iterate).  FD_COV = -1: moments only.
+template <typename S, int FD_COV>
 __global__ __launch_bounds__(kBlockThreads) void p2pSolveSmallKernel(
     const S *tiles, int num_tiles, const P2PSweepArgs<S> *__restrict__ d_args,
     const AffineBasis *__restrict__ d_basis, double *result, const LmProblem problem,
     const LmStart<S> start, int max_points) {
+  constexpr bool kChooses = FD_COV >= 0;
+  __shared__ int fd_choice;  // written by the step: the next point takes the literal form
+  if (threadIdx.x == 0) fd_choice = 0;
   __shared__ P2PSweepArgs<S> A;
   __shared__ AffineBasis B;
   // the problem's description, read from LDS inside the loop: as kernel arguments its 1.2 KB are
@@ -1566,26 +1574,66 @@ __global__ __launch_bounds__(kBlockThreads) void p2pSolveSmallKernel(
 #ifdef MOPT_LM_TIMING
     const unsigned long long tick_step = wall_clock64();
 #endif
-    const bool finished = lmStepBodyFor<S, kMaxParams, true, kNumParams>(
-        P, point == 0, start, own, 0, false, LmStateWords(), &A, &B);
+    const bool finished = lmStepBodyFor<S, kMaxParams, true, kNumParams, kChooses>(
+        P, point == 0, start, own, 0, false, LmStateWords(), &A, &B, &fd_choice);
     if (finished || point >= max_points) break;
 #ifdef MOPT_LM_TIMING
     const unsigned long long tick_sweep = wall_clock64();
+    unsigned long long tick_finalize = tick_sweep;
 #endif
-    double acc[kAccMoments];
+    bool literal = false;
+    if constexpr (kChooses) literal = fd_choice != 0;  // (uniform; the step's barriers precede this read)
+    if (literal) {
+      if constexpr (kChooses) {
+        constexpr int NACC = (FD_COV == kCovGeneral) ? kAccFull : kAccSym;
+        __shared__ double dense_row[NACC];
+        p2pForwardDiffRow<S, FD_COV, kFdRotationLds>(
+            A, A,
+            [&](auto &&body) {
 #pragma unroll
-    for (int k = 0; k < kAccMoments; ++k) acc[k] = 0.0;
+              for (int t = 0; t < kSolveSmallTiles; ++t)
+                if (t < num_tiles) body(held[t], (long long)t * TP + threadIdx.x * V);
+            },
+            dense_row);
+        __syncthreads();
+        // one row: nothing to add up — H (column-major) | b | sum_sq out of the row's layout, as
+        // finalizeDenseBody lays them out
+        const int k = threadIdx.x;
+        constexpr int n = kNumParams, count = n * n + n + 1;
+        if (k < count) {
+          double v;
+          if (k < n * n) {
+            const int i = k % n, j = k / n;
+            if (FD_COV == kCovGeneral) {
+              v = dense_row[j * n + i];
+            } else {
+              const int lo = i < j ? i : j, hi = i < j ? j : i;
+              v = dense_row[hi * (hi + 1) / 2 + lo];
+            }
+          } else {
+            v = dense_row[(FD_COV == kCovGeneral ? n * n : n * (n + 1) / 2) + (k - n * n)];
+          }
+          result[k] = v;
+          own[k] = v;
+        }
+        __syncthreads();
+      }
+    } else {
+      double acc[kAccMoments];
 #pragma unroll
-    for (int t = 0; t < kSolveSmallTiles; ++t)
-      if (t < num_tiles) momentsOfPack<S>(acc, held[t], (long long)t * TP + threadIdx.x * V, A);
-    blockReduceStore<kAccMoments>(acc, row);
-    __syncthreads();
+      for (int k = 0; k < kAccMoments; ++k) acc[k] = 0.0;
+#pragma unroll
+      for (int t = 0; t < kSolveSmallTiles; ++t)
+        if (t < num_tiles) momentsOfPack<S>(acc, held[t], (long long)t * TP + threadIdx.x * V, A);
+      blockReduceStore<kAccMoments>(acc, row);
+      __syncthreads();
 #ifdef MOPT_LM_TIMING
-    const unsigned long long tick_finalize = wall_clock64();
+      tick_finalize = wall_clock64();
 #endif
-    finalizeMomentsBody<kBlockThreads, NoHook, false>(row, 1, B, result, HostPublish(), PeerCombine(),
-                                                      own);
-    __syncthreads();
+      finalizeMomentsBody<kBlockThreads, NoHook, false>(row, 1, B, result, HostPublish(), PeerCombine(),
+                                                        own);
+      __syncthreads();
+    }
 #ifdef MOPT_LM_TIMING
     if (threadIdx.x == 0)
       printf("one launch, point %d: step %llu sweep of %d tiles %llu contraction %llu (x10 ns)\n", point,
@@ -1953,22 +2001,40 @@ int solveSmallMaxTiles() { return kSolveSmallTiles; }
 template <typename S>
 hipError_t launchP2PSolveSmall(const S *tiles, int num_tiles, const P2PSweepArgs<S> *d_args,
                                const AffineBasis *d_basis, double *result, const LmProblem &problem,
-                               const S *x0, int max_points, hipStream_t stream) {
+                               const S *x0, int max_points, int fd_cov, hipStream_t stream) {
   if (num_tiles < 1 || num_tiles > kSolveSmallTiles || problem.num_costs != 1 ||
       problem.n != kNumParams || max_points < 1)
     return hipErrorInvalidValue;
   LmStart<S> start;
   for (int i = 0; i < kMaxWideParams; ++i) start.x[i] = i < problem.n ? x0[i] : S(0);
-  hipLaunchKernelGGL((p2pSolveSmallKernel<S>), dim3(1), dim3(kBlockThreads), 0, stream, tiles,
-                     num_tiles, d_args, d_basis, result, problem, start, max_points);
+  const dim3 g(1), b(kBlockThreads);
+  switch (problem.fd_per_iterate ? fd_cov : -1) {
+    case kCovIdentity:
+      hipLaunchKernelGGL((p2pSolveSmallKernel<S, kCovIdentity>), g, b, 0, stream, tiles, num_tiles, d_args,
+                         d_basis, result, problem, start, max_points);
+      break;
+    case kCovSymmetric:
+      hipLaunchKernelGGL((p2pSolveSmallKernel<S, kCovSymmetric>), g, b, 0, stream, tiles, num_tiles, d_args,
+                         d_basis, result, problem, start, max_points);
+      break;
+    case kCovGeneral:
+      hipLaunchKernelGGL((p2pSolveSmallKernel<S, kCovGeneral>), g, b, 0, stream, tiles, num_tiles, d_args,
+                         d_basis, result, problem, start, max_points);
+      break;
+    default:
+      if (problem.fd_per_iterate) return hipErrorInvalidValue;  // (needs the literal form: name its covariance)
+      hipLaunchKernelGGL((p2pSolveSmallKernel<S, -1>), g, b, 0, stream, tiles, num_tiles, d_args, d_basis,
+                         result, problem, start, max_points);
+      break;
+  }
   return hipGetLastError();
 }
 template hipError_t launchP2PSolveSmall<float>(const float *, int, const P2PSweepArgs<float> *,
                                                const AffineBasis *, double *, const LmProblem &,
-                                               const float *, int, hipStream_t);
+                                               const float *, int, int, hipStream_t);
 template hipError_t launchP2PSolveSmall<double>(const double *, int, const P2PSweepArgs<double> *,
                                                 const AffineBasis *, double *, const LmProblem &,
-                                                const double *, int, hipStream_t);
+                                                const double *, int, int, hipStream_t);
 
 template <typename S>
 hipError_t launchP2PMomentsResident(const S *tiles, int num_tiles, const P2PSweepArgs<S> *d_args,

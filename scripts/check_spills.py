@@ -43,6 +43,13 @@ ACCEPTED_SGPR_SPILLS = (
     # time, 92 with n = 6 fixed at compile time (the solve's dispatch on n and every `i < n` predicate
     # fold away); a point costs 7-8 us instead of 10-11 (profiles/r5_small_solve.txt)
     ("mopt::p2pSolveSmallKernel<", 100, "LM step inside a loop"),
+    # the variants that also hold the literal forward-difference form for a cost whose sweep is chosen per
+    # point (round 6; FD_COV = 0, 1, 2): the fp64 ones park 160 / 160 / 208 scalars — the same step plus
+    # the choice and a second sweep body in the loop; measured +0.3-0.4 us per evaluated point against the
+    # moments-only variant (profiles/r6_small_solve.txt), against +3-4 us for the launch-per-point loop
+    ("mopt::p2pSolveSmallKernel<double, 0>", 170, "LM step + two sweep forms inside a loop"),
+    ("mopt::p2pSolveSmallKernel<double, 1>", 170, "LM step + two sweep forms inside a loop"),
+    ("mopt::p2pSolveSmallKernel<double, 2>", 216, "LM step + two sweep forms inside a loop"),
 )
 # Vector registers the allocator moved to the accumulation registers of the same lane (vgpr spills
 # with NO scratch memory): for the kernel that holds its correspondences in registers across a whole

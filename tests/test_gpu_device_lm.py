@@ -688,9 +688,6 @@ def test_small_problems_in_one_launch_take_the_same_iterates(hip_lib, oracle, dt
             numeric = jac == mo.JAC_NUMERIC
             cost.set_covariance(cv)
             cost.set_loss(loss, 100.0)
-            # forward differences under AUTO choose their sweep point by point and stay out of the one-launch
-            # solve (moptimizer_hip.h); MOMENTS_ALWAYS is the variant that takes it
-            cost.set_kernel_variant(mo.KERNEL_MOMENTS_ALWAYS if numeric else mo.KERNEL_AUTO)
             for k in (1, 3, 15):
                 got = {}
                 for tiles in ("4", "0"):
@@ -729,3 +726,74 @@ def test_small_problems_in_one_launch_take_the_same_iterates(hip_lib, oracle, dt
             assert (rep["status"], rep["iterations"]) == (status, iters), (k, rep, status, iters)
             assert np.abs(x - xr).max() < 1e-9 * max(1.0, np.abs(xr).max()), (k, x, xr)
         cost.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_one_launch_solve_holds_both_forward_difference_forms(hip_lib, oracle, dtype, monkeypatch):
+    """A small point2point cost that differentiates numerically under AUTO is still minimised by one launch
+    of one workgroup: the kernel holds the literal forward-difference form beside the moments
+    (p2pSolveSmallKernel<S, FD_COV>, fd_device.hpp over the packs held in registers) and the step chooses
+    per point, as in the launch-per-point loop (MOPT_LM_ONE_LAUNCH_TILES=0), whose sums it adds in another
+    order.  Nearly aligned clouds — every point small, every sweep literal — under each covariance form
+    and the robust loss: the same status, iteration count, sweeps and, to forward-difference noise, x as
+    that loop; the first iterate is the CPU loop's; and a solve in which both forms run."""
+    mo = hip_lib
+    fp64 = dtype == np.float64
+    per_tile = 512 if fp64 else 1024
+    rng = np.random.default_rng(21)
+    x_small = np.array([0.02, -0.03, 0.01, 0.004, -0.006, 0.005])
+    covs = (None, np.array([[2.0, 0.3, -0.1], [0.3, 0.5, 0.2], [-0.1, 0.2, 1.5]]),
+            np.array([[2.0, 0.7, -0.1], [0.3, 0.5, 0.9], [-0.4, 0.2, 1.5]]))
+    differed = 0
+    for n in (700, 4 * per_tile):
+        src = rng.random((n, 3)) * 10.0
+        T = oracle.se3_from_x(x_small)
+        tgt = src @ T[:3, :3].T + T[:3, 3] + rng.normal(0, 0.01, (n, 3))
+        cost = mo.Point2PointCost(src.astype(dtype), tgt.astype(dtype), dtype=dtype)
+        x0 = (0.5 * x_small).astype(dtype)
+        for cov in covs:
+            for loss in (0, 1):
+                cost.set_covariance(cov)
+                cost.set_loss(loss, 100.0)
+                for k in (1, 3, 15):
+                    p0, l0 = cost.lm_choice_stats()
+                    monkeypatch.delenv("MOPT_LM_ONE_LAUNCH_TILES", raising=False)
+                    xa, ra = mo.capi.lm_minimize([cost], [mo.JAC_NUMERIC], x0, max_iterations=k)
+                    p1, l1 = cost.lm_choice_stats()
+                    assert p1 - p0 == ra["sweeps"] and l1 - l0 == ra["sweeps"], (n, k, p1 - p0, l1 - l0, ra)
+                    monkeypatch.setenv("MOPT_LM_ONE_LAUNCH_TILES", "0")
+                    xb, rb = mo.capi.lm_minimize([cost], [mo.JAC_NUMERIC], x0, max_iterations=k)
+                    what = (n, cov is not None, loss, k, ra, rb, xa - xb)
+                    if k < 15 and fp64:
+                        assert (ra["status"], ra["iterations"], ra["sweeps"]) == (rb["status"], rb["iterations"], rb["sweeps"]), what
+                    # (run into the iteration limit, both loops wander at the noise floor of literal forward
+                    # differences at |x_j| ~ 0.005 — eps |R p + t| / h_j ~ 4e-5 per Jacobian entry — each along
+                    # its own summation order: same minimum, looser x)
+                    tol = (FD_ITERATE_TOL if k < 15 else 1e-6) if fp64 else 5e-3
+                    assert np.abs(xa - xb).max() <= tol, what
+                    assert abs(ra["cost"] - rb["cost"]) <= (1e-6 if fp64 else 1e-2) * rb["cost"], what
+                    differed += int(not np.array_equal(xa, xb))
+        if fp64:  # the first iterate against the CPU loop (identity covariance, no loss)
+            cost.set_covariance(None)
+            cost.set_loss(0, 0.0)
+            monkeypatch.delenv("MOPT_LM_ONE_LAUNCH_TILES", raising=False)
+            x1, rep = mo.capi.lm_minimize([cost], [mo.JAC_NUMERIC], x0, max_iterations=1)
+            xr1, _, _ = oracle.p2p_minimize(src, tgt, 0.5 * x_small, cost_class=ob.NUMERIC_DYN,
+                                            layout=ob.LAYOUT_ROW_MAJOR, max_iter=1)
+            assert rep["iterations"] == 1 and np.abs(x1 - xr1).max() < 1e-10, x1 - xr1
+        cost.close()
+    # the two loops are different kernels: identical bits throughout would mean the one launch never ran
+    assert differed > 0
+    # from x = 0 (fixed step: moments) to a pose with one small component (literal): both forms in one launch
+    monkeypatch.delenv("MOPT_LM_ONE_LAUNCH_TILES", raising=False)
+    x_true = np.array([0.5, -0.3, 0.2, 0.01, -0.2, 0.3])
+    src = rng.random((1500, 3)) * 10.0
+    T = oracle.se3_from_x(x_true)
+    tgt = src @ T[:3, :3].T + T[:3, 3] + rng.normal(0, 0.01, (1500, 3))
+    cost = mo.Point2PointCost(src.astype(dtype), tgt.astype(dtype), dtype=dtype)
+    x, rep = mo.capi.lm_minimize([cost], [mo.JAC_NUMERIC], np.zeros(6, dtype=dtype))
+    points, literal = cost.lm_choice_stats()
+    assert points == rep["sweeps"] and 0 < literal < points, (points, literal, rep)
+    assert np.abs(x - x_true).max() < (2e-3 if fp64 else 1e-2), x - x_true
+    cost.close()
+
