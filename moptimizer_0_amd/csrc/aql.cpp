@@ -282,12 +282,14 @@ void aqlWarm(int device) {
   DeviceState *d = deviceState(device);
   if (!d) return;
   std::lock_guard<std::mutex> lock(d->mutex);
-  // as many queues as costs live on the device, up to the pool's size: costs draw them round robin, so the
-  // second cost of a process finds the second queue made as well (a caller that creates its costs first
-  // and sweeps afterwards — two reprojection costs of one problem — pays for no queue inside a sweep)
+  // the queues the next draws are going to hand out (aqlAcquireQueue: round robin from `next`), as many
+  // as costs live on the device, up to the pool's size: a caller that creates its costs first and sweeps
+  // afterwards — two reprojection costs of one problem — pays for no queue inside a sweep, and neither
+  // does the cost that follows a short-lived one (whose draw moved `next` on)
   const int want = d->users < kQueuesPerDevice ? d->users : kQueuesPerDevice;
+  const unsigned first = d->next.load();
   for (int j = 0; j < want; ++j) {
-    AqlQueue &q = d->queues[j];
+    AqlQueue &q = d->queues[(first + unsigned(j)) % kQueuesPerDevice];
     if (!q.queue && !q.faulted.load() && !createQueue(*d, q)) q.faulted.store(true);
   }
 }
