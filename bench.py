@@ -345,10 +345,37 @@ def spawn_ranks(args):
         raise SystemExit(bad[0] if bad else 1)
 
 
+def refuse_more_processes_than_the_gpu_admits(world):
+    """A rehearsal (MOPT_BENCH_BACKEND=gloo: ranks share GPUs) on a machine that limits the processes per
+    GPU — this pool ends a run that puts more than 6 on one, the caller included — is refused HERE, by name,
+    before any rank exists, when MOPT_MAX_PROCESSES_PER_GPU says what the limit is: eight rank processes on
+    one GPU are not a time-out or a killed run but exit code 4 and a sentence.  (Ranks as threads reach
+    world size 8 on such a machine: tests/test_gpu_multirank.py test_eight_ranks_combine_through_the_library.)"""
+    limit = int(os.environ.get("MOPT_MAX_PROCESSES_PER_GPU", "0"))
+    if limit <= 0 or os.environ.get("MOPT_BENCH_BACKEND", "nccl") == "nccl":
+        return
+    import subprocess
+    try:  # (counting devices does not initialise the GPU in this process)
+        ndev = int(subprocess.check_output([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                                           stderr=subprocess.DEVNULL).split()[-1])
+    except Exception:  # noqa: BLE001
+        ndev = 1
+    per_gpu = -(-world // max(ndev, 1))
+    if per_gpu + 1 > limit:
+        print(json.dumps({"error": "bench.py: %d ranks on %d GPU(s) are %d rank processes on one GPU, %d with "
+                                   "their caller; MOPT_MAX_PROCESSES_PER_GPU=%d (this machine's limit on processes "
+                                   "per GPU) admits %d ranks per GPU — not started" %
+                                   (world, ndev, per_gpu, per_gpu + 1, limit, limit - 1),
+                          "resource": "processes per GPU", "ranks": world, "gpus": ndev, "limit": limit}),
+              file=sys.stderr, flush=True)
+        raise SystemExit(4)
+
+
 def main():
     args = parse_args()
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
+        refuse_more_processes_than_the_gpu_admits(args.gpus)
         return spawn_ranks(args)
     world = int(env_world or "1")
     if world != args.gpus:

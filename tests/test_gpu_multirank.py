@@ -310,6 +310,41 @@ def test_bench_launches_its_own_ranks(hip_lib):
     _check_multirank_line(line, 2, rehearsal)
 
 
+def test_eight_rank_processes_on_one_gpu_are_refused_by_name(hip_lib):
+    """BASELINE config 4's world size as rank PROCESSES cannot be rehearsed on this pool: it ends a run that
+    puts more than 6 processes on a GPU (its process guard), the test runner being one — so `bench.py
+    --gpus 8` on one GPU would be killed, not measured.  Told the limit (MOPT_MAX_PROCESSES_PER_GPU), the
+    bench refuses before it starts a single rank: exit code 4 and the resource named on stderr, within a
+    second or two — not a time-out.  (World size 8 itself runs above, as rank threads.)"""
+    import json
+    import time
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("several GPUs: eight ranks need not share one")
+    env = dict(os.environ, MOPT_BENCH_BACKEND="gloo", MOPT_MAX_PROCESSES_PER_GPU="6")
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ds.ROOT, "bench.py"), "--gpus", "8", "--steps", "20",
+                          "--warmup", "5", "--collective", "rccl"], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=120)
+    assert out.returncode == 4, (out.returncode, out.stderr.decode()[-2000:])
+    assert out.stdout.decode().strip() == ""
+    said = json.loads([ln for ln in out.stderr.decode().splitlines() if ln.startswith("{")][-1])
+    assert said["resource"] == "processes per GPU" and said["ranks"] == 8 and said["limit"] == 6
+    assert "not started" in said["error"]
+    assert time.time() - t0 < 60
+    # ... and a world size the limit admits is not refused by that check (5 ranks + the caller = 6)
+    env["MOPT_MAX_PROCESSES_PER_GPU"] = "6"
+    import bench
+    os.environ.update({"MOPT_BENCH_BACKEND": "gloo", "MOPT_MAX_PROCESSES_PER_GPU": "6"})
+    try:
+        bench.refuse_more_processes_than_the_gpu_admits(5)
+        with pytest.raises(SystemExit):
+            bench.refuse_more_processes_than_the_gpu_admits(6)
+    finally:
+        os.environ.pop("MOPT_BENCH_BACKEND", None)
+        os.environ.pop("MOPT_MAX_PROCESSES_PER_GPU", None)
+
+
 def test_driver_command_rehearsed_with_four_ranks(hip_lib):
     """The driver's multi-GPU command — default workload (10 M correspondences per rank), default
     settling, every extra pass, the 10 M strong-scaling split, the CPU baseline; plus `--collective
