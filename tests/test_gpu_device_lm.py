@@ -797,3 +797,41 @@ def test_one_launch_solve_holds_both_forward_difference_forms(hip_lib, oracle, d
     assert np.abs(x - x_true).max() < (2e-3 if fp64 else 1e-2), x - x_true
     cost.close()
 
+
+def test_metric_size_10M_device_loop_chooses_per_point(hip_lib, oracle):
+    """The per-point choice of the forward-difference sweep at the metric's own size (10 M correspondences,
+    BASELINE.json), through properties that need no CPU sweep: between nearly aligned clouds every point is
+    small and the AUTO solve is the LITERAL solve bit for bit (the literal form of the kernel that holds both
+    ran at every point); between clouds a generic pose apart no point is small and it is the MOMENTS_ALWAYS
+    solve bit for bit; either lands on the pose the data were made with."""
+    mo = hip_lib
+    import torch
+    n = 10_000_000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    src = torch.rand((n, 3), generator=g, device="cuda", dtype=torch.float64) * 10.0
+    for x_true, other, all_literal in ((np.array([0.02, -0.03, 0.01, 0.004, -0.006, 0.005]), mo.KERNEL_LITERAL, True),
+                                       (np.array([1.5, -1.3, 1.2, 0.4, -0.5, 0.3]), mo.KERNEL_MOMENTS_ALWAYS, False)):
+        T = torch.tensor(oracle.se3_from_x(x_true), device="cuda", dtype=torch.float64)
+        tgt = (src @ T[:3, :3].T + T[:3, 3] + 0.01 * torch.randn((n, 3), generator=g, device="cuda",
+                                                                   dtype=torch.float64)).contiguous()
+        torch.cuda.synchronize()
+        cost = mo.Point2PointCost(src.data_ptr(), tgt.data_ptr(), device_ptrs=True, count=n)
+        x0 = x_true * (0.5 if all_literal else 1.0) + (0.0 if all_literal else 0.05)
+        got = {}
+        for variant in (mo.KERNEL_AUTO, other):
+            cost.set_kernel_variant(variant)
+            got[variant] = mo.capi.lm_minimize([cost], [mo.JAC_NUMERIC], x0, max_iterations=4)
+        (xa, ra), (xo, ro) = got[mo.KERNEL_AUTO], got[other]
+        points, literal = cost.lm_choice_stats()
+        assert points == ra["sweeps"] and literal == (points if all_literal else 0), (points, literal, ra)
+        assert ra == ro and np.array_equal(xa, xo), (ra, ro, xa - xo)
+        assert np.abs(xa - x_true).max() < 5e-2, xa - x_true
+        # (four damped iterations: near, not at, the pose; run out, at it)
+        cost.set_kernel_variant(mo.KERNEL_AUTO)
+        xf, rf = mo.capi.lm_minimize([cost], [mo.JAC_NUMERIC], x0, max_iterations=30)
+        assert np.abs(xf - x_true).max() < 2e-3, (xf - x_true, rf)
+        cost.close()
+        del tgt
+    torch.cuda.empty_cache()
+

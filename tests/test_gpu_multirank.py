@@ -85,8 +85,9 @@ def run_thread_ranks(tmp_path, world, processes, n_total, extra_env=None, timeou
     return [np.load(os.path.join(tmp_path, "rank%d.npz" % r)) for r in range(world)]
 
 
-@pytest.mark.parametrize("world,processes", [(8, 4), (8, 2), (4, 4)])
-def test_eight_ranks_combine_through_the_library(hip_lib, tmp_path, world, processes):
+@pytest.mark.parametrize("world,processes,n_total", [(8, 4, 400_009), (8, 2, 400_009), (4, 4, 400_009),
+                                                     (8, 4, 10_000_000)])
+def test_eight_ranks_combine_through_the_library(hip_lib, tmp_path, world, processes, n_total):
     """BASELINE config 4's world size, G = kMaxPeers = 8 (csrc/sweep.hpp) — every one of the eight
     slots of both fused transports in use — on the one GPU there is: the 43 sums of every sweep on every
     rank are, word for word, the per-shard sums added in shard order (levenberg_marquadt_dyn.cpp:57-59
@@ -94,8 +95,9 @@ def test_eight_ranks_combine_through_the_library(hip_lib, tmp_path, world, proce
     peer slots takes identical iterates on all eight ranks and lands on the unsharded solution.
     (8, 4): 4 processes x 2 rank threads - IPC handles between processes and same-process pointers
     mixed; (8, 2): 4 rank threads per process; (4, 4): the threaded worker with one rank per process,
-    IPC only."""
-    res = run_thread_ranks(tmp_path, world, processes, 400_009)
+    IPC only; n_total = 10 M: BASELINE config 4's own sizes — 10 M correspondences in eight shards of
+    1.25 M — on the one GPU (what it lacks of config 4 is the seven other GPUs and RCCL)."""
+    res = run_thread_ranks(tmp_path, world, processes, n_total, timeout=900)
     for name in ("host", "peer"):
         for jm in (0, 2):
             for xi in range(3):
