@@ -113,6 +113,10 @@ def run(args):
         Subject("camera/b", mo.ReprojectionCost(pts[8000:], pix[8000:]),
                 mo.ReprojectionCost(pts[8000:], pix[8000:]), [mo.JAC_NUMERIC]),
         Subject("jit/p2p", jit_p2p(), jit_p2p(), [mo.JAC_NUMERIC]),
+        # three tiles: alone in a device-resident solve it is minimised by one launch of one workgroup —
+        # the moments-only kernel, or (forward differences under AUTO) the one that holds both forms (round 6)
+        Subject("p2p/small", mo.Point2PointCost(src[20000:21500], tgt[20000:21500]),
+                mo.Point2PointCost(src[20000:21500], tgt[20000:21500]), [mo.JAC_ANALYTIC, mo.JAC_NUMERIC]),
     ]
     # an ICP cost: its correspondences are a function of the last update(x); never queued ahead
     tgt_cloud = tgt[rng.permutation(len(tgt))[:12_000]]
@@ -195,12 +199,14 @@ def run(args):
             # sum is an ill-conditioned problem whose iterates amplify forward-difference noise)
             cameras = rng.random() < 0.4
             family = [g for g in pose if g.name.startswith("camera") == cameras and g.name != "icp"]
-            group = [family[i] for i in rng.permutation(len(family))[:rng.integers(1, len(family) + 1)]]
+            # (mopt_lm_minimize sums at most 4 costs)
+            group = [family[i] for i in rng.permutation(len(family))[:rng.integers(1, min(len(family), 4) + 1)]]
             modes = [g.jac_modes[-1] if g.name.startswith("camera") else g.jac_modes[0] for g in group]
             modes = [m if m != mo.JAC_ANALYTIC_LEFT else mo.JAC_ANALYTIC for m in modes]
             if not cameras and rng.random() < 0.5:
                 # the literally evaluated costs in forward differences: still one launch for the pair
-                modes = [mo.JAC_NUMERIC if g.name.startswith("p2p/literal") else m for g, m in zip(group, modes)]
+                modes = [mo.JAC_NUMERIC if g.name.startswith(("p2p/literal", "p2p/small")) else m
+                         for g, m in zip(group, modes)]
             # (the reprojection problem from within its basin: far from it the robust loss saturates and
             # the iterates become a noise amplifier, which compares rounding, not code paths)
             x0 = (np.array([-0.01, 0.02, -0.058, 0.018, -0.0013, 0.027]) + 0.003 * rng.standard_normal(6)
