@@ -1,0 +1,140 @@
+"""A second, independent restatement of the reference's linearization for the point-to-point model — numpy,
+vectorised over the correspondences, written from the reference's text and sharing no code with oracle/ —
+against the C++ oracle.  The reference holds no H / b vectors for point2point, so the 1e-6
+claim on J^T J / J^T r rests on the oracle being a faithful reading; two readings in two languages that
+agree to rounding on random inputs make a transcription slip (an index, a layout, a sign) in either
+visible.  What it cannot catch is a misreading common to both.
+
+Restated here (file:line of /root/reference):
+  so3::Exp                          src/so3.cpp:43-57 (Rodrigues, identity below 10 eps), skew: so3.h:4
+  convert6DOFParameterToMatrix      src/so3.cpp:7-19 (x = (t, w))
+  Point2Point::f / f_df             tst/point2point.cpp:32-78 (r = (T [p; 1])_{0..2} - q; the 18 Jacobian
+                                    numbers written through a column-major 3x6 map, :71-75)
+  CostComputation::computeHessian   include/moptimizer/linearization.h:126-158 (Jacobian buffer read
+                                    row-major, :17-18; H += w J^T S J, b += w J^T S r, sum += r^T r)
+  computeHessianNumerical           linearization.h:65-124 (h_j = sqrt(eps) |x_j|, or sqrt(eps) where
+                                    that is zero, :78-87; J.col(j) = (r+ - r) / h_j, :105)
+  GemmanMCClure::weight             loss_function/geman_mcclure.h:11-13
+"""
+import numpy as np
+import pytest
+
+from tests import datasets as ds
+from tests import oracle_binding as ob
+
+
+def exp_so3(w):
+    theta = np.linalg.norm(w)
+    if theta > 10.0 * np.finfo(np.float64).eps:
+        a = w / theta
+        K = np.array([[0.0, -a[2], a[1]], [a[2], 0.0, -a[0]], [-a[1], a[0], 0.0]])
+        return np.eye(3) + np.sin(theta) * K + (1.0 - np.cos(theta)) * (K @ K)
+    return np.eye(3)
+
+
+def transform_of(x):
+    T = np.eye(4)
+    T[:3, 3] = x[:3]
+    T[:3, :3] = exp_so3(np.asarray(x[3:6], dtype=np.float64))
+    return T
+
+
+def residuals(T, src, tgt):
+    hom = np.concatenate([src, np.ones((src.shape[0], 1))], axis=1)
+    return (hom @ T.T)[:, :3] - tgt
+
+
+def jacobians_as_read(src, layout):
+    """The 3 x 6 Jacobian of every correspondence as CostComputation reads it (row-major m x n).
+    row_major: the model writes [I | -skew(p)] row by row (model.h:35-42).
+    as written in tst/point2point.cpp:71-75: the same 18 numbers stored through a COLUMN-major 3x6 map,
+    then read row-major."""
+    n = src.shape[0]
+    J = np.zeros((n, 3, 6))
+    J[:, 0, 0] = J[:, 1, 1] = J[:, 2, 2] = 1.0
+    x, y, z = src[:, 0], src[:, 1], src[:, 2]
+    # -skew(p) = [[0, z, -y], [-z, 0, x], [y, -x, 0]]
+    J[:, 0, 4], J[:, 0, 5] = z, -y
+    J[:, 1, 3], J[:, 1, 5] = -z, x
+    J[:, 2, 3], J[:, 2, 4] = y, -x
+    if layout == "row_major":
+        return J
+    buffers = J.transpose(0, 2, 1).reshape(n, 18)  # column-major storage of the intended matrix
+    return buffers.reshape(n, 3, 6)                # ... read back row-major
+
+
+def loss_weights(rr, loss):
+    if loss is None:
+        return np.ones_like(rr)
+    return loss * loss / ((rr + loss) * (rr + loss))
+
+
+def accumulate(J, r, cov, loss):
+    rr = np.einsum("ia,ia->i", r, r)
+    w = loss_weights(rr, loss)
+    SJ = np.einsum("ab,ibj->iaj", cov, J)
+    H = np.einsum("i,iak,iaj->kj", w, J, SJ)
+    b = np.einsum("i,iak,ab,ib->k", w, J, cov, r)
+    return H, b, rr.sum()
+
+
+def linearize_analytic(src, tgt, x, layout, cov, loss):
+    return accumulate(jacobians_as_read(src, layout), residuals(transform_of(x), src, tgt), cov, loss)
+
+
+def linearize_numeric(src, tgt, x, cov, loss):
+    x = np.asarray(x, dtype=np.float64)
+    step = np.sqrt(np.finfo(np.float64).eps)
+    r = residuals(transform_of(x), src, tgt)
+    J = np.zeros((src.shape[0], 3, 6))
+    for j in range(6):
+        h = step * abs(x[j])
+        if h == 0.0:
+            h = step
+        xp = x.copy()
+        xp[j] += h
+        J[:, :, j] = (residuals(transform_of(xp), src, tgt) - r) / h
+    return accumulate(J, r, cov, loss)
+
+
+def rel(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / np.abs(np.asarray(b)).max()
+
+
+@pytest.fixture(scope="module")
+def clouds():
+    return ds.synthetic_pair(2003, seed=77, noise=0.02)
+
+
+@pytest.mark.parametrize("x", [ds.X_ZERO, ds.X_GENERIC, ds.X_GENERIC * 0.01], ids=["zero", "generic", "small"])
+@pytest.mark.parametrize("loss", [None, 50.0], ids=["noloss", "gm"])
+@pytest.mark.parametrize("cov", [np.eye(3), np.array([[2.0, 0.5, -0.1], [0.3, 1.5, 0.4], [-0.3, 0.2, 0.8]])],
+                         ids=["identity", "general"])
+def test_two_restatements_agree(oracle, clouds, x, loss, cov):
+    src, tgt = clouds
+    kw = dict(cov=cov, loss_kind=0 if loss is None else 1, loss_param=0.0 if loss is None else loss)
+    for layout, code in (("row_major", ob.LAYOUT_ROW_MAJOR), ("as_written", ob.LAYOUT_TST)):
+        H, b, s = linearize_analytic(src, tgt, x, layout, cov, loss)
+        Ho, bo, so = oracle.p2p_linearize(src, tgt, x, cost_class=ob.ANALYTIC_DYN, layout=code, **kw)
+        assert rel(H, Ho) < 1e-11 and rel(b, bo) < 1e-11 and abs(s - so) < 1e-11 * so, (layout, rel(H, Ho), rel(b, bo))
+    # forward differences: the two sides call different sin / cos and contract products differently, and a
+    # last-bit difference of a residual is amplified by eps / h_j in one Jacobian entry; over 2 k points
+    # the sums agree far inside the 1e-6 bar at every step size tried here
+    H, b, s = linearize_numeric(src, tgt, x, cov, loss)
+    Ho, bo, so = oracle.p2p_linearize(src, tgt, x, cost_class=ob.NUMERIC_DYN, **kw)
+    tol = 1e-6 if np.any((np.abs(x) > 0) & (np.abs(x) < 0.01)) else 1e-7
+    assert rel(H, Ho) < tol and rel(b, bo) < tol and abs(s - so) < 1e-11 * so, (rel(H, Ho), rel(b, bo))
+    assert abs(oracle.p2p_cost(src, tgt, x) - s) < 1e-11 * s
+
+
+def test_as_written_layout_has_the_zero_row_the_survey_describes(clouds):
+    """read row-major, the 18 numbers of tst/point2point.cpp:71-75 give
+    J_eff = [[1,0,0,0,1,0],[0,0,1,0,-z,y],[z,0,-x,-y,x,0]] — parameter 1 never moves a residual."""
+    src, _ = clouds
+    J = jacobians_as_read(src[:5], "as_written")
+    x, y, z = src[:5, 0], src[:5, 1], src[:5, 2]
+    want = np.zeros((5, 3, 6))
+    want[:, 0, 0] = want[:, 0, 4] = want[:, 1, 2] = 1.0
+    want[:, 1, 4], want[:, 1, 5] = -z, y
+    want[:, 2, 0], want[:, 2, 2], want[:, 2, 3], want[:, 2, 4] = z, -x, -y, x
+    assert np.array_equal(J, want) and not J[:, :, 1].any()
