@@ -15,6 +15,8 @@ Restated here (file:line of /root/reference):
   computeHessianNumerical           linearization.h:65-124 (h_j = sqrt(eps) |x_j|, or sqrt(eps) where
                                     that is zero, :78-87; J.col(j) = (r+ - r) / h_j, :105)
   GemmanMCClure::weight             loss_function/geman_mcclure.h:11-13
+  CameraModel                       tst/camera_calibration.cpp:12-41 (o = K T C P; r = pixel - (o0 / o2, o1 / o2);
+                                    K :29-30, C = Rx(pi/2) Rz(pi/2) :25-27; no Jacobian: forward differences only)
 """
 import numpy as np
 import pytest
@@ -138,3 +140,60 @@ def test_as_written_layout_has_the_zero_row_the_survey_describes(clouds):
     want[:, 1, 4], want[:, 1, 5] = -z, y
     want[:, 2, 0], want[:, 2, 2], want[:, 2, 3], want[:, 2, 4] = z, -x, -y, x
     assert np.array_equal(J, want) and not J[:, :, 1].any()
+
+
+# ---- the camera model of BASELINE config 5 ---------------------------------------------------------
+def axis_rotation(axis, angle):
+    c, s_ = np.cos(angle), np.sin(angle)
+    i, j = [(1, 2), (2, 0), (0, 1)][axis]
+    R = np.eye(3)
+    R[i, i], R[i, j], R[j, i], R[j, j] = c, -s_, s_, c
+    return R
+
+
+CAMERA_K = np.array([[586.122314453125, 0, 638.8477694496105, 0],
+                     [0, 722.3973388671875, 323.031267074588, 0],
+                     [0, 0, 1, 0]])                                   # camera_calibration.cpp:29-30
+CAMERA_C = np.eye(4)
+CAMERA_C[:3, :3] = axis_rotation(0, np.pi / 2) @ axis_rotation(2, np.pi / 2)   # :25-27
+
+
+def camera_residuals(x, pts, pix):
+    o = pts @ (CAMERA_K @ transform_of(x) @ CAMERA_C).T
+    return pix.astype(np.float64) - o[:, :2] / o[:, 2:3]
+
+
+def camera_linearize_numeric(x, pts, pix, cov, loss):
+    x = np.asarray(x, dtype=np.float64)
+    step = np.sqrt(np.finfo(np.float64).eps)
+    r = camera_residuals(x, pts, pix)
+    J = np.zeros((pts.shape[0], 2, 6))
+    for j in range(6):
+        h = step * abs(x[j]) or step
+        xp = x.copy()
+        xp[j] += h
+        J[:, :, j] = (camera_residuals(xp, pts, pix) - r) / h
+    return accumulate(J, r, cov, loss)
+
+
+@pytest.mark.parametrize("loss", [None, 100.0], ids=["noloss", "gm"])
+def test_two_restatements_of_the_camera_model_agree(oracle, loss):
+    """BASELINE config 5's residual (two outputs, numeric Jacobian only) under both readings: the same
+    H, b, cost at the Ceres solution the reference's test quotes and away from it.  Forward differences of
+    a projection in pixels (|o / o2| ~ 600, h_j = sqrt(eps) |x_j| down to 2e-11 at x_4 = -0.0013): one
+    Jacobian entry carries eps 600 / h ~ 1e-2 of rounding noise against a magnitude of ~ 1e3, a different
+    realisation for any two programs that round the chain K T C P differently (numpy's BLAS here, plain
+    loops in the oracle) — 4e-6 on the sums over 5 k elements.  That is the reading being compared, at the
+    noise two readings can agree to; the GPU kernel is held to the oracle's very bits instead (its chain
+    and its divisions spelled the same way: DESIGN.md §3 K4), and the cost, which has no quotient, agrees
+    to 1e-11 here."""
+    pts, pix = ds.synthetic_camera(5000, seed=9)
+    cov = np.array([[1.5, 0.2], [0.2, 0.7]])
+    for x in (np.array([-0.01, 0.02, -0.058, 0.018, -0.0013, 0.027]), np.array([0.05, -0.04, 0.03, 0.06, -0.05, 0.04])):
+        for c in (np.eye(2), cov):
+            H, b, s = camera_linearize_numeric(x, pts, pix, c, loss)
+            Ho, bo, so = oracle.camera_linearize(pts, pix, x, cov=c, loss_kind=0 if loss is None else 1,
+                                                 loss_param=0.0 if loss is None else loss)
+            assert rel(H, Ho) < 2e-5 and rel(b, bo) < 2e-5 and abs(s - so) < 1e-11 * so, (rel(H, Ho), rel(b, bo))
+            assert abs(oracle.camera_cost(pts, pix, x) - s) < 1e-11 * s
+
