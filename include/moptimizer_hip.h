@@ -119,8 +119,8 @@ enum mopt_kernel_variant {
                               for forward differences with some 0 < |x_j| < 0.08, where that
                               evaluation leaves the 1e-6 bar (it lacks the reference's own
                               per-point cancellation noise eps |R p + t| / h_j) and the literal
-                              evaluation is used.  That rule is the blocking and asynchronous
-                              calls'; the device-resident loop: as under AUTO                 */
+                              evaluation is used: in every call and at every point of the
+                              device-resident loop, as under AUTO                              */
   MOPT_KERNEL_MOMENTS_ALWAYS = 3 /* moments whatever the step size: for measurements; forward
                               differences then differ from the reference's by up to
                               2e-8 / min |x_j| relative (0.97 at |x_j| ~ 1e-8)                  */
@@ -434,7 +434,8 @@ MOPT_API int mopt_cost_get_combine(const mopt_cost *cost, int *combine_mode, int
  * reference's own test sizes) with fixed correspondences is minimised by ONE launch of one workgroup
  * that keeps the correspondences in registers and never leaves the kernel between points (same sums,
  * added in another order; MOPT_LM_ONE_LAUNCH_TILES=0 in the environment keeps the launch-per-point
- * form; `window` does not apply).
+ * form; `window` does not apply); where the forward-difference form is chosen per point
+ * (MOPT_KERNEL_AUTO / _MOMENTS with MOPT_JAC_NUMERIC) that kernel holds both forms.
  *
  * costs / jacobian_modes: the costs of Optimizer::addCost (optimizer.h:58) with the Jacobian mode
  * of each (the cost class the caller would have used), at most 4, same device / scalar type / n;
